@@ -1,0 +1,265 @@
+// Flash-style attention for gfx950 (see attention.h).
+//
+// One workgroup = 4 wave64 = 128 queries of one (batch, head); each wave owns 32 queries.
+// Everything is computed TRANSPOSED so that softmax statistics are lane-local:
+//   S^T[key][q] = K . Q^T      (MFMA A = K rows from LDS, B = Q rows held in registers)
+//   O^T[d][q]  += V^T . P^T    (MFMA A = V^T rows from LDS, B = P^T straight from the S^T registers)
+// The MFMA C/D layout gives lane (q = lane&31, h = lane>>5) the scores of query q against
+// 16 of each 32 keys, which is exactly the B-operand layout the second MFMA needs (the key
+// order inside a k-step is a free permutation as long as V^T is read with the same one),
+// so P never leaves registers and the running max / rescale factor is one scalar per lane.
+#include "attention.h"
+#include "gemm.h"  // DT_*
+
+namespace roma {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+template <int HD, typename TOUT>
+__global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a) {
+  constexpr int KV = (HD == 64) ? 64 : 32;
+  constexpr int KS = HD + 4, VS = KV + 4;
+  constexpr int KT = KV / 32, DT = HD / 32, G = HD / 8;
+  __shared__ __attribute__((aligned(16))) float Ks[KV * KS];
+  __shared__ __attribute__((aligned(16))) float Vs[HD * VS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const long bh = (long)b * a.heads + head;
+  const int qi = blockIdx.x * 128 + wave * 32 + l31;
+  const float* Q = reinterpret_cast<const float*>(a.q) + (bh * a.npad) * HD;
+  const float* K = reinterpret_cast<const float*>(a.k) + (bh * a.npad) * HD;
+  const float* Vt = reinterpret_cast<const float*>(a.vt) + (bh * HD) * a.npad;
+
+  f32x4 qf[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) qf[g] = *reinterpret_cast<const f32x4*>(Q + (long)qi * HD + 8 * g + 4 * h);
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kv0 = 0; kv0 < a.N; kv0 += KV) {
+    // ---- stage K tile [KV][HD] and V^T tile [HD][KV]
+    for (int idx = tid; idx < KV * (HD / 4); idx += 256) {
+      const int row = idx / (HD / 4), c4 = idx % (HD / 4);
+      *reinterpret_cast<f32x4*>(&Ks[row * KS + c4 * 4]) =
+          *reinterpret_cast<const f32x4*>(K + (long)(kv0 + row) * HD + c4 * 4);
+    }
+    for (int idx = tid; idx < HD * (KV / 4); idx += 256) {
+      const int row = idx / (KV / 4), c4 = idx % (KV / 4);
+      *reinterpret_cast<f32x4*>(&Vs[row * VS + c4 * 4]) =
+          *reinterpret_cast<const f32x4*>(Vt + (long)row * a.npad + kv0 + c4 * 4);
+    }
+    __syncthreads();
+    // ---- S^T = K Q^T
+    f32x16 s[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[(32 * kt + l31) * KS + 8 * g + 4 * h]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[g][j], s[kt], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (per query = per lane column)
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float sv = key < a.N ? s[kt][r] : -INFINITY;
+        s[kt][r] = sv;
+        tmax = fmaxf(tmax, sv);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = expf(m_run - m_new);
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = expf(s[kt][r] - m_new);
+        s[kt][r] = p;
+        lsum += p;
+      }
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const f32x4 vf = *reinterpret_cast<const f32x4*>(&Vs[(32 * d + l31) * VS + 32 * kt + 8 * rg + 4 * h]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j], s[kt][4 * rg + j], o[d], 0, 0, 0);
+        }
+    __syncthreads();
+  }
+  l_run += __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_run;
+  if (qi < a.N) {
+    TOUT* O = reinterpret_cast<TOUT*>(a.out) + ((long)b * a.N + qi) * a.ldo + head * HD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = o[d][4 * rg + j] * inv;
+        ElemIO<TOUT>::st4(O + 32 * d + 8 * rg + 4 * h, v);
+      }
+  }
+}
+
+// bf16 inputs, f32 softmax/accumulate; v_mfma_f32_32x32x16_bf16.
+template <int HD, typename TOUT>
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
+  constexpr int KV = 64;
+  constexpr int KS = HD + 8, VS = KV + 8;  // bf16 elements per LDS row
+  constexpr int KT = KV / 32, DT = HD / 32, NS = HD / 16;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[KV * KS];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[HD * VS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const long bh = (long)b * a.heads + head;
+  const int qi = blockIdx.x * 128 + wave * 32 + l31;
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (bh * a.npad) * HD;
+  const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (bh * a.npad) * HD;
+  const bf16_t* Vt = reinterpret_cast<const bf16_t*>(a.vt) + (bh * HD) * a.npad;
+
+  uint4 qf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const uint4*>(Q + (long)qi * HD + 16 * s + 8 * h);
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kv0 = 0; kv0 < a.N; kv0 += KV) {
+    for (int idx = tid; idx < KV * (HD / 8); idx += 256) {
+      const int row = idx / (HD / 8), c8 = idx % (HD / 8);
+      *reinterpret_cast<uint4*>(&Ks[row * KS + c8 * 8]) =
+          *reinterpret_cast<const uint4*>(K + (long)(kv0 + row) * HD + c8 * 8);
+    }
+    for (int idx = tid; idx < HD * (KV / 8); idx += 256) {
+      const int row = idx / (KV / 8), c8 = idx % (KV / 8);
+      *reinterpret_cast<uint4*>(&Vs[row * VS + c8 * 8]) =
+          *reinterpret_cast<const uint4*>(Vt + (long)row * a.npad + kv0 + c8 * 8);
+    }
+    __syncthreads();
+    f32x16 s[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(&Ks[(32 * kt + l31) * KS + 16 * st + 8 * h]);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
+                                                        __builtin_bit_cast(bf16x8_t, qf[st]), s[kt], 0, 0, 0);
+      }
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float sv = key < a.N ? s[kt][r] : -INFINITY;
+        s[kt][r] = sv;
+        tmax = fmaxf(tmax, sv);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __expf(m_run - m_new);
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __expf(s[kt][r] - m_new);
+        s[kt][r] = p;
+        lsum += p;
+      }
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        uint4 pk;
+        pk.x = (uint32_t)f32_to_bf16(s[kt][8 * u + 0]) | ((uint32_t)f32_to_bf16(s[kt][8 * u + 1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16(s[kt][8 * u + 2]) | ((uint32_t)f32_to_bf16(s[kt][8 * u + 3]) << 16);
+        pk.z = (uint32_t)f32_to_bf16(s[kt][8 * u + 4]) | ((uint32_t)f32_to_bf16(s[kt][8 * u + 5]) << 16);
+        pk.w = (uint32_t)f32_to_bf16(s[kt][8 * u + 6]) | ((uint32_t)f32_to_bf16(s[kt][8 * u + 7]) << 16);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const bf16_t* vrow = &Vs[(32 * d + l31) * VS + 32 * kt + 16 * u + 4 * h];
+          const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+          const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 8);
+          const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
+                                                         __builtin_bit_cast(bf16x8_t, pk), o[d], 0, 0, 0);
+        }
+      }
+    __syncthreads();
+  }
+  l_run += __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_run;
+  if (qi < a.N) {
+    TOUT* O = reinterpret_cast<TOUT*>(a.out) + ((long)b * a.N + qi) * a.ldo + head * HD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = o[d][4 * rg + j] * inv;
+        ElemIO<TOUT>::st4(O + 32 * d + 8 * rg + 4 * h, v);
+      }
+  }
+}
+
+int attention_launch(const AttnArgs& a, hipStream_t stream) {
+  ROMA_REQUIRE(a.hd == 64 || a.hd == 128, "attention: head dim must be 64 or 128");
+  ROMA_REQUIRE(a.npad % 128 == 0 && a.npad >= a.N, "attention: Npad must be a multiple of 128 and >= N");
+  ROMA_REQUIRE(a.ldo % 4 == 0, "attention: ldo must be a multiple of 4");
+  dim3 grid((unsigned)((a.N + 127) / 128), (unsigned)a.heads, (unsigned)a.B);
+#define ROMA_ATTN(KERNEL, HDV, TOUT) hipLaunchKernelGGL((KERNEL<HDV, TOUT>), grid, dim3(256), 0, stream, a)
+  if (a.in_dt == DT_F32) {
+    if (a.hd == 64) { if (a.out_dt == DT_F32) ROMA_ATTN(attn_f32_kernel, 64, float); else ROMA_ATTN(attn_f32_kernel, 64, bf16_t); }
+    else            { if (a.out_dt == DT_F32) ROMA_ATTN(attn_f32_kernel, 128, float); else ROMA_ATTN(attn_f32_kernel, 128, bf16_t); }
+  } else {
+    if (a.hd == 64) { if (a.out_dt == DT_F32) ROMA_ATTN(attn_bf16_kernel, 64, float); else ROMA_ATTN(attn_bf16_kernel, 64, bf16_t); }
+    else            { if (a.out_dt == DT_F32) ROMA_ATTN(attn_bf16_kernel, 128, float); else ROMA_ATTN(attn_bf16_kernel, 128, bf16_t); }
+  }
+#undef ROMA_ATTN
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace roma

@@ -1,0 +1,47 @@
+// MFMA GEMM family:  C[M,N] = epilogue( alpha * A[M,K] . W[N,K]^T )   (both operands K-contiguous)
+//   * f32 inputs  -> v_mfma_f32_32x32x2_f32   (exact f32, parity mode)
+//   * bf16 inputs -> v_mfma_f32_32x32x16_bf16 (throughput mode), f32 accumulate
+//   * A may be an implicit im2col view of an NHWC tensor (3x3, pad 1)  -> VGG convolutions
+//   * epilogues: bias / activation / per-column scale / residual, QKV head scatter (+V transposed),
+//     cosine-kernel Gram matrix (GP), alpha=-1 accumulate (Cholesky trailing update / TRSM).
+#pragma once
+#include "common.h"
+
+namespace roma {
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+enum { EPI_STD = 0, EPI_QKV = 1, EPI_COSK = 2 };
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+struct GemmArgs {
+  const void* A = nullptr;  // [M,K] (lda) or NHWC tensor when conv_c > 0
+  const void* W = nullptr;  // [N,K] (ldw)
+  void* C = nullptr;        // [M,N] (ldc)
+  long lda = 0, ldw = 0, ldc = 0;
+  long sA = 0, sW = 0, sC = 0;  // batch strides in elements
+  int M = 0, N = 0, K = 0, batch = 1;
+  int in_dt = DT_F32, out_dt = DT_F32;
+  float alpha = 1.f;
+  const float* bias = nullptr;   // [N]
+  const float* scale = nullptr;  // [N]
+  const float* res = nullptr;    // f32 [M,N] (ldr), may alias C when C is f32
+  long ldr = 0, sR = 0;
+  int act = ACT_NONE;
+  int mode = EPI_STD;
+  int lower_only = 0;  // skip tiles strictly above the diagonal (square problems)
+  // implicit 3x3 convolution view of A (NHWC, pad 1); M = B*H*W, K = 9*conv_c
+  int conv_h = 0, conv_w = 0, conv_c = 0;
+  // EPI_QKV
+  void *q = nullptr, *k = nullptr, *vt = nullptr;
+  int heads = 0, hd = 0, ntok = 0, npad = 0;
+  float qscale = 1.f;
+  // EPI_COSK:  exp((acc/(nx[m]*ny[n]+1e-6) - 1) * inv_t) (+ diag_add on m==n)
+  const float *nx = nullptr, *ny = nullptr;
+  long sNx = 0, sNy = 0;
+  float inv_t = 0.f, diag_add = 0.f;
+};
+
+// Launches on `stream`; returns 0 or a negative error code (message via roma_last_error()).
+int gemm_launch(const GemmArgs& a, hipStream_t stream);
+
+}  // namespace roma

@@ -1,0 +1,176 @@
+"""Seeded synthetic state-dicts and inputs (no pretrained weights exist offline).
+
+Key / shape contract = the reference's strict `load_state_dict` contract
+(romatch/models/model_zoo/roma_models.py:204; DINOv2 dict romatch/models/encoders.py:42-43),
+pinned by tests/golden/state_dict_contract.json which was dumped from the reference itself.
+
+Everything is drawn from numpy's PCG64 `Generator` (stream-stable across machines, unlike
+vectorised torch CPU normals), so the build container (where goldens are made from the real
+reference) and the GPU box (where the HIP path and the oracle run) see bit-identical tensors.
+
+The scales are chosen so that the random network is *numerically well posed* for parity:
+  * He/Xavier-like fan-in scaling keeps activations O(1) through ~60 sequential layers;
+  * BatchNorm running stats / affine are non-trivial (so BN folding is actually exercised);
+  * `to_out` is amplified so the 4096-way class logits are peaked: default-init weights give a
+    nearly flat softmax whose arg-max (romatch/utils/utils.py:315) flips on 1e-8 perturbations
+    (hard part 1).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+VGG_CONV_IDX = [0, 3, 7, 10, 14, 17, 20, 23, 27, 30, 33, 36]
+VGG_CHANNELS = [64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512]
+
+# (in_dim == hidden_dim, displacement_emb_dim, local_corr_radius) per refiner scale
+# romatch/models/model_zoo/roma_models.py:103-139
+REFINER_CFG = OrderedDict([
+    ("16", dict(feat=512, emb=128, radius=7)),
+    ("8", dict(feat=512, emb=64, radius=3)),
+    ("4", dict(feat=256, emb=32, radius=2)),
+    ("2", dict(feat=64, emb=16, radius=0)),
+    ("1", dict(feat=9, emb=6, radius=0)),
+])
+# proj heads: scale -> (cin, cout); roma_models.py:156-160
+PROJ_CFG = OrderedDict([("16", (1024, 512)), ("8", (512, 512)), ("4", (256, 256)),
+                        ("2", (128, 64)), ("1", (64, 9))])
+
+
+def refiner_dim(scale: str) -> int:
+    c = REFINER_CFG[scale]
+    k = (2 * c["radius"] + 1) ** 2 if c["radius"] else 0
+    return 2 * c["feat"] + c["emb"] + k
+
+
+class _Rng:
+    def __init__(self, seed: int):
+        self.g = np.random.Generator(np.random.PCG64(seed))
+
+    def normal(self, shape, std=1.0):
+        a = self.g.standard_normal(size=shape, dtype=np.float32)
+        if std != 1.0:
+            a *= np.float32(std)
+        return torch.from_numpy(a)
+
+    def uniform(self, shape, lo, hi):
+        a = self.g.random(size=shape, dtype=np.float32)
+        a = a * np.float32(hi - lo) + np.float32(lo)
+        return torch.from_numpy(a)
+
+
+def _bn(sd, rng, prefix, c):
+    sd[prefix + ".weight"] = rng.uniform((c,), 0.8, 1.2)
+    sd[prefix + ".bias"] = rng.normal((c,), 0.1)
+    sd[prefix + ".running_mean"] = rng.normal((c,), 0.1)
+    sd[prefix + ".running_var"] = rng.uniform((c,), 0.8, 1.25)
+    sd[prefix + ".num_batches_tracked"] = torch.tensor(1000, dtype=torch.int64)
+
+
+def make_matcher_state_dict(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """603 tensors / 111.36 M parameters."""
+    rng = _Rng(seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    # --- VGG19-BN features[:40]  (romatch/models/encoders.py:13)
+    cin = 3
+    for idx, cout in zip(VGG_CONV_IDX, VGG_CHANNELS):
+        sd[f"encoder.cnn.layers.{idx}.weight"] = rng.normal((cout, cin, 3, 3), math.sqrt(2.0 / (9 * cin)))
+        sd[f"encoder.cnn.layers.{idx}.bias"] = rng.normal((cout,), 0.05)
+        _bn(sd, rng, f"encoder.cnn.layers.{idx + 1}", cout)
+        cin = cout
+    # --- transformer decoder (roma_models.py:75-84): 5 x Block(1024, 8 heads), no qkv bias
+    D = 1024
+    for i in range(5):
+        p = f"decoder.embedding_decoder.blocks.{i}"
+        sd[p + ".norm1.weight"] = rng.uniform((D,), 0.8, 1.2)
+        sd[p + ".norm1.bias"] = rng.normal((D,), 0.05)
+        sd[p + ".attn.qkv.weight"] = rng.normal((3 * D, D), 1.5 / math.sqrt(D))
+        sd[p + ".attn.proj.weight"] = rng.normal((D, D), 0.5 / math.sqrt(D))
+        sd[p + ".attn.proj.bias"] = rng.normal((D,), 0.02)
+        sd[p + ".norm2.weight"] = rng.uniform((D,), 0.8, 1.2)
+        sd[p + ".norm2.bias"] = rng.normal((D,), 0.05)
+        sd[p + ".mlp.fc1.weight"] = rng.normal((4 * D, D), 1.0 / math.sqrt(D))
+        sd[p + ".mlp.fc1.bias"] = rng.normal((4 * D,), 0.02)
+        sd[p + ".mlp.fc2.weight"] = rng.normal((D, 4 * D), 0.5 / math.sqrt(4 * D))
+        sd[p + ".mlp.fc2.bias"] = rng.normal((D,), 0.02)
+    # peaked class logits (see module docstring)
+    w_out = rng.normal((64 * 64 + 1, D), 0.25)
+    w_out[-1] *= 0.1  # certainty logit row: keep sigmoid(certainty) in its sensitive range
+    sd["decoder.embedding_decoder.to_out.weight"] = w_out
+    sd["decoder.embedding_decoder.to_out.bias"] = rng.normal((64 * 64 + 1,), 0.1)
+    # --- GP (matcher.py:222): Conv2d(2, 512, 1)
+    sd["decoder.gps.16.pos_conv.weight"] = rng.normal((512, 2, 1, 1), 0.5)
+    sd["decoder.gps.16.pos_conv.bias"] = rng.normal((512,), 0.5)
+    # --- proj heads
+    for s, (ci, co) in PROJ_CFG.items():
+        sd[f"decoder.proj.{s}.0.weight"] = rng.normal((co, ci, 1, 1), 1.0 / math.sqrt(ci))
+        sd[f"decoder.proj.{s}.0.bias"] = rng.normal((co,), 0.05)
+        _bn(sd, rng, f"decoder.proj.{s}.1", co)
+    # --- ConvRefiners (matcher.py:92-122; roma_models.py:85-139)
+    for s in REFINER_CFG:
+        C = refiner_dim(s)
+        p = f"decoder.conv_refiner.{s}"
+
+        def block(bp):
+            sd[bp + ".0.weight"] = rng.normal((C, 1, 5, 5), math.sqrt(2.0 / 25.0) * 0.7)
+            sd[bp + ".0.bias"] = rng.normal((C,), 0.05)
+            _bn(sd, rng, bp + ".1", C)
+            sd[bp + ".3.weight"] = rng.normal((C, C, 1, 1), math.sqrt(2.0 / C) * 0.7)
+            sd[bp + ".3.bias"] = rng.normal((C,), 0.05)
+
+        block(p + ".block1")
+        for hb in range(8):
+            block(p + f".hidden_blocks.{hb}")
+        sd[p + ".out_conv.weight"] = rng.normal((3, C, 1, 1), 1.0 / math.sqrt(C))
+        sd[p + ".out_conv.bias"] = rng.normal((3,), 0.05)
+        e = REFINER_CFG[s]["emb"]
+        sd[p + ".disp_emb.weight"] = rng.normal((e, 2, 1, 1), 0.7)
+        sd[p + ".disp_emb.bias"] = rng.normal((e,), 0.1)
+    return sd
+
+
+def make_dinov2_state_dict(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """343 tensors / 304.37 M parameters: DINOv2 ViT-L/14 (transformer/dinov2.py:333-343)."""
+    rng = _Rng(seed + 7919)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    D = 1024
+    sd["cls_token"] = rng.normal((1, 1, D), 0.5)
+    sd["pos_embed"] = rng.normal((1, 1 + 37 * 37, D), 0.5)
+    sd["mask_token"] = torch.zeros(1, D)
+    sd["patch_embed.proj.weight"] = rng.normal((D, 3, 14, 14), 1.0 / math.sqrt(3 * 14 * 14))
+    sd["patch_embed.proj.bias"] = rng.normal((D,), 0.05)
+    for i in range(24):
+        p = f"blocks.{i}"
+        sd[p + ".norm1.weight"] = rng.uniform((D,), 0.8, 1.2)
+        sd[p + ".norm1.bias"] = rng.normal((D,), 0.05)
+        sd[p + ".attn.qkv.weight"] = rng.normal((3 * D, D), 1.5 / math.sqrt(D))
+        sd[p + ".attn.qkv.bias"] = rng.normal((3 * D,), 0.05)
+        sd[p + ".attn.proj.weight"] = rng.normal((D, D), 1.0 / math.sqrt(D))
+        sd[p + ".attn.proj.bias"] = rng.normal((D,), 0.02)
+        sd[p + ".ls1.gamma"] = rng.uniform((D,), 0.05, 0.3)
+        sd[p + ".norm2.weight"] = rng.uniform((D,), 0.8, 1.2)
+        sd[p + ".norm2.bias"] = rng.normal((D,), 0.05)
+        sd[p + ".mlp.fc1.weight"] = rng.normal((4 * D, D), 1.0 / math.sqrt(D))
+        sd[p + ".mlp.fc1.bias"] = rng.normal((4 * D,), 0.02)
+        sd[p + ".mlp.fc2.weight"] = rng.normal((D, 4 * D), 1.0 / math.sqrt(4 * D))
+        sd[p + ".mlp.fc2.bias"] = rng.normal((D,), 0.02)
+        sd[p + ".ls2.gamma"] = rng.uniform((D,), 0.05, 0.3)
+    sd["norm.weight"] = rng.uniform((D,), 0.8, 1.2)
+    sd["norm.bias"] = rng.normal((D,), 0.05)
+    return sd
+
+
+def make_inputs(batch: int, coarse_res, upsample_res=None, seed: int = 1):
+    """Standard-normal images exactly as the reference's timing script feeds them
+    (tests/test_roma_upsample_inference_time.py:9-12), but from the portable generator."""
+    rng = _Rng(seed)
+    ch, cw = (coarse_res, coarse_res) if isinstance(coarse_res, int) else coarse_res
+    out = {"im_A": rng.normal((batch, 3, ch, cw)), "im_B": rng.normal((batch, 3, ch, cw))}
+    if upsample_res is not None:
+        uh, uw = (upsample_res, upsample_res) if isinstance(upsample_res, int) else upsample_res
+        out["im_A_high_res"] = rng.normal((batch, 3, uh, uw))
+        out["im_B_high_res"] = rng.normal((batch, 3, uh, uw))
+    return out

@@ -1,0 +1,175 @@
+"""Generate tests/golden/* by running the UNMODIFIED reference (/root/reference) on CPU.
+
+Build-container only (needs /root/reference; see tools/ref_import.py).  The committed
+fixtures are what travels to the GPU box.  Usage:
+
+    python tools/make_goldens.py contract      # state-dict key/shape contract
+    python tools/make_goldens.py ops           # operator-level goldens from reference functions
+    python tools/make_goldens.py tiny          # match() 112 -> 168, B=1 symmetric (+ stage tensors)
+    python tools/make_goldens.py small         # match() 224 -> 336, B=2, non-symmetric and symmetric coarse-only
+    python tools/make_goldens.py full          # match() 560 -> 864, B=1 symmetric (sub-sampled)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from ref_import import install_stubs, build_reference_matcher  # noqa: E402
+from roma_amd import synthetic  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+
+
+def np32(t):
+    return t.detach().float().contiguous().numpy()
+
+
+def contract():
+    install_stubs()
+    from romatch.models.transformer import vit_large
+    from romatch.models.model_zoo import roma_models as rm
+    d = vit_large(img_size=518, patch_size=14, init_values=1.0, ffn_layer="mlp", block_chunks=0).state_dict()
+    orig = rm.RegressionMatcher.load_state_dict
+    rm.RegressionMatcher.load_state_dict = lambda self, w, **k: None
+    m = rm.roma_model(resolution=(112, 112), upsample_preds=True, device="cpu", weights=None,
+                      dinov2_weights=d, upsample_res=(168, 168), use_custom_corr=False)
+    rm.RegressionMatcher.load_state_dict = orig
+    out = {"matcher": {k: list(v.shape) for k, v in m.state_dict().items()},
+           "dinov2": {k: list(v.shape) for k, v in d.items()}}
+    with open(os.path.join(GOLD, "state_dict_contract.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("contract:", len(out["matcher"]), len(out["dinov2"]))
+
+
+def ops():
+    """Operator goldens straight from reference functions/modules (no match())."""
+    install_stubs()
+    from romatch.utils.local_correlation import local_correlation
+    from romatch.utils.utils import cls_to_flow_refine
+    g = np.random.Generator(np.random.PCG64(123))
+
+    def rn(*s, std=1.0):
+        return torch.from_numpy(g.standard_normal(size=s, dtype=np.float32) * np.float32(std))
+
+    out = {}
+    # local correlation: (r, C, h, w) small versions of the three real configurations
+    for name, (r, C, h, w) in {"lc_r7": (7, 64, 10, 12), "lc_r3": (3, 128, 14, 14), "lc_r2": (2, 32, 20, 24)}.items():
+        B = 2
+        f0, f1 = rn(B, C, h, w), rn(B, C, h, w)
+        ys = torch.linspace(-1 + 1 / h, 1 - 1 / h, h)
+        xs = torch.linspace(-1 + 1 / w, 1 - 1 / w, w)
+        gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+        grid = torch.stack((gx, gy))[None].expand(B, 2, h, w)
+        warp = grid + rn(B, 2, h, w, std=0.35)          # includes out-of-range taps (zero padding)
+        warp[0, :, 0, 0] = torch.tensor([-1.7, 0.2])       # far outside
+        warp[0, :, 0, 1] = torch.tensor([1.0 - 1.0 / w, -1.0 + 1.0 / h])  # exact pixel centre (integer coords)
+        corr = local_correlation(f0, f1, r, warp, use_custom_corr=False)
+        out[name + "_f0"], out[name + "_f1"], out[name + "_warp"], out[name + "_corr"] = map(np32, (f0, f1, warp, corr))
+    # cls_to_flow_refine
+    cls = rn(2, 4096, 6, 5, std=3.0)
+    cls[0, 0, 0, 0] = 40.0      # mode at class 0   (clamped neighbours)
+    cls[0, 4095, 0, 1] = 40.0   # mode at last class
+    cls[0, 63, 0, 2] = 40.0     # row wrap-around neighbour
+    out["c2f_cls"], out["c2f_flow"] = np32(cls), np32(cls_to_flow_refine(cls))
+    np.savez_compressed(os.path.join(GOLD, "ops_reference.npz"), **out)
+    print("ops:", {k: v.shape for k, v in out.items()})
+
+
+def _run_reference(cfg_name, coarse, up, B, symmetric, upsample_preds, seed_w, seed_in, capture=True):
+    sd = synthetic.make_matcher_state_dict(seed_w)
+    dsd = synthetic.make_dinov2_state_dict(seed_w)
+    m = build_reference_matcher(sd, dsd, (coarse, coarse), (up, up), symmetric=symmetric,
+                                upsample_preds=upsample_preds)
+    inp = synthetic.make_inputs(B, coarse, up if upsample_preds else None, seed=seed_in)
+    stages = {}
+    if capture:
+        calls = {"n": 0}
+
+        def hook_ref(scale):
+            def fn(mod, args, out):
+                k = calls.get(("cnt", scale), 0)
+                calls[("cnt", scale)] = k + 1
+                stages[f"ref{scale}_call{k}_dflow"] = np32(out[0])
+                stages[f"ref{scale}_call{k}_dcert"] = np32(out[1])
+            return fn
+
+        for s in ["16", "8", "4", "2", "1"]:
+            m.decoder.conv_refiner[s].register_forward_hook(hook_ref(s))
+        def gp_hook(mod, a, o):
+            stages["gp16"] = np32(o)
+        m.decoder.gps["16"].register_forward_hook(gp_hook)
+
+        def tdec_hook(mod, a, o):
+            stages["cls16_argmax"] = o[0].argmax(dim=1).numpy().astype(np.int32)
+            top2 = o[0].topk(2, dim=1).values
+            stages["cls16_top2gap"] = np32(top2[:, 0] - top2[:, 1])
+            stages["gm_cert16"] = np32(o[1])
+        m.decoder.embedding_decoder.register_forward_hook(tdec_hook)
+        def proj_hook(mod, a, o):
+            if "proj16_first" not in stages:
+                stages["proj16_first"] = np32(o)
+        m.decoder.proj["16"].register_forward_hook(proj_hook)
+    t = time.time()
+    kw = {}
+    if upsample_preds:
+        kw = dict(im_A_high_res=inp["im_A_high_res"], im_B_high_res=inp["im_B_high_res"])
+    warp, cert = m.match(inp["im_A"], inp["im_B"], **kw)
+    dt = time.time() - t
+    print(f"{cfg_name}: reference match() {dt:.1f}s  warp {tuple(warp.shape)} cert {tuple(cert.shape)}")
+    return warp, cert, stages, dt
+
+
+def tiny():
+    warp, cert, stages, dt = _run_reference("tiny", 112, 168, 1, True, True, 0, 1)
+    np.savez_compressed(os.path.join(GOLD, "match_tiny.npz"), warp=np32(warp), certainty=np32(cert), **stages)
+    meta = dict(coarse=112, up=168, B=1, symmetric=True, upsample_preds=True, seed_w=0, seed_in=1,
+                min_top2_gap=float(stages["cls16_top2gap"].min()), ref_seconds=dt,
+                torch=torch.__version__)
+    json.dump(meta, open(os.path.join(GOLD, "match_tiny.json"), "w"), indent=1)
+    print(meta)
+
+
+def small():
+    out = {}
+    warp, cert, st, _ = _run_reference("small_nonsym", 224, 336, 2, False, True, 3, 4)
+    out["nonsym_warp"], out["nonsym_cert"] = np32(warp)[:, ::3, ::3], np32(cert)[:, ::3, ::3]
+    out["nonsym_gap"] = st["cls16_top2gap"]
+    warp, cert, st, _ = _run_reference("small_coarse_sym", 224, 336, 2, True, False, 3, 4)
+    out["coarse_warp"], out["coarse_cert"] = np32(warp)[:, ::3, ::3], np32(cert)[:, ::3, ::3]
+    out["coarse_gap"] = st["cls16_top2gap"]
+    np.savez_compressed(os.path.join(GOLD, "match_small.npz"), **out)
+    meta = dict(coarse=224, up=336, B=2, seed_w=3, seed_in=4, subsample=3,
+                min_gap_nonsym=float(out["nonsym_gap"].min()), min_gap_coarse=float(out["coarse_gap"].min()))
+    json.dump(meta, open(os.path.join(GOLD, "match_small.json"), "w"), indent=1)
+    print(meta)
+
+
+def full():
+    torch.set_num_threads(os.cpu_count())
+    warp, cert, st, dt = _run_reference("full", 560, 864, 1, True, True, 0, 1)
+    w, c = np32(warp), np32(cert)
+    out = dict(warp_sub=w[:, ::8, ::8], cert_sub=c[:, ::8, ::8],
+               warp_rowsum=w.sum(axis=(2, 3), dtype=np.float64), cert_rowsum=c.sum(axis=2, dtype=np.float64),
+               cls16_argmax=st["cls16_argmax"], cls16_top2gap=st["cls16_top2gap"], gm_cert16=st["gm_cert16"],
+               gp16_sub=st["gp16"][:, ::8])
+    for k, v in st.items():
+        if k.startswith("ref") and v.size <= 200000:
+            out[k] = v
+    np.savez_compressed(os.path.join(GOLD, "match_full.npz"), **out)
+    meta = dict(coarse=560, up=864, B=1, symmetric=True, seed_w=0, seed_in=1, subsample=8,
+                min_top2_gap=float(st["cls16_top2gap"].min()), ref_seconds=dt,
+                threads=torch.get_num_threads(), torch=torch.__version__)
+    json.dump(meta, open(os.path.join(GOLD, "match_full.json"), "w"), indent=1)
+    print(meta)
+
+
+if __name__ == "__main__":
+    for what in sys.argv[1:]:
+        {"contract": contract, "ops": ops, "tiny": tiny, "small": small, "full": full}[what]()
