@@ -1,0 +1,103 @@
+/* libroma_hip - C ABI of the MI355X-native RoMa dense-matching path.
+ *
+ * The reference (Parskatt/RoMa) is pure Python; the interfaces this library replaces are
+ *   - romatch/models/model_zoo/__init__.py:31-93  roma_outdoor / roma_indoor factories
+ *                                                 -> roma_create / roma_set_tensor / roma_finalize
+ *   - romatch/models/model_zoo/roma_models.py:204 strict load_state_dict       -> roma_set_tensor + roma_finalize
+ *   - romatch/models/matcher.py:779-934           RegressionMatcher.match()    -> roma_match
+ *   - romatch/utils/local_correlation.py:22-35    local_corr.local_corr(...) (external fused-local-corr wheel)
+ *                                                 -> roma_op_local_corr (plugin signature),
+ *                                                    roma_op_local_corr_window (what local_correlation():77-143 needs)
+ * plus per-operator entry points so that every kernel can be parity-tested alone.
+ *
+ * Conventions: plain pointers and sizes only; all tensor pointers are DEVICE pointers unless
+ * stated otherwise; `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ * asynchronous on that stream; return 0 on success, negative on error (text: roma_last_error()).
+ * One handle per device, one in-flight roma_match per handle (the reference's single-caller model).
+ */
+#ifndef ROMA_HIP_H
+#define ROMA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct roma_model* roma_handle_t;
+
+enum { ROMA_F32 = 0, ROMA_BF16 = 1 };            /* arithmetic / storage type of activations */
+enum { ROMA_ERR_ARG = -1, ROMA_ERR_HIP = -2, ROMA_ERR_STATE = -3 };
+
+typedef struct {
+  int coarse_h, coarse_w;     /* multiples of 14 (DINOv2 patch) and of 8 (VGG pyramid)            */
+  int upsample_h, upsample_w; /* multiples of 8; used when upsample_preds != 0                     */
+  int symmetric;              /* matcher.py:801   */
+  int upsample_preds;         /* matcher.py:836   */
+  int attenuate_cert;         /* matcher.py:839   */
+  int precision;              /* ROMA_F32 (exact f32 MFMA; CPU-oracle parity) or ROMA_BF16          */
+  int max_batch;              /* largest number of image pairs per roma_match call                 */
+  int device;                 /* HIP device ordinal                                                */
+} roma_config_t;
+
+const char* roma_last_error(void);
+const char* roma_version(void);
+
+int roma_create(const roma_config_t* cfg, roma_handle_t* out);
+/* name: a key of the reference's matcher state-dict, or "dinov2." + a key of the DINOv2 dict.
+ * data: HOST pointer to float32 (int64 for num_batches_tracked, ignored). The library copies. */
+int roma_set_tensor(roma_handle_t h, const char* name, int ndim, const int64_t* shape, const void* data, int is_int64);
+/* strict key/shape check (as load_state_dict strict=True), BN folding, repacking, upload. */
+int roma_finalize(roma_handle_t h);
+/* mutable attributes of RegressionMatcher (README.md:82-90): "symmetric", "upsample_preds", "attenuate_cert", "debug" */
+int roma_set_option(roma_handle_t h, const char* key, int value);
+/* im_*: [B,3,H,W] float32 normalised images (already on the device). *_hr may be NULL when
+ * upsample_preds == 0.  warp_out: [B,Ho,2*Wo,4] (symmetric) or [B,Ho,Wo,4]; cert_out: [B,Ho,2*Wo] / [B,Ho,Wo]. */
+int roma_match(roma_handle_t h, int B, const float* im_a, const float* im_b, const float* im_a_hr,
+               const float* im_b_hr, float* warp_out, float* cert_out, void* stream);
+/* debug stage capture (enabled by roma_set_option(h,"debug",1)): copies a named intermediate to HOST memory.
+ * Returns the number of bytes available when dst == NULL. */
+long roma_debug_fetch(roma_handle_t h, const char* name, void* dst_host, long nbytes);
+int roma_destroy(roma_handle_t h);
+
+/* ---- operator entry points (dt: ROMA_F32 / ROMA_BF16) ------------------------------------------------ */
+
+/* Drop-in for local_corr.local_corr(feature0[B,HW,C], feature1[B,H,W,C], warp[B,HW,K,2], "bilinear",
+ * normalized_coords=True) -> out[B,HW,K]   (local_correlation.py:26-32).  feature0 is expected pre-scaled. */
+int roma_op_local_corr(const void* feature0, const void* feature1, const float* warp, void* out, int B, int H, int W,
+                       int C, int K, int dt_in, int dt_out, void* stream);
+/* Window form: warp is the centre coordinate [B,HW,2]; taps = (2r+1)^2 one-pixel steps; scale multiplies the
+ * result (1/sqrt(C) when feature0 is not pre-scaled); out row stride ldo >= K. */
+int roma_op_local_corr_window(const void* feature0, const void* feature1, const float* warp, void* out, int B, int H,
+                              int W, int C, int radius, float scale, long ldo, int dt_in, int dt_out, void* stream);
+
+/* C[M,N] = act(A[M,K] W[N,K]^T + bias) * scale + res   (batched with element strides; any pointer may be NULL) */
+int roma_op_gemm(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, int batch,
+                 long sA, long sW, long sC, const float* bias, const float* scale, const float* res, long ldr,
+                 int act, float alpha, int dt_in, int dt_out, void* stream);
+/* 3x3 conv (pad 1) as implicit GEMM on NHWC input: out[B,H,W,Cout] = relu?(conv(in[B,H,W,Cin], w[Cout][9*Cin]) + bias) */
+int roma_op_conv3x3(const void* in, const void* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                    int relu, int dt, void* stream);
+/* Multi-head attention from a packed qkv activation [B*N, 3*heads*hd] (f32): out[B*N, heads*hd].
+ * Workspace q,k,vt must hold B*heads*Npad*hd elements each, Npad = roundup(N,128), zero-initialised. */
+int roma_op_attention(const void* q, const void* k, const void* vt, void* out, int B, int heads, int N, int npad, int hd,
+                      int dt_in, int dt_out, void* stream);
+int roma_op_qkv_scatter_gemm(const void* A, const void* W, const float* bias, void* q, void* k, void* vt, int B, int N,
+                             int npad, int heads, int hd, int K, int dt_in, int dt_out, void* stream);
+int roma_op_layernorm(const float* x, const float* w, const float* b, void* out, long M, int D, float eps, int dt_out,
+                      void* stream);
+/* Batched SPD solve  (A + 0 ) X = F  via blocked Cholesky: A [batch,n,n] f32 (destroyed), Ft [batch, d, n] = F^T,
+ * overwritten by X^T.  Workspaces: LT [batch,n,n], Linv/LinvT [batch, n/64, 64, 64].  n multiple of 64. */
+int roma_op_cholesky_solve_t(float* A, float* Ft, float* LT, float* Linv, float* LinvT, int n, int d, int batch,
+                             void* stream);
+int roma_op_cls_to_flow(const float* logits, long ld, float* flow, float* cert, long M, void* stream);
+int roma_op_resize_bilinear(const float* in, float* out, int B, int Hin, int Win, int Hout, int Wout, int nc,
+                            void* stream);
+int roma_op_dwconv5x5(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp, int dt,
+                      void* stream);
+int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream);
+int roma_op_conv3x3_c3(const float* img, const float* w, const float* bias, void* out, int B, int H, int W, int dt_out,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

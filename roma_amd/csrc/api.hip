@@ -1,0 +1,189 @@
+// extern "C" boundary of libroma_hip (declarations + reference citations: include/roma_hip.h)
+#include <mutex>
+
+#include "../../include/roma_hip.h"
+#include "attention.h"
+#include "elementwise.h"
+#include "gemm.h"
+#include "local_corr.h"
+#include "model.h"
+
+namespace roma {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace roma
+
+struct roma_model {
+  roma::Model m;
+};
+
+using namespace roma;
+
+static inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
+static inline int DT(int dt) { return dt == ROMA_BF16 ? DT_BF16 : DT_F32; }
+
+extern "C" {
+
+const char* roma_last_error(void) { return g_err.c_str(); }
+const char* roma_version(void) { return "roma_hip 0.1 (gfx950)"; }
+
+int roma_create(const roma_config_t* cfg, roma_handle_t* out) {
+  ROMA_REQUIRE(cfg && out, "roma_create: null argument");
+  ROMA_REQUIRE(cfg->coarse_h > 0 && cfg->coarse_w > 0 && cfg->coarse_h % 14 == 0 && cfg->coarse_w % 14 == 0,
+               "Needs to be multiple of 14 for backbone");  // roma_models.py:58-59
+  ROMA_REQUIRE(cfg->coarse_h % 8 == 0 && cfg->coarse_w % 8 == 0, "roma_create: coarse resolution must be a multiple of 8 (VGG pyramid)");
+  ROMA_REQUIRE(cfg->upsample_h % 8 == 0 && cfg->upsample_w % 8 == 0 && cfg->upsample_h >= 0,
+               "roma_create: upsample resolution must be a multiple of 8");
+  ROMA_REQUIRE(cfg->max_batch >= 1, "roma_create: max_batch must be >= 1");
+  ROMA_REQUIRE(cfg->precision == ROMA_F32 || cfg->precision == ROMA_BF16, "roma_create: bad precision");
+  int ndev = 0;
+  ROMA_CHECK_HIP(hipGetDeviceCount(&ndev));
+  ROMA_REQUIRE(cfg->device >= 0 && cfg->device < ndev, "roma_create: no such HIP device (the HIP path has no CPU fallback)");
+  roma_model* h = new roma_model();
+  h->m.cfg = *cfg;
+  *out = h;
+  return 0;
+}
+
+int roma_set_tensor(roma_handle_t h, const char* name, int ndim, const int64_t* shape, const void* data, int is_int64) {
+  ROMA_REQUIRE(h, "roma_set_tensor: null handle");
+  return h->m.set_tensor(name, ndim, shape, data, is_int64);
+}
+
+int roma_finalize(roma_handle_t h) {
+  ROMA_REQUIRE(h, "roma_finalize: null handle");
+  return h->m.finalize();
+}
+
+int roma_set_option(roma_handle_t h, const char* key, int value) {
+  ROMA_REQUIRE(h && key, "roma_set_option: null argument");
+  const std::string k(key);
+  if (k == "symmetric") h->m.cfg.symmetric = value ? 1 : 0;
+  else if (k == "upsample_preds") {
+    ROMA_REQUIRE(!value || h->m.cfg.upsample_h > 0, "roma_set_option: handle was created without an upsample resolution");
+    h->m.cfg.upsample_preds = value ? 1 : 0;
+  } else if (k == "attenuate_cert") h->m.cfg.attenuate_cert = value ? 1 : 0;
+  else if (k == "debug") h->m.debug = value != 0;
+  else {
+    set_error("roma_set_option: unknown key " + k);
+    return ROMA_ERR_ARG;
+  }
+  return 0;
+}
+
+int roma_match(roma_handle_t h, int B, const float* im_a, const float* im_b, const float* im_a_hr, const float* im_b_hr,
+               float* warp_out, float* cert_out, void* stream) {
+  ROMA_REQUIRE(h, "roma_match: null handle");
+  return h->m.match(B, im_a, im_b, im_a_hr, im_b_hr, warp_out, cert_out, S(stream));
+}
+
+long roma_debug_fetch(roma_handle_t h, const char* name, void* dst_host, long nbytes) {
+  if (!h || !name) return ROMA_ERR_ARG;
+  auto it = h->m.dbg.find(name);
+  if (it == h->m.dbg.end()) {
+    set_error(std::string("roma_debug_fetch: no such stage: ") + name);
+    return ROMA_ERR_ARG;
+  }
+  if (!dst_host) return (long)it->second.second;
+  if ((size_t)nbytes < it->second.second) {
+    set_error("roma_debug_fetch: destination too small");
+    return ROMA_ERR_ARG;
+  }
+  if (hipDeviceSynchronize() != hipSuccess) return ROMA_ERR_HIP;
+  if (hipMemcpy(dst_host, it->second.first, it->second.second, hipMemcpyDeviceToHost) != hipSuccess) return ROMA_ERR_HIP;
+  return (long)it->second.second;
+}
+
+int roma_destroy(roma_handle_t h) {
+  delete h;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ operators
+int roma_op_local_corr(const void* feature0, const void* feature1, const float* warp, void* out, int B, int H, int W,
+                       int C, int K, int dt_in, int dt_out, void* stream) {
+  LocalCorrArgs a;
+  a.f0 = feature0; a.f1 = feature1; a.warp = warp; a.out = out; a.B = B; a.H = H; a.W = W; a.C = C; a.K = K;
+  a.ld0 = C; a.ld1 = C; a.ldo = K; a.nimg = B; a.f1_shift = 0; a.scale = 1.f; a.in_dt = DT(dt_in); a.out_dt = DT(dt_out);
+  return local_corr_general_launch(a, S(stream));
+}
+
+int roma_op_local_corr_window(const void* feature0, const void* feature1, const float* warp, void* out, int B, int H,
+                              int W, int C, int radius, float scale, long ldo, int dt_in, int dt_out, void* stream) {
+  LocalCorrArgs a;
+  a.f0 = feature0; a.f1 = feature1; a.warp = warp; a.out = out; a.B = B; a.H = H; a.W = W; a.C = C; a.radius = radius;
+  a.ld0 = C; a.ld1 = C; a.ldo = ldo; a.nimg = B; a.f1_shift = 0; a.scale = scale; a.in_dt = DT(dt_in); a.out_dt = DT(dt_out);
+  ROMA_REQUIRE(ldo >= (2 * radius + 1) * (2 * radius + 1), "local_corr_window: ldo < K");
+  return local_corr_window_launch(a, S(stream));
+}
+
+int roma_op_gemm(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, int batch,
+                 long sA, long sW, long sC, const float* bias, const float* scale, const float* res, long ldr, int act,
+                 float alpha, int dt_in, int dt_out, void* stream) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.batch = batch;
+  g.sA = sA; g.sW = sW; g.sC = sC; g.bias = bias; g.scale = scale; g.res = res; g.ldr = ldr; g.sR = sC; g.act = act;
+  g.alpha = alpha; g.in_dt = DT(dt_in); g.out_dt = DT(dt_out);
+  return gemm_launch(g, S(stream));
+}
+
+int roma_op_conv3x3(const void* in, const void* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                    int relu, int dt, void* stream) {
+  GemmArgs g;
+  g.A = in; g.W = w; g.ldw = 9 * Cin; g.C = out; g.ldc = Cout; g.M = B * H * W; g.N = Cout; g.K = 9 * Cin;
+  g.in_dt = DT(dt); g.out_dt = DT(dt); g.bias = bias; g.act = relu ? ACT_RELU : ACT_NONE;
+  g.conv_h = H; g.conv_w = W; g.conv_c = Cin;
+  return gemm_launch(g, S(stream));
+}
+
+int roma_op_attention(const void* q, const void* k, const void* vt, void* out, int B, int heads, int N, int npad, int hd,
+                      int dt_in, int dt_out, void* stream) {
+  AttnArgs a;
+  a.q = q; a.k = k; a.vt = vt; a.out = out; a.B = B; a.heads = heads; a.N = N; a.npad = npad; a.hd = hd;
+  a.ldo = (long)heads * hd; a.in_dt = DT(dt_in); a.out_dt = DT(dt_out);
+  return attention_launch(a, S(stream));
+}
+
+int roma_op_qkv_scatter_gemm(const void* A, const void* W, const float* bias, void* q, void* k, void* vt, int B, int N,
+                             int npad, int heads, int hd, int K, int dt_in, int dt_out, void* stream) {
+  GemmArgs g;
+  g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = B * N; g.N = 3 * heads * hd; g.K = K; g.in_dt = DT(dt_in);
+  g.out_dt = DT(dt_out); g.bias = bias; g.mode = EPI_QKV; g.q = q; g.k = k; g.vt = vt; g.heads = heads; g.hd = hd;
+  g.ntok = N; g.npad = npad; g.qscale = 1.0f / sqrtf((float)hd);
+  return gemm_launch(g, S(stream));
+}
+
+int roma_op_layernorm(const float* x, const float* w, const float* b, void* out, long M, int D, float eps, int dt_out,
+                      void* stream) {
+  return layernorm_launch(x, w, b, out, M, D, eps, DT(dt_out), S(stream));
+}
+
+int roma_op_cholesky_solve_t(float* A, float* Ft, float* LT, float* Linv, float* LinvT, int n, int d, int batch,
+                             void* stream) {
+  return cholesky_solve_t(A, Ft, LT, Linv, LinvT, n, d, batch, S(stream));
+}
+
+int roma_op_cls_to_flow(const float* logits, long ld, float* flow, float* cert, long M, void* stream) {
+  return cls_to_flow_launch(logits, ld, flow, cert, M, S(stream));
+}
+
+int roma_op_resize_bilinear(const float* in, float* out, int B, int Hin, int Win, int Hout, int Wout, int nc,
+                            void* stream) {
+  return resize_bilinear_launch(in, out, B, Hin, Win, Hout, Wout, nc, S(stream));
+}
+
+int roma_op_dwconv5x5(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp, int dt,
+                      void* stream) {
+  return dwconv5x5_launch(in, out, w, bias, B, H, W, Cp, DT(dt), S(stream));
+}
+
+int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream) {
+  return maxpool2x2_launch(in, out, B, H, W, C, DT(dt), S(stream));
+}
+
+int roma_op_conv3x3_c3(const float* img, const float* w, const float* bias, void* out, int B, int H, int W, int dt_out,
+                       void* stream) {
+  return conv3x3_c3_launch(img, w, bias, out, B, H, W, DT(dt_out), S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// HBM-bound kernels of the match() path (everything that is not a GEMM / attention / local-corr).
+// All activations are channels-last; `dt` arguments are DT_F32 / DT_BF16 (gemm.h).
+#pragma once
+#include "common.h"
+
+namespace roma {
+
+// LayerNorm over the last dim (D multiple of 256, <= 2048): x f32 [M,D] -> out [M,D] (dt_out)
+int layernorm_launch(const float* x, const float* w, const float* b, void* out, long M, int D, float eps,
+                     int dt_out, hipStream_t s);
+
+// First VGG layer: NCHW f32 image -> conv3x3(3->64, pad 1) + folded BN + ReLU -> NHWC (dt_out)
+// w: [27][64] (tap-major: (ci*9+ky*3+kx), cout fastest), bias [64]
+int conv3x3_c3_launch(const float* img, const float* w, const float* bias, void* out, int B, int H, int W,
+                      int dt_out, hipStream_t s);
+
+// MaxPool 2x2 stride 2 (floor), NHWC
+int maxpool2x2_launch(const void* in, void* out, int B, int H, int W, int C, int dt, hipStream_t s);
+
+// DINOv2 patchify: NCHW f32 image -> A[B*th*tw, Kpad] with k = c*196 + ky*14 + kx (zero padded to Kpad)
+int im2col_patch14_launch(const float* img, void* out, int B, int H, int W, int Kpad, int dt_out, hipStream_t s);
+
+// tokens[b,0,:] = cls + pos[0];  tokens[b,1+t,:] = patch[b,t,:] + pos[1+t]     (all f32, D columns)
+int assemble_tokens_launch(const float* patch, const float* cls, const float* pos, float* tokens, int B, int T,
+                           int D, hipStream_t s);
+
+// rows x cols strided copy with dtype conversion: out[r*ldo + c] = in[r*ldi + c]
+int copy2d_launch(const void* in, long ldi, int dt_in, void* out, long ldo, int dt_out, long rows, int cols,
+                  hipStream_t s);
+
+// L2 norm of each row: in [M, C] (ld, dt) -> norms f32 [M]
+int rownorm_launch(const void* in, long ld, int dt, float* norms, long M, int C, hipStream_t s);
+
+// GP Fourier basis, transposed: Ft[d, j] = cos(8*pi*(w[d,0]*x_j + w[d,1]*y_j + b[d])), j over the h x w grid
+// (row-major, x fastest); columns j >= h*w are zero.  Ft: [Dg, npad]
+int gp_basis_launch(const float* w, const float* b, float* Ft, int Dg, int h, int wdt, int npad, hipStream_t s);
+
+// batched square transpose (f32): out[b][j][i] = in[b][i][j], n x n with leading dim ld
+int transpose_launch(const float* in, float* out, int n, long ld, int batch, hipStream_t s);
+
+// Cholesky of one 64x64 diagonal block per batch item, in place (lower), plus its inverse and inverse^T.
+// A: [batch][n][ld]; block k starts at (64k,64k).  Linv/LinvT: [batch][nblk][64][64]
+int chol_diag_launch(float* A, long ld, long strideA, float* Linv, float* LinvT, int k, int nblk, int batch,
+                     hipStream_t s);
+
+// pad the trailing (npad - n) diagonal of a Gram matrix with identity and zero its off-diagonals
+int pad_identity_launch(float* A, long ld, long strideA, int n, int npad, int batch, hipStream_t s);
+
+// cls_to_flow_refine (romatch/utils/utils.py:300-322): logits [M, ld] (4096 classes + 1 certainty logit)
+// -> flow [M,2] (x,y), cert [M]
+int cls_to_flow_launch(const float* logits, long ld, float* flow, float* cert, long M, hipStream_t s);
+
+struct RefinerInputArgs {
+  const void* feat = nullptr;  // projected features [nimg, H*W, C] (row stride ldf)
+  long ldf = 0;
+  const float* flow = nullptr;  // [B, H*W, 2]
+  void* d = nullptr;            // [B, H*W, ldd]: [x | x_hat | emb | (corr written by local_corr) | zero pad]
+  long ldd = 0;
+  const float* emb_w = nullptr;  // [E,2]
+  const float* emb_b = nullptr;  // [E]
+  int B = 0, H = 0, W = 0, C = 0, E = 0, Kcorr = 0, nimg = 0, shift = 0;
+  float disp_scale = 1.f;  // 40/32 * scale_factor
+  int dt = 0;
+};
+int refiner_input_launch(const RefinerInputArgs& a, hipStream_t s);
+
+// depthwise 5x5 (pad 2) + folded BN + ReLU, NHWC.  w: [25][Cp], bias [Cp]
+int dwconv5x5_launch(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp,
+                     int dt, hipStream_t s);
+
+// out_conv (C->3, f32) fused with the flow / certainty update (matcher.py:177-178, 496-506)
+int refiner_out_launch(const void* d, long ldd, int dt, const float* w /*[3][Cp]*/, const float* b /*[3]*/,
+                       float* flow, float* cert, long M, int Cp, float sx, float sy, hipStream_t s);
+
+// bilinear resize, align_corners=False, channels-last small-channel maps (nc = 1 or 2), f32
+int resize_bilinear_launch(const float* in, float* out, int B, int Hin, int Win, int Hout, int Wout, int nc,
+                           hipStream_t s);
+
+struct FinalArgs {
+  const float* flow = nullptr;    // [b, H, W, 2] finest flow
+  const float* cert = nullptr;    // [b, H, W] finest certainty logits
+  const float* cert16 = nullptr;  // [b, h16, w16] pass-1 stride-16 certainty logits (attenuation) or null
+  float* warp = nullptr;          // [B, H, 2W, 4] (symmetric) or [B, H, W, 4]
+  float* certainty = nullptr;     // [B, H, 2W] or [B, H, W]
+  int B = 0, H = 0, W = 0, h16 = 0, w16 = 0, symmetric = 1;
+};
+int final_epilogue_launch(const FinalArgs& a, hipStream_t s);
+
+}  // namespace roma

@@ -1,0 +1,749 @@
+// HBM-bound kernels of the RoMa match() path for gfx950 (see elementwise.h).
+// Conventions: channels-last activations, 16-byte (or 8-byte for bf16 quads) vector accesses,
+// one wave64 per row for row reductions, f32 math everywhere.
+#include "elementwise.h"
+#include "gemm.h"  // DT_*
+
+namespace roma {
+
+#define ROMA_DT_SWITCH(dt, T, ...)            \
+  if ((dt) == DT_F32) { using T = float; __VA_ARGS__; } else { using T = bf16_t; __VA_ARGS__; }
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// torch.linspace(-1+1/n, 1-1/n, n)[i] in f32 (symmetric two-sided evaluation like ATen)
+__device__ inline float pix_coord(int i, int n) {
+  const float start = (float)(-1.0 + 1.0 / n), end = (float)(1.0 - 1.0 / n);
+  if (n == 1) return start;
+  const float step = (end - start) / (float)(n - 1);
+  return (i < n / 2) ? start + step * (float)i : end - step * (float)(n - 1 - i);
+}
+
+// ------------------------------------------------------------------ LayerNorm
+template <typename TOUT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* w, const float* b, TOUT* out,
+                                                        long M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + row * D;
+  f32x4 v[8];
+  const int nv = D / 256;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < nv) {
+      v[i] = *reinterpret_cast<const f32x4*>(xr + (i * 64 + lane) * 4);
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < nv) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < nv) {
+      const int c = (i * 64 + lane) * 4;
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(b + c);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
+      ElemIO<TOUT>::st4(out + row * D + c, o);
+    }
+}
+
+int layernorm_launch(const float* x, const float* w, const float* b, void* out, long M, int D, float eps,
+                     int dt_out, hipStream_t s) {
+  ROMA_REQUIRE(D % 256 == 0 && D <= 2048, "layernorm: D must be a multiple of 256 and <= 2048");
+  dim3 grid((unsigned)((M + 3) / 4));
+  ROMA_DT_SWITCH(dt_out, T, hipLaunchKernelGGL(layernorm_kernel<T>, grid, dim3(256), 0, s, x, w, b, (T*)out, M, D, eps));
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ conv3x3, Cin = 3 (first VGG layer)
+template <typename TOUT>
+__global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float* img, const float* w, const float* bias,
+                                                         TOUT* out, int B, int H, int W) {
+  __shared__ __attribute__((aligned(16))) float ws[27 * 64];
+  __shared__ float bs[64];
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) ws[i] = w[i];
+  if (threadIdx.x < 64) bs[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const long HW = (long)H * W;
+  const long pix = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int cg = threadIdx.x & 3;  // 16 output channels each
+  if (pix >= (long)B * HW) return;
+  const int b = (int)(pix / HW);
+  const int rem = (int)(pix - (long)b * HW);
+  const int y = rem / W, x = rem - y * W;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = bs[cg * 16 + j];
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[((long)(b * 3 + ci) * H + yy) * W + xx];
+        const float* wr = &ws[(ci * 9 + ky * 3 + kx) * 64 + cg * 16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = fmaf(v, wr[j], acc[j]);
+      }
+  TOUT* o = out + pix * 64 + cg * 16;
+#pragma unroll
+  for (int j4 = 0; j4 < 4; ++j4) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[j4 * 4 + j], 0.f);
+    ElemIO<TOUT>::st4(o + j4 * 4, v);
+  }
+}
+
+int conv3x3_c3_launch(const float* img, const float* w, const float* bias, void* out, int B, int H, int W,
+                      int dt_out, hipStream_t s) {
+  const long total = (long)B * H * W;
+  dim3 grid((unsigned)((total + 63) / 64));
+  ROMA_DT_SWITCH(dt_out, T, hipLaunchKernelGGL(conv3x3_c3_kernel<T>, grid, dim3(256), 0, s, img, w, bias, (T*)out, B, H, W));
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ MaxPool 2x2
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* in, T* out, int B, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+  const long total = (long)B * Ho * Wo * C4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % C4) * 4;
+    long r = idx / C4;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const T* p = in + (((long)b * H + 2 * yo) * W + 2 * xo) * C + c;
+    const f32x4 a0 = ElemIO<T>::ld4(p), a1 = ElemIO<T>::ld4(p + C), a2 = ElemIO<T>::ld4(p + (long)W * C),
+                a3 = ElemIO<T>::ld4(p + (long)W * C + C);
+    f32x4 m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a0[j], a1[j]), fmaxf(a2[j], a3[j]));
+    ElemIO<T>::st4(out + (((long)b * Ho + yo) * Wo + xo) * C + c, m);
+  }
+}
+
+int maxpool2x2_launch(const void* in, void* out, int B, int H, int W, int C, int dt, hipStream_t s) {
+  ROMA_REQUIRE(C % 4 == 0, "maxpool: C must be a multiple of 4");
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 65536));
+  ROMA_DT_SWITCH(dt, T, hipLaunchKernelGGL(maxpool_kernel<T>, grid, dim3(256), 0, s, (const T*)in, (T*)out, B, H, W, C));
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ DINOv2 patchify (im2col, 14x14 / stride 14)
+template <typename TOUT>
+__global__ __launch_bounds__(256) void im2col_patch14_kernel(const float* img, TOUT* out, int B, int H, int W, int Kpad) {
+  const int th = H / 14, tw = W / 14;
+  const long total = (long)B * th * tw * Kpad;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int k = (int)(idx % Kpad);
+    long r = idx / Kpad;
+    const int tx = (int)(r % tw);
+    r /= tw;
+    const int ty = (int)(r % th);
+    const int b = (int)(r / th);
+    float v = 0.f;
+    if (k < 588) {
+      const int c = k / 196, rem = k - c * 196, ky = rem / 14, kx = rem - ky * 14;
+      v = img[((long)(b * 3 + c) * H + ty * 14 + ky) * W + tx * 14 + kx];
+    }
+    ElemIO<TOUT>::st(out + idx, v);
+  }
+}
+
+int im2col_patch14_launch(const float* img, void* out, int B, int H, int W, int Kpad, int dt_out, hipStream_t s) {
+  ROMA_REQUIRE(H % 14 == 0 && W % 14 == 0 && Kpad >= 588, "im2col_patch14: bad geometry");
+  const long total = (long)B * (H / 14) * (W / 14) * Kpad;
+  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 65536));
+  ROMA_DT_SWITCH(dt_out, T, hipLaunchKernelGGL(im2col_patch14_kernel<T>, grid, dim3(256), 0, s, img, (T*)out, B, H, W, Kpad));
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ token assembly (cls + pos-embed)
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* patch, const float* cls, const float* pos,
+                                                              float* tokens, int B, int T, int D) {
+  const int D4 = D / 4;
+  const long total = (long)B * (T + 1) * D4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % D4) * 4;
+    const long r = idx / D4;
+    const int t = (int)(r % (T + 1));
+    const int b = (int)(r / (T + 1));
+    f32x4 v = (t == 0) ? *reinterpret_cast<const f32x4*>(cls + c)
+                       : *reinterpret_cast<const f32x4*>(patch + ((long)b * T + (t - 1)) * D + c);
+    v += *reinterpret_cast<const f32x4*>(pos + (long)t * D + c);
+    *reinterpret_cast<f32x4*>(tokens + r * D + c) = v;
+  }
+}
+
+int assemble_tokens_launch(const float* patch, const float* cls, const float* pos, float* tokens, int B, int T,
+                           int D, hipStream_t s) {
+  const long total = (long)B * (T + 1) * (D / 4);
+  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 65536));
+  hipLaunchKernelGGL(assemble_tokens_kernel, grid, dim3(256), 0, s, patch, cls, pos, tokens, B, T, D);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ strided copy / convert
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void copy2d_kernel(const TI* in, long ldi, TO* out, long ldo, long rows, int cols) {
+  const int c4n = cols / 4;
+  const long total = rows * c4n;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % c4n) * 4;
+    const long r = idx / c4n;
+    ElemIO<TO>::st4(out + r * ldo + c, ElemIO<TI>::ld4(in + r * ldi + c));
+  }
+}
+
+int copy2d_launch(const void* in, long ldi, int dt_in, void* out, long ldo, int dt_out, long rows, int cols,
+                  hipStream_t s) {
+  ROMA_REQUIRE(cols % 4 == 0 && ldi % 4 == 0 && ldo % 4 == 0, "copy2d: cols / strides must be multiples of 4");
+  const long total = rows * (cols / 4);
+  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 65536));
+  ROMA_DT_SWITCH(dt_in, TI, ROMA_DT_SWITCH(dt_out, TO, hipLaunchKernelGGL((copy2d_kernel<TI, TO>), grid, dim3(256), 0, s,
+                                                                          (const TI*)in, ldi, (TO*)out, ldo, rows, cols)));
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ row L2 norms
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_kernel(const T* in, long ld, float* norms, long M, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float s = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    const f32x4 v = ElemIO<T>::ld4(in + row * ld + c);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  s = wave_sum(s);
+  if (lane == 0) norms[row] = sqrtf(s);
+}
+
+int rownorm_launch(const void* in, long ld, int dt, float* norms, long M, int C, hipStream_t s) {
+  ROMA_REQUIRE(C % 4 == 0, "rownorm: C must be a multiple of 4");
+  dim3 grid((unsigned)((M + 3) / 4));
+  ROMA_DT_SWITCH(dt, T, hipLaunchKernelGGL(rownorm_kernel<T>, grid, dim3(256), 0, s, (const T*)in, ld, norms, M, C));
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ GP Fourier basis (transposed)
+__global__ __launch_bounds__(256) void gp_basis_kernel(const float* w, const float* b, float* Ft, int Dg, int h, int wd,
+                                                       int npad) {
+  const long total = (long)Dg * npad;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int j = (int)(idx % npad);
+    const int d = (int)(idx / npad);
+    float v = 0.f;
+    if (j < h * wd) {
+      const int y = j / wd, x = j - y * wd;
+      const float cx = pix_coord(x, wd), cy = pix_coord(y, h);
+      const float z = w[d * 2 + 0] * cx + w[d * 2 + 1] * cy + b[d];
+      v = cosf((float)(8.0 * 3.14159265358979323846) * z);
+    }
+    Ft[idx] = v;
+  }
+}
+
+int gp_basis_launch(const float* w, const float* b, float* Ft, int Dg, int h, int wdt, int npad, hipStream_t s) {
+  const long total = (long)Dg * npad;
+  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 65536));
+  hipLaunchKernelGGL(gp_basis_kernel, grid, dim3(256), 0, s, w, b, Ft, Dg, h, wdt, npad);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ batched square transpose
+__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, int n, long ld) {
+  __shared__ float tile[32][33];
+  const float* ib = in + (long)blockIdx.z * n * ld;
+  float* ob = out + (long)blockIdx.z * n * ld;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  for (int j = ty; j < 32; j += 8)
+    if (y0 + j < n && x0 + tx < n) tile[j][tx] = ib[(long)(y0 + j) * ld + x0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (x0 + j < n && y0 + tx < n) ob[(long)(x0 + j) * ld + y0 + tx] = tile[tx][j];
+}
+
+int transpose_launch(const float* in, float* out, int n, long ld, int batch, hipStream_t s) {
+  dim3 grid((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), (unsigned)batch);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, n, ld);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ 64x64 Cholesky + triangular inverse
+__global__ __launch_bounds__(256) void chol_diag_kernel(float* A, long ld, long strideA, float* Linv, float* LinvT,
+                                                        int k, int nblk) {
+  __shared__ float L[64][65];
+  __shared__ float X[64][65];
+  float* Ab = A + (long)blockIdx.x * strideA + ((long)k * 64) * ld + (long)k * 64;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < 64 * 64; idx += 256) L[idx >> 6][idx & 63] = Ab[(long)(idx >> 6) * ld + (idx & 63)];
+  __syncthreads();
+  for (int j = 0; j < 64; ++j) {
+    if (tid == 0) L[j][j] = sqrtf(L[j][j]);
+    __syncthreads();
+    const float dj = L[j][j];
+    if (tid > j && tid < 64) L[tid][j] /= dj;
+    __syncthreads();
+    // trailing update of the lower triangle: L[i][c] -= L[i][j] * L[c][j], c in (j, i]
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+      const int i = idx >> 6, c = idx & 63;
+      if (c > j && i >= c) L[i][c] -= L[i][j] * L[c][j];
+    }
+    __syncthreads();
+  }
+  // inverse of the lower-triangular factor: column c by forward substitution
+  if (tid < 64) {
+    const int c = tid;
+    for (int i = 0; i < c; ++i) X[i][c] = 0.f;
+    X[c][c] = 1.0f / L[c][c];
+    for (int i = c + 1; i < 64; ++i) {
+      float sacc = 0.f;
+      for (int t = c; t < i; ++t) sacc = fmaf(L[i][t], X[t][c], sacc);
+      X[i][c] = -sacc / L[i][i];
+    }
+  }
+  __syncthreads();
+  float* Li = Linv + ((long)blockIdx.x * nblk + k) * 4096;
+  float* LiT = LinvT + ((long)blockIdx.x * nblk + k) * 4096;
+  for (int idx = tid; idx < 64 * 64; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    Ab[(long)i * ld + c] = (c <= i) ? L[i][c] : 0.f;
+    Li[idx] = X[i][c];
+    LiT[idx] = X[c][i];
+  }
+}
+
+int chol_diag_launch(float* A, long ld, long strideA, float* Linv, float* LinvT, int k, int nblk, int batch,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)batch), dim3(256), 0, s, A, ld, strideA, Linv, LinvT, k, nblk);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void pad_identity_kernel(float* A, long ld, long strideA, int n, int npad) {
+  float* Ab = A + (long)blockIdx.y * strideA;
+  const long total = (long)npad * npad;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int i = (int)(idx / npad), j = (int)(idx % npad);
+    if (i >= n || j >= n) Ab[(long)i * ld + j] = (i == j) ? 1.f : 0.f;
+  }
+}
+
+int pad_identity_launch(float* A, long ld, long strideA, int n, int npad, int batch, hipStream_t s) {
+  if (npad == n) return 0;
+  const long total = (long)npad * npad;
+  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 4096), (unsigned)batch);
+  hipLaunchKernelGGL(pad_identity_kernel, grid, dim3(256), 0, s, A, ld, strideA, n, npad);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ cls_to_flow_refine
+__global__ __launch_bounds__(256) void cls_to_flow_kernel(const float* logits, long ld, float* flow, float* cert, long M) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* lr = logits + row * ld;
+  float mx = -INFINITY;
+  int arg = 0;
+  f32x4 v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(lr + (i * 64 + lane) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (v[i][j] > mx) {
+        mx = v[i][j];
+        arg = (i * 64 + lane) * 4 + j;
+      }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float om = __shfl_xor(mx, off);
+    const int oa = __shfl_xor(arg, off);
+    if (om > mx || (om == mx && oa < arg)) {
+      mx = om;
+      arg = oa;
+    }
+  }
+  float se = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) se += expf(v[i][j] - mx);
+  se = wave_sum(se);
+  if (lane == 0) {
+    const int idx5[5] = {arg - 1, arg, arg + 1, arg - 64, arg + 64};
+    float fx = 0.f, fy = 0.f, tot = 0.f;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int c = min(max(idx5[t], 0), 4095);
+      const float p = expf(lr[c] - mx) / se;
+      fx += p * pix_coord(c & 63, 64);
+      fy += p * pix_coord(c >> 6, 64);
+      tot += p;
+    }
+    flow[row * 2 + 0] = fx / tot;
+    flow[row * 2 + 1] = fy / tot;
+    cert[row] = lr[4096];
+  }
+}
+
+int cls_to_flow_launch(const float* logits, long ld, float* flow, float* cert, long M, hipStream_t s) {
+  ROMA_REQUIRE(ld % 4 == 0 && ld >= 4097, "cls_to_flow: bad leading dimension");
+  dim3 grid((unsigned)((M + 3) / 4));
+  hipLaunchKernelGGL(cls_to_flow_kernel, grid, dim3(256), 0, s, logits, ld, flow, cert, M);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ refiner input: [x | grid_sample(y, flow) | disp_emb | . | 0]
+template <typename T>
+__global__ __launch_bounds__(256) void refiner_input_kernel(const RefinerInputArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long HW = (long)a.H * a.W;
+  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= (long)a.B * HW) return;
+  const int b = (int)(pix / HW);
+  const long p = pix - (long)b * HW;
+  const int y = (int)(p / a.W), x = (int)(p - (long)y * a.W);
+  const T* feat = reinterpret_cast<const T*>(a.feat);
+  const T* fq = feat + ((long)b * HW + p) * a.ldf;
+  const int simg = (b + a.shift) % a.nimg;
+  const T* fs = feat + (long)simg * HW * a.ldf;
+  T* d = reinterpret_cast<T*>(a.d) + pix * a.ldd;
+  const float wx = a.flow[pix * 2 + 0], wy = a.flow[pix * 2 + 1];
+  float ix = ((wx + 1.f) * a.W - 1.f) * 0.5f, iy = ((wy + 1.f) * a.H - 1.f) * 0.5f;
+  ix = fminf(fmaxf(ix, -1.0e6f), 1.0e6f);
+  iy = fminf(fmaxf(iy, -1.0e6f), 1.0e6f);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float tx = ix - fx0, ty = iy - fy0;
+  const float wgt[4] = {(1.f - tx) * (1.f - ty), tx * (1.f - ty), (1.f - tx) * ty, tx * ty};
+  bool ok[4];
+  long off[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
+    ok[t] = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+    off[t] = ((long)yy * a.W + xx) * a.ldf;
+  }
+  for (int c = lane * 4; c < a.C; c += 256) {
+    ElemIO<T>::st4(d + c, ElemIO<T>::ld4(fq + c));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (ok[t]) {
+        const f32x4 v = ElemIO<T>::ld4(fs + off[t] + c);
+        acc += wgt[t] * v;
+      }
+    ElemIO<T>::st4(d + a.C + c, acc);
+  }
+  const float dx = a.disp_scale * (wx - pix_coord(x, a.W)), dy = a.disp_scale * (wy - pix_coord(y, a.H));
+  for (int e = lane; e < a.E; e += 64) {
+    const float v = a.emb_w[e * 2 + 0] * dx + a.emb_w[e * 2 + 1] * dy + a.emb_b[e];
+    ElemIO<T>::st(d + 2 * a.C + e, v);
+  }
+  for (long c = 2 * a.C + a.E + a.Kcorr + lane; c < a.ldd; c += 64) ElemIO<T>::st(d + c, 0.f);
+}
+
+// small / odd channel counts (stride-1 refiner: C = 9): one thread per (pixel, padded channel slot)
+template <typename T>
+__global__ __launch_bounds__(256) void refiner_input_small_kernel(const RefinerInputArgs a) {
+  const long HW = (long)a.H * a.W;
+  const int slots = (int)a.ldd;
+  const long total = (long)a.B * HW * slots;
+  const T* feat = reinterpret_cast<const T*>(a.feat);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % slots);
+    const long pix = idx / slots;
+    const int b = (int)(pix / HW);
+    const long p = pix - (long)b * HW;
+    T* d = reinterpret_cast<T*>(a.d) + pix * a.ldd;
+    if (c < a.C) {
+      ElemIO<T>::st(d + c, ElemIO<T>::ld(feat + ((long)b * HW + p) * a.ldf + c));
+    } else if (c < 2 * a.C) {
+      const int cc = c - a.C;
+      const int simg = (b + a.shift) % a.nimg;
+      const T* fs = feat + (long)simg * HW * a.ldf;
+      const float wx = a.flow[pix * 2 + 0], wy = a.flow[pix * 2 + 1];
+      float ix = ((wx + 1.f) * a.W - 1.f) * 0.5f, iy = ((wy + 1.f) * a.H - 1.f) * 0.5f;
+      ix = fminf(fmaxf(ix, -1.0e6f), 1.0e6f);
+      iy = fminf(fmaxf(iy, -1.0e6f), 1.0e6f);
+      const float fx0 = floorf(ix), fy0 = floorf(iy);
+      const int x0 = (int)fx0, y0 = (int)fy0;
+      const float tx = ix - fx0, ty = iy - fy0;
+      const float wgt[4] = {(1.f - tx) * (1.f - ty), tx * (1.f - ty), (1.f - tx) * ty, tx * ty};
+      float acc = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+          acc += wgt[t] * ElemIO<T>::ld(fs + ((long)yy * a.W + xx) * a.ldf + cc);
+      }
+      ElemIO<T>::st(d + c, acc);
+    } else if (c < 2 * a.C + a.E) {
+      const int e = c - 2 * a.C;
+      const int y = (int)(p / a.W), x = (int)(p - (long)y * a.W);
+      const float dx = a.disp_scale * (a.flow[pix * 2 + 0] - pix_coord(x, a.W));
+      const float dy = a.disp_scale * (a.flow[pix * 2 + 1] - pix_coord(y, a.H));
+      ElemIO<T>::st(d + c, a.emb_w[e * 2 + 0] * dx + a.emb_w[e * 2 + 1] * dy + a.emb_b[e]);
+    } else if (c >= 2 * a.C + a.E + a.Kcorr) {
+      ElemIO<T>::st(d + c, 0.f);
+    }
+  }
+}
+
+int refiner_input_launch(const RefinerInputArgs& a, hipStream_t s) {
+  const long npix = (long)a.B * a.H * a.W;
+  if (a.C % 4 != 0 || a.C < 32) {
+    const long total = npix * a.ldd;
+    dim3 grid((unsigned)std::min<long>((total + 255) / 256, 1 << 20));
+    ROMA_DT_SWITCH(a.dt, T, hipLaunchKernelGGL(refiner_input_small_kernel<T>, grid, dim3(256), 0, s, a));
+    ROMA_LAUNCH_CHECK();
+    return 0;
+  }
+  ROMA_REQUIRE(a.ldf % 4 == 0 && a.ldd % 4 == 0, "refiner_input: strides must be multiples of 4");
+  dim3 grid((unsigned)((npix + 3) / 4));
+  ROMA_DT_SWITCH(a.dt, T, hipLaunchKernelGGL(refiner_input_kernel<T>, grid, dim3(256), 0, s, a));
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ depthwise 5x5 + BN(folded) + ReLU
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv5x5_kernel(const T* in, T* out, const float* w, const float* bias, int B,
+                                                        int H, int W, int Cp) {
+  const int C4 = Cp / 4;
+  const int xt = (W + 3) / 4;
+  const long total = (long)B * H * xt * C4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % C4) * 4;
+    long r = idx / C4;
+    const int xb = (int)(r % xt) * 4;
+    r /= xt;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+    f32x4 acc[4] = {bv, bv, bv, bv};
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      const int yy = y + ky - 2;
+      if (yy < 0 || yy >= H) continue;
+      const T* rowp = in + (((long)b * H + yy) * W) * Cp + c;
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int xx = xb - 2 + j;
+        if (xx >= 0 && xx < W) v[j] = ElemIO<T>::ld4(rowp + (long)xx * Cp);
+        else v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (long)(ky * 5 + kx) * Cp + c);
+#pragma unroll
+        for (int px = 0; px < 4; ++px) acc[px] += v[px + kx] * wv;
+      }
+    }
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      if (xb + px < W) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaxf(acc[px][j], 0.f);
+        ElemIO<T>::st4(out + (((long)b * H + y) * W + xb + px) * Cp + c, o);
+      }
+    }
+  }
+}
+
+int dwconv5x5_launch(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp,
+                     int dt, hipStream_t s) {
+  ROMA_REQUIRE(Cp % 4 == 0, "dwconv5x5: padded channel count must be a multiple of 4");
+  const long total = (long)B * H * ((W + 3) / 4) * (Cp / 4);
+  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 1 << 20));
+  ROMA_DT_SWITCH(dt, T, hipLaunchKernelGGL(dwconv5x5_kernel<T>, grid, dim3(256), 0, s, (const T*)in, (T*)out, w, bias, B, H, W, Cp));
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ out_conv + flow / certainty update
+template <typename T, int G>
+__global__ __launch_bounds__(256) void refiner_out_kernel(const T* d, long ldd, const float* w, const float* bb, float* flow,
+                                                          float* cert, long M, int Cp, float sx, float sy) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % G, rw = lane / G;
+  constexpr int RPW = 64 / G;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + rw;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  if (row < M) {
+    for (int c = sub * 4; c < Cp; c += G * 4) {
+      const f32x4 v = ElemIO<T>::ld4(d + row * ldd + c);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + Cp + c);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(w + 2 * Cp + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0 = fmaf(v[j], w0[j], a0);
+        a1 = fmaf(v[j], w1[j], a1);
+        a2 = fmaf(v[j], w2[j], a2);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = G / 2; off >= 1; off >>= 1) {
+    a0 += __shfl_xor(a0, off);
+    a1 += __shfl_xor(a1, off);
+    a2 += __shfl_xor(a2, off);
+  }
+  if (row < M && sub == 0) {
+    flow[row * 2 + 0] += sx * (a0 + bb[0]);
+    flow[row * 2 + 1] += sy * (a1 + bb[1]);
+    cert[row] += a2 + bb[2];
+  }
+}
+
+int refiner_out_launch(const void* d, long ldd, int dt, const float* w, const float* b, float* flow, float* cert,
+                       long M, int Cp, float sx, float sy, hipStream_t s) {
+  ROMA_REQUIRE(Cp % 4 == 0 && ldd % 4 == 0, "refiner_out: channel padding must be a multiple of 4");
+  const int chunks = Cp / 4;
+#define ROMA_RO(G)                                                                                          \
+  {                                                                                                         \
+    const long rows_per_block = 4 * (64 / G);                                                               \
+    dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block));                                       \
+    ROMA_DT_SWITCH(dt, T, hipLaunchKernelGGL((refiner_out_kernel<T, G>), grid, dim3(256), 0, s, (const T*)d, ldd, w, b, \
+                                             flow, cert, M, Cp, sx, sy));                                   \
+  }
+  if (chunks <= 8) ROMA_RO(8)
+  else if (chunks <= 16) ROMA_RO(16)
+  else if (chunks <= 32) ROMA_RO(32)
+  else ROMA_RO(64)
+#undef ROMA_RO
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ bilinear resize (align_corners=False)
+__device__ inline void bilinear_src(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* in, float* out, int B, int Hin, int Win, int Hout,
+                                                              int Wout, int nc) {
+  const float sh = (float)Hin / (float)Hout, sw = (float)Win / (float)Wout;
+  const long total = (long)B * Hout * Wout;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int x = (int)(idx % Wout);
+    long r = idx / Wout;
+    const int y = (int)(r % Hout);
+    const int b = (int)(r / Hout);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilinear_src(y, sh, Hin, y0, y1, ly);
+    bilinear_src(x, sw, Win, x0, x1, lx);
+    const float* ib = in + (long)b * Hin * Win * nc;
+    for (int c = 0; c < nc; ++c) {
+      const float v00 = ib[((long)y0 * Win + x0) * nc + c], v01 = ib[((long)y0 * Win + x1) * nc + c];
+      const float v10 = ib[((long)y1 * Win + x0) * nc + c], v11 = ib[((long)y1 * Win + x1) * nc + c];
+      out[idx * nc + c] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    }
+  }
+}
+
+int resize_bilinear_launch(const float* in, float* out, int B, int Hin, int Win, int Hout, int Wout, int nc,
+                           hipStream_t s) {
+  const long total = (long)B * Hout * Wout;
+  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 65536));
+  hipLaunchKernelGGL(resize_bilinear_kernel, grid, dim3(256), 0, s, in, out, B, Hin, Win, Hout, Wout, nc);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ final epilogue (matcher.py:839-850, 891-929)
+__global__ __launch_bounds__(256) void final_epilogue_kernel(const FinalArgs a) {
+  const int Wout = a.symmetric ? 2 * a.W : a.W;
+  const long total = (long)a.B * a.H * Wout;
+  const float sh = a.cert16 ? (float)a.h16 / (float)a.H : 0.f, sw = a.cert16 ? (float)a.w16 / (float)a.W : 0.f;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int xo = (int)(idx % Wout);
+    long r = idx / Wout;
+    const int y = (int)(r % a.H);
+    const int bo = (int)(r / a.H);
+    const int half = xo / a.W, x = xo - half * a.W;
+    const int dp = bo + half * a.B;
+    const long src = ((long)dp * a.H + y) * a.W + x;
+    float fx = a.flow[src * 2 + 0], fy = a.flow[src * 2 + 1];
+    float c = a.cert[src];
+    if (a.cert16) {
+      int y0, y1, x0, x1;
+      float ly, lx;
+      bilinear_src(y, sh, a.h16, y0, y1, ly);
+      bilinear_src(x, sw, a.w16, x0, x1, lx);
+      const float* cb = a.cert16 + (long)dp * a.h16 * a.w16;
+      const float low = (1.f - ly) * ((1.f - lx) * cb[y0 * a.w16 + x0] + lx * cb[y0 * a.w16 + x1]) +
+                        ly * ((1.f - lx) * cb[y1 * a.w16 + x0] + lx * cb[y1 * a.w16 + x1]);
+      c -= (low < 0.f) ? 0.5f * low : 0.f;
+    }
+    c = 1.f / (1.f + expf(-c));
+    if (fabsf(fx) > 1.f || fabsf(fy) > 1.f) c = 0.f;
+    fx = fminf(fmaxf(fx, -1.f), 1.f);
+    fy = fminf(fmaxf(fy, -1.f), 1.f);
+    const float gx = pix_coord(x, a.W), gy = pix_coord(y, a.H);
+    f32x4 o;
+    if (half == 0) o = f32x4{gx, gy, fx, fy};
+    else o = f32x4{fx, fy, gx, gy};
+    *reinterpret_cast<f32x4*>(a.warp + idx * 4) = o;
+    a.certainty[idx] = c;
+  }
+}
+
+int final_epilogue_launch(const FinalArgs& a, hipStream_t s) {
+  const long total = (long)a.B * a.H * (a.symmetric ? 2 * a.W : a.W);
+  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 65536));
+  hipLaunchKernelGGL(final_epilogue_kernel, grid, dim3(256), 0, s, a);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace roma

@@ -1,0 +1,29 @@
+// Fused local-window correlation - the reference's one native operator
+// (`local_corr.local_corr`, call site romatch/utils/local_correlation.py:22-35; semantics pinned
+// to the in-repo torch fallback :39-74):
+//   corr[b,p,k] = scale * sum_c f0[b,p,c] * bilinear_zeropad(f1[b'], coord[b,p,k])[c]
+#pragma once
+#include "common.h"
+
+namespace roma {
+
+struct LocalCorrArgs {
+  const void* f0 = nullptr;    // [nimg, HW, C]  channels-last, row stride ld0
+  const void* f1 = nullptr;    // [nimg, H, W, C] channels-last, pixel stride ld1
+  const float* warp = nullptr; // window form: [B, HW, 2] centre (x,y) normalised;  general form: [B, HW, K, 2]
+  void* out = nullptr;         // [B, HW, K] with row stride ldo (lets the op write into the refiner concat buffer)
+  int B = 0, H = 0, W = 0, C = 0;
+  int radius = 0;              // window form: K = (2r+1)^2
+  int K = 0;                   // general form
+  long ld0 = 0, ld1 = 0, ldo = 0;
+  int nimg = 0, f1_shift = 0;  // image of f0 = b, image of f1 = (b + f1_shift) % nimg
+  float scale = 1.f;           // 1/sqrt(C) when f0 is not pre-scaled
+  int in_dt = 0, out_dt = 0;
+};
+
+// Window form (integer-patch identity: all K taps share one fractional offset).
+int local_corr_window_launch(const LocalCorrArgs& a, hipStream_t stream);
+// General per-tap form (drop-in for the plugin signature).
+int local_corr_general_launch(const LocalCorrArgs& a, hipStream_t stream);
+
+}  // namespace roma

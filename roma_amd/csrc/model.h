@@ -1,0 +1,108 @@
+// Host-side model object behind the C ABI: state-dict intake, BN folding / repacking, device
+// workspace (bump arena, planned by a dry run - no allocation inside roma_match) and the
+// kernel schedule of RegressionMatcher.match() (romatch/models/matcher.py:779-934).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/roma_hip.h"
+#include "common.h"
+
+namespace roma {
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  long numel() const {
+    long n = 1;
+    for (auto d : shape) n *= d;
+    return n;
+  }
+};
+
+struct Lin {  // y = x W^T + b ; W in activation dtype [N][ldw]
+  void* w = nullptr;
+  float* b = nullptr;
+  int N = 0, K = 0, ldw = 0;
+};
+
+struct VitBlockW {
+  float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
+  Lin qkv, proj, fc1, fc2;
+};
+
+struct RefinerW {
+  int Cf = 0, E = 0, radius = 0, K = 0, C = 0, Cp = 0;
+  float *emb_w = nullptr, *emb_b = nullptr;
+  float* dw_w[9] = {nullptr};  // [25][Cp], BN folded
+  float* dw_b[9] = {nullptr};
+  Lin pw[9];
+  float *out_w = nullptr, *out_b = nullptr;  // [3][Cp], [3]
+};
+
+class Arena {
+ public:
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool dry = true;
+  void reset() { off = 0; }
+  void* alloc(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = dry ? reinterpret_cast<void*>((uintptr_t)0x1000 + off) : (void*)(base + off);
+    off += bytes;
+    if (off > peak) peak = off;
+    return p;
+  }
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+};
+
+class Model {
+ public:
+  roma_config_t cfg{};
+  int act_dt = 0;  // DT_F32 / DT_BF16
+  bool finalized = false;
+  bool debug = false;
+  std::map<std::string, HostTensor> host;
+
+  // packed weights (device)
+  float *c1_w = nullptr, *c1_b = nullptr;  // first VGG conv [27][64]
+  Lin vgg[12];                             // [1..11] implicit-GEMM convs (index 0 unused)
+  int vgg_cin[12] = {0}, vgg_cout[12] = {0};
+  Lin patch;
+  float *cls_tok = nullptr, *pos_emb = nullptr;  // pos-embed already resized to the coarse token grid
+  VitBlockW dino[24];
+  float *dino_nw = nullptr, *dino_nb = nullptr;
+  VitBlockW tdec[5];
+  Lin to_out;
+  float *gp_w = nullptr, *gp_b = nullptr;
+  Lin proj[5];  // scales 16,8,4,2,1
+  RefinerW ref[5];
+
+  Arena arena;        // per-call scratch
+  Arena persist;      // zero-initialised, never aliased (attention q/k/v^T pads, GP basis)
+  std::vector<void*> owned;  // device allocations to free
+  std::map<std::string, std::pair<void*, size_t>> dbg;
+
+  ~Model();
+  int set_tensor(const char* name, int ndim, const int64_t* shape, const void* data, int is_int64);
+  int finalize();
+  int match(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
+            float* cert, hipStream_t st);
+
+ private:
+  int check_contract();
+  int pack_weights();
+  int match_impl(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
+                 float* cert, hipStream_t st, bool dry);
+  int dbg_save(const char* name, const void* p, size_t bytes, hipStream_t st);
+  template <typename F> int upload_f32(const std::vector<float>& v, F** out);
+  int upload_act(const std::vector<float>& v, void** out);
+  int make_lin(const std::vector<float>& w, const std::vector<float>* b, int N, int K, Lin* out);
+};
+
+// Batched SPD solve via blocked Cholesky (see include/roma_hip.h roma_op_cholesky_solve_t)
+int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, int n, int d, int batch, hipStream_t st);
+
+}  // namespace roma

@@ -1,0 +1,843 @@
+// Model object: weight intake / packing and the match() kernel schedule (see model.h).
+#include "model.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <set>
+
+#include "attention.h"
+#include "elementwise.h"
+#include "gemm.h"
+#include "local_corr.h"
+
+namespace roma {
+
+static const int VGG_IDX[12] = {0, 3, 7, 10, 14, 17, 20, 23, 27, 30, 33, 36};
+static const int VGG_CH[12] = {64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512};
+static const char* SCALES[5] = {"16", "8", "4", "2", "1"};
+static const int SCALE_INT[5] = {16, 8, 4, 2, 1};
+static const int PROJ_CIN[5] = {1024, 512, 256, 128, 64};
+static const int PROJ_COUT[5] = {512, 512, 256, 64, 9};
+static const int REF_EMB[5] = {128, 64, 32, 16, 6};
+static const int REF_RAD[5] = {7, 3, 2, 0, 0};
+
+Model::~Model() {
+  for (void* p : owned) (void)hipFree(p);
+  for (auto& kv : dbg) (void)hipFree(kv.second.first);
+}
+
+int Model::set_tensor(const char* name, int ndim, const int64_t* shape, const void* data, int is_int64) {
+  ROMA_REQUIRE(!finalized, "roma_set_tensor: model already finalized");
+  ROMA_REQUIRE(name && data && ndim >= 0 && ndim <= 8, "roma_set_tensor: bad arguments");
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  const long n = t.numel();
+  t.data.resize((size_t)n);
+  if (is_int64) {
+    const int64_t* s = static_cast<const int64_t*>(data);
+    for (long i = 0; i < n; ++i) t.data[(size_t)i] = (float)s[i];
+  } else {
+    memcpy(t.data.data(), data, (size_t)n * sizeof(float));
+  }
+  host[name] = std::move(t);
+  return 0;
+}
+
+// ---------------------------------------------------------------- strict state-dict contract
+static void expect(std::vector<std::pair<std::string, std::vector<int64_t>>>& v, const std::string& k,
+                   std::vector<int64_t> s) {
+  v.emplace_back(k, std::move(s));
+}
+static void expect_bn(std::vector<std::pair<std::string, std::vector<int64_t>>>& v, const std::string& p, int c) {
+  expect(v, p + ".weight", {c});
+  expect(v, p + ".bias", {c});
+  expect(v, p + ".running_mean", {c});
+  expect(v, p + ".running_var", {c});
+  expect(v, p + ".num_batches_tracked", {});
+}
+
+int Model::check_contract() {
+  std::vector<std::pair<std::string, std::vector<int64_t>>> e;
+  int cin = 3;
+  for (int i = 0; i < 12; ++i) {
+    const std::string p = "encoder.cnn.layers." + std::to_string(VGG_IDX[i]);
+    expect(e, p + ".weight", {VGG_CH[i], cin, 3, 3});
+    expect(e, p + ".bias", {VGG_CH[i]});
+    expect_bn(e, "encoder.cnn.layers." + std::to_string(VGG_IDX[i] + 1), VGG_CH[i]);
+    cin = VGG_CH[i];
+  }
+  auto vit = [&](const std::string& p, bool qkv_bias, bool ls) {
+    expect(e, p + ".norm1.weight", {1024});
+    expect(e, p + ".norm1.bias", {1024});
+    expect(e, p + ".attn.qkv.weight", {3072, 1024});
+    if (qkv_bias) expect(e, p + ".attn.qkv.bias", {3072});
+    expect(e, p + ".attn.proj.weight", {1024, 1024});
+    expect(e, p + ".attn.proj.bias", {1024});
+    if (ls) expect(e, p + ".ls1.gamma", {1024});
+    expect(e, p + ".norm2.weight", {1024});
+    expect(e, p + ".norm2.bias", {1024});
+    expect(e, p + ".mlp.fc1.weight", {4096, 1024});
+    expect(e, p + ".mlp.fc1.bias", {4096});
+    expect(e, p + ".mlp.fc2.weight", {1024, 4096});
+    expect(e, p + ".mlp.fc2.bias", {1024});
+    if (ls) expect(e, p + ".ls2.gamma", {1024});
+  };
+  for (int i = 0; i < 5; ++i) vit("decoder.embedding_decoder.blocks." + std::to_string(i), false, false);
+  expect(e, "decoder.embedding_decoder.to_out.weight", {4097, 1024});
+  expect(e, "decoder.embedding_decoder.to_out.bias", {4097});
+  expect(e, "decoder.gps.16.pos_conv.weight", {512, 2, 1, 1});
+  expect(e, "decoder.gps.16.pos_conv.bias", {512});
+  for (int s = 0; s < 5; ++s) {
+    const std::string p = std::string("decoder.proj.") + SCALES[s];
+    expect(e, p + ".0.weight", {PROJ_COUT[s], PROJ_CIN[s], 1, 1});
+    expect(e, p + ".0.bias", {PROJ_COUT[s]});
+    expect_bn(e, p + ".1", PROJ_COUT[s]);
+  }
+  for (int s = 0; s < 5; ++s) {
+    const int K = REF_RAD[s] ? (2 * REF_RAD[s] + 1) * (2 * REF_RAD[s] + 1) : 0;
+    const int C = 2 * PROJ_COUT[s] + REF_EMB[s] + K;
+    const std::string p = std::string("decoder.conv_refiner.") + SCALES[s];
+    for (int b = 0; b < 9; ++b) {
+      const std::string bp = b == 0 ? p + ".block1" : p + ".hidden_blocks." + std::to_string(b - 1);
+      expect(e, bp + ".0.weight", {C, 1, 5, 5});
+      expect(e, bp + ".0.bias", {C});
+      expect_bn(e, bp + ".1", C);
+      expect(e, bp + ".3.weight", {C, C, 1, 1});
+      expect(e, bp + ".3.bias", {C});
+    }
+    expect(e, p + ".out_conv.weight", {3, C, 1, 1});
+    expect(e, p + ".out_conv.bias", {3});
+    expect(e, p + ".disp_emb.weight", {REF_EMB[s], 2, 1, 1});
+    expect(e, p + ".disp_emb.bias", {REF_EMB[s]});
+  }
+  // DINOv2 dict under the "dinov2." prefix
+  expect(e, "dinov2.cls_token", {1, 1, 1024});
+  expect(e, "dinov2.pos_embed", {1, 1370, 1024});
+  expect(e, "dinov2.mask_token", {1, 1024});
+  expect(e, "dinov2.patch_embed.proj.weight", {1024, 3, 14, 14});
+  expect(e, "dinov2.patch_embed.proj.bias", {1024});
+  for (int i = 0; i < 24; ++i) vit("dinov2.blocks." + std::to_string(i), true, true);
+  expect(e, "dinov2.norm.weight", {1024});
+  expect(e, "dinov2.norm.bias", {1024});
+
+  std::set<std::string> seen;
+  for (auto& kv : e) {
+    auto it = host.find(kv.first);
+    if (it == host.end()) {
+      set_error("roma_finalize: missing key in state_dict: " + kv.first);
+      return ROMA_ERR_STATE;
+    }
+    if (it->second.shape != kv.second) {
+      set_error("roma_finalize: size mismatch for " + kv.first);
+      return ROMA_ERR_STATE;
+    }
+    seen.insert(kv.first);
+  }
+  for (auto& kv : host)
+    if (!seen.count(kv.first)) {
+      set_error("roma_finalize: unexpected key in state_dict: " + kv.first);
+      return ROMA_ERR_STATE;
+    }
+  return 0;
+}
+
+// ---------------------------------------------------------------- uploads
+template <typename F>
+int Model::upload_f32(const std::vector<float>& v, F** out) {
+  void* p = nullptr;
+  ROMA_CHECK_HIP(hipMalloc(&p, std::max<size_t>(v.size(), 4) * sizeof(float)));
+  owned.push_back(p);
+  ROMA_CHECK_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = static_cast<F*>(p);
+  return 0;
+}
+
+int Model::upload_act(const std::vector<float>& v, void** out) {
+  if (act_dt == DT_F32) {
+    float* p = nullptr;
+    if (int rc = upload_f32(v, &p)) return rc;
+    *out = p;
+    return 0;
+  }
+  std::vector<bf16_t> h(v.size());
+  for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_bf16(v[i]);
+  void* p = nullptr;
+  ROMA_CHECK_HIP(hipMalloc(&p, std::max<size_t>(h.size(), 8) * sizeof(bf16_t)));
+  owned.push_back(p);
+  ROMA_CHECK_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+  *out = p;
+  return 0;
+}
+
+// w: [N][K] row-major; pads K to a multiple of 8
+int Model::make_lin(const std::vector<float>& w, const std::vector<float>* b, int N, int K, Lin* out) {
+  const int ldw = (int)round_up(K, 8);
+  std::vector<float> wp((size_t)N * ldw, 0.f);
+  for (int n = 0; n < N; ++n) memcpy(&wp[(size_t)n * ldw], &w[(size_t)n * K], (size_t)K * sizeof(float));
+  out->N = N;
+  out->K = ldw;
+  out->ldw = ldw;
+  if (int rc = upload_act(wp, &out->w)) return rc;
+  out->b = nullptr;
+  if (b)
+    if (int rc = upload_f32(*b, &out->b)) return rc;
+  return 0;
+}
+
+static void bn_fold(const std::map<std::string, HostTensor>& h, const std::string& p, std::vector<float>& s,
+                    std::vector<float>& t) {
+  const auto& g = h.at(p + ".weight").data;
+  const auto& be = h.at(p + ".bias").data;
+  const auto& mu = h.at(p + ".running_mean").data;
+  const auto& var = h.at(p + ".running_var").data;
+  s.resize(g.size());
+  t.resize(g.size());
+  for (size_t i = 0; i < g.size(); ++i) {
+    s[i] = g[i] / sqrtf(var[i] + 1e-5f);
+    t[i] = be[i] - mu[i] * s[i];
+  }
+}
+
+static inline float cubic1(float x) { const float A = -0.75f; return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+static inline float cubic2(float x) { const float A = -0.75f; return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+// DINOv2 interpolate_pos_encoding (romatch/models/transformer/dinov2.py:166-190): bicubic, A=-0.75, with the
+// scale_factor=(h0+0.1)/37 quirk (coordinates map with 37/(h0+0.1), not 37/h0).
+static std::vector<float> resize_pos_embed(const std::vector<float>& pos, int th, int tw) {
+  const int M = 37, D = 1024;
+  std::vector<float> out((size_t)(1 + th * tw) * D);
+  memcpy(out.data(), pos.data(), D * sizeof(float));
+  if (th == M && tw == M) {
+    memcpy(out.data(), pos.data(), out.size() * sizeof(float));
+    return out;
+  }
+  const float sh = (float)(1.0 / ((th + 0.1) / 37.0)), sw = (float)(1.0 / ((tw + 0.1) / 37.0));
+  std::vector<int> iy(th * 4), ix(tw * 4);
+  std::vector<float> wy(th * 4), wx(tw * 4);
+  auto prep = [&](int n, float scale, std::vector<int>& idx, std::vector<float>& wgt) {
+    for (int o = 0; o < n; ++o) {
+      const float src = scale * ((float)o + 0.5f) - 0.5f;
+      const float fl = floorf(src);
+      float t = src - fl;
+      t = std::min(std::max(t, 0.f), 1.f);
+      const int i0 = (int)fl;
+      const float c[4] = {cubic2(t + 1.f), cubic1(t), cubic1(1.f - t), cubic2(2.f - t)};
+      for (int j = 0; j < 4; ++j) {
+        idx[o * 4 + j] = std::max(std::min(i0 - 1 + j, M - 1), 0);
+        wgt[o * 4 + j] = c[j];
+      }
+    }
+  };
+  prep(th, sh, iy, wy);
+  prep(tw, sw, ix, wx);
+  const float* pp = pos.data() + D;  // patch part [37*37][D]
+  for (int y = 0; y < th; ++y)
+    for (int x = 0; x < tw; ++x) {
+      float* o = &out[(size_t)(1 + y * tw + x) * D];
+      for (int d = 0; d < D; ++d) o[d] = 0.f;
+      for (int a = 0; a < 4; ++a) {
+        for (int b = 0; b < 4; ++b) {
+          const float w = wy[y * 4 + a] * wx[x * 4 + b];
+          const float* src = pp + (size_t)(iy[y * 4 + a] * M + ix[x * 4 + b]) * D;
+          for (int d = 0; d < D; ++d) o[d] += w * src[d];
+        }
+      }
+    }
+  return out;
+}
+
+int Model::pack_weights() {
+  auto H = [&](const std::string& k) -> const std::vector<float>& { return host.at(k).data; };
+  // ---- VGG19-BN: fold BN, repack to [cout][(ky*3+kx)*cin + ci]
+  int cin = 3;
+  for (int i = 0; i < 12; ++i) {
+    const int cout = VGG_CH[i];
+    const std::string p = "encoder.cnn.layers." + std::to_string(VGG_IDX[i]);
+    std::vector<float> s, t;
+    bn_fold(host, "encoder.cnn.layers." + std::to_string(VGG_IDX[i] + 1), s, t);
+    const auto& w = H(p + ".weight");
+    const auto& b = H(p + ".bias");
+    std::vector<float> bf(cout);
+    for (int o = 0; o < cout; ++o) bf[o] = b[o] * s[o] + t[o];
+    if (i == 0) {
+      std::vector<float> wp(27 * 64);
+      for (int o = 0; o < 64; ++o)
+        for (int ci = 0; ci < 3; ++ci)
+          for (int k = 0; k < 9; ++k) wp[(ci * 9 + k) * 64 + o] = w[(o * 3 + ci) * 9 + k] * s[o];
+      if (int rc = upload_f32(wp, &c1_w)) return rc;
+      if (int rc = upload_f32(bf, &c1_b)) return rc;
+    } else {
+      std::vector<float> wp((size_t)cout * 9 * cin);
+      for (int o = 0; o < cout; ++o)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int k = 0; k < 9; ++k)
+            wp[(size_t)o * 9 * cin + (size_t)k * cin + ci] = w[((size_t)o * cin + ci) * 9 + k] * s[o];
+      if (int rc = make_lin(wp, &bf, cout, 9 * cin, &vgg[i])) return rc;
+    }
+    vgg_cin[i] = cin;
+    vgg_cout[i] = cout;
+    cin = cout;
+  }
+  // ---- ViT blocks
+  auto pack_vit = [&](const std::string& p, bool qkv_bias, bool ls, VitBlockW& o) -> int {
+    if (int rc = upload_f32(H(p + ".norm1.weight"), &o.ln1w)) return rc;
+    if (int rc = upload_f32(H(p + ".norm1.bias"), &o.ln1b)) return rc;
+    if (int rc = upload_f32(H(p + ".norm2.weight"), &o.ln2w)) return rc;
+    if (int rc = upload_f32(H(p + ".norm2.bias"), &o.ln2b)) return rc;
+    if (ls) {
+      if (int rc = upload_f32(H(p + ".ls1.gamma"), &o.ls1)) return rc;
+      if (int rc = upload_f32(H(p + ".ls2.gamma"), &o.ls2)) return rc;
+    }
+    if (int rc = make_lin(H(p + ".attn.qkv.weight"), qkv_bias ? &H(p + ".attn.qkv.bias") : nullptr, 3072, 1024, &o.qkv)) return rc;
+    if (int rc = make_lin(H(p + ".attn.proj.weight"), &H(p + ".attn.proj.bias"), 1024, 1024, &o.proj)) return rc;
+    if (int rc = make_lin(H(p + ".mlp.fc1.weight"), &H(p + ".mlp.fc1.bias"), 4096, 1024, &o.fc1)) return rc;
+    if (int rc = make_lin(H(p + ".mlp.fc2.weight"), &H(p + ".mlp.fc2.bias"), 1024, 4096, &o.fc2)) return rc;
+    return 0;
+  };
+  for (int i = 0; i < 24; ++i)
+    if (int rc = pack_vit("dinov2.blocks." + std::to_string(i), true, true, dino[i])) return rc;
+  for (int i = 0; i < 5; ++i)
+    if (int rc = pack_vit("decoder.embedding_decoder.blocks." + std::to_string(i), false, false, tdec[i])) return rc;
+  if (int rc = make_lin(H("dinov2.patch_embed.proj.weight"), &H("dinov2.patch_embed.proj.bias"), 1024, 588, &patch)) return rc;
+  {
+    std::vector<float> cls(H("dinov2.cls_token"));
+    if (int rc = upload_f32(cls, &cls_tok)) return rc;
+    std::vector<float> pe = resize_pos_embed(H("dinov2.pos_embed"), cfg.coarse_h / 14, cfg.coarse_w / 14);
+    if (int rc = upload_f32(pe, &pos_emb)) return rc;
+  }
+  if (int rc = upload_f32(H("dinov2.norm.weight"), &dino_nw)) return rc;
+  if (int rc = upload_f32(H("dinov2.norm.bias"), &dino_nb)) return rc;
+  if (int rc = make_lin(H("decoder.embedding_decoder.to_out.weight"), &H("decoder.embedding_decoder.to_out.bias"), 4097, 1024, &to_out)) return rc;
+  if (int rc = upload_f32(H("decoder.gps.16.pos_conv.weight"), &gp_w)) return rc;
+  if (int rc = upload_f32(H("decoder.gps.16.pos_conv.bias"), &gp_b)) return rc;
+  // ---- proj heads (conv1x1 + BN folded)
+  for (int s = 0; s < 5; ++s) {
+    const std::string p = std::string("decoder.proj.") + SCALES[s];
+    std::vector<float> sc, sh;
+    bn_fold(host, p + ".1", sc, sh);
+    const int co = PROJ_COUT[s], ci = PROJ_CIN[s];
+    std::vector<float> w(H(p + ".0.weight")), b(co);
+    for (int o = 0; o < co; ++o) {
+      for (int c = 0; c < ci; ++c) w[(size_t)o * ci + c] *= sc[o];
+      b[o] = H(p + ".0.bias")[o] * sc[o] + sh[o];
+    }
+    if (int rc = make_lin(w, &b, co, ci, &proj[s])) return rc;
+  }
+  // ---- ConvRefiners
+  for (int s = 0; s < 5; ++s) {
+    RefinerW& r = ref[s];
+    r.Cf = PROJ_COUT[s];
+    r.E = REF_EMB[s];
+    r.radius = REF_RAD[s];
+    r.K = r.radius ? (2 * r.radius + 1) * (2 * r.radius + 1) : 0;
+    r.C = 2 * r.Cf + r.E + r.K;
+    r.Cp = (int)round_up(r.C, 8);
+    const std::string p = std::string("decoder.conv_refiner.") + SCALES[s];
+    if (int rc = upload_f32(H(p + ".disp_emb.weight"), &r.emb_w)) return rc;
+    if (int rc = upload_f32(H(p + ".disp_emb.bias"), &r.emb_b)) return rc;
+    for (int b = 0; b < 9; ++b) {
+      const std::string bp = b == 0 ? p + ".block1" : p + ".hidden_blocks." + std::to_string(b - 1);
+      std::vector<float> sc, sh;
+      bn_fold(host, bp + ".1", sc, sh);
+      const auto& w = H(bp + ".0.weight");
+      const auto& bb = H(bp + ".0.bias");
+      std::vector<float> dw((size_t)25 * r.Cp, 0.f), db((size_t)r.Cp, 0.f);
+      for (int c = 0; c < r.C; ++c) {
+        for (int t = 0; t < 25; ++t) dw[(size_t)t * r.Cp + c] = w[(size_t)c * 25 + t] * sc[c];
+        db[c] = bb[c] * sc[c] + sh[c];
+      }
+      if (int rc = upload_f32(dw, &r.dw_w[b])) return rc;
+      if (int rc = upload_f32(db, &r.dw_b[b])) return rc;
+      const auto& pw = H(bp + ".3.weight");
+      std::vector<float> pwp((size_t)r.Cp * r.Cp, 0.f), pb((size_t)r.Cp, 0.f);
+      for (int o = 0; o < r.C; ++o) {
+        memcpy(&pwp[(size_t)o * r.Cp], &pw[(size_t)o * r.C], (size_t)r.C * sizeof(float));
+        pb[o] = H(bp + ".3.bias")[o];
+      }
+      if (int rc = make_lin(pwp, &pb, r.Cp, r.Cp, &r.pw[b])) return rc;
+    }
+    std::vector<float> ow((size_t)3 * r.Cp, 0.f);
+    for (int o = 0; o < 3; ++o)
+      memcpy(&ow[(size_t)o * r.Cp], &H(p + ".out_conv.weight")[(size_t)o * r.C], (size_t)r.C * sizeof(float));
+    if (int rc = upload_f32(ow, &r.out_w)) return rc;
+    if (int rc = upload_f32(H(p + ".out_conv.bias"), &r.out_b)) return rc;
+  }
+  return 0;
+}
+
+int Model::finalize() {
+  ROMA_REQUIRE(!finalized, "roma_finalize: already finalized");
+  ROMA_CHECK_HIP(hipSetDevice(cfg.device));
+  if (int rc = check_contract()) return rc;
+  act_dt = cfg.precision == ROMA_BF16 ? DT_BF16 : DT_F32;
+  if (int rc = pack_weights()) return rc;
+  host.clear();
+  // plan the workspace with a dry run at the largest configuration
+  arena.dry = persist.dry = true;
+  arena.peak = persist.peak = 0;
+  const int keep_sym = cfg.symmetric, keep_up = cfg.upsample_preds;
+  cfg.symmetric = 1;
+  cfg.upsample_preds = cfg.upsample_h > 0 ? 1 : 0;
+  int rc = match_impl(cfg.max_batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+  cfg.symmetric = keep_sym;
+  cfg.upsample_preds = keep_up;
+  if (rc) return rc;
+  arena.cap = arena.peak + 4096;
+  persist.cap = persist.peak + 4096;
+  ROMA_CHECK_HIP(hipMalloc((void**)&arena.base, arena.cap));
+  owned.push_back(arena.base);
+  ROMA_CHECK_HIP(hipMalloc((void**)&persist.base, persist.cap));
+  owned.push_back(persist.base);
+  ROMA_CHECK_HIP(hipMemset(persist.base, 0, persist.cap));
+  ROMA_CHECK_HIP(hipMemset(arena.base, 0, arena.cap));
+  arena.dry = persist.dry = false;
+  finalized = true;
+  return 0;
+}
+
+int Model::dbg_save(const char* name, const void* p, size_t bytes, hipStream_t st) {
+  if (!debug) return 0;
+  auto it = dbg.find(name);
+  if (it == dbg.end() || it->second.second != bytes) {
+    if (it != dbg.end()) (void)hipFree(it->second.first);
+    void* q = nullptr;
+    ROMA_CHECK_HIP(hipMalloc(&q, bytes));
+    dbg[name] = {q, bytes};
+    it = dbg.find(name);
+  }
+  ROMA_CHECK_HIP(hipMemcpyAsync(it->second.first, p, bytes, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int Model::match(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
+                 float* cert, hipStream_t st) {
+  ROMA_REQUIRE(finalized, "roma_match: call roma_finalize first");
+  ROMA_REQUIRE(B >= 1 && B <= cfg.max_batch, "roma_match: batch size out of range (max_batch)");
+  ROMA_REQUIRE(ima && imb && warp && cert, "roma_match: null image / output pointer");
+  if (cfg.upsample_preds) {
+    ROMA_REQUIRE(cfg.upsample_h > 0, "roma_match: upsample_preds set but the handle has no upsample resolution");
+    ROMA_REQUIRE(ima_hr && imb_hr, "roma_match: upsample_preds requires im_A_high_res and im_B_high_res");
+  }
+  ROMA_CHECK_HIP(hipSetDevice(cfg.device));
+  return match_impl(B, ima, imb, ima_hr, imb_hr, warp, cert, st, false);
+}
+
+// ---------------------------------------------------------------- blocked Cholesky solve (transposed RHS)
+// Solves A X = F for SPD A (n x n, n % 64 == 0) with Rt = F^T [d x n] overwritten by X^T.
+// Right-looking 64-wide blocked factorisation; diagonal blocks are factorised and explicitly inverted by one
+// workgroup (chol_diag), everything else is the MFMA GEMM with alpha = -1 accumulate:
+//   panel  L[i,k]  = A[i,k] Linv_kk^T ; trailing A[i,j] -= L[i,k] L[j,k]^T (lower tiles only)
+//   fwd    Yt[:,k] = Rt[:,k] Linv_kk^T ; Rt[:,i>k] -= Yt[:,k] L[i,k]^T
+//   bwd    Xt[:,k] = Rt[:,k] Linv_kk   ; Rt[:,j<k] -= Xt[:,k] L[k,j]      (via LT = L^T)
+int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, int n, int d, int batch, hipStream_t st) {
+  ROMA_REQUIRE(n % 64 == 0 && n > 0 && d % 4 == 0, "cholesky_solve: n must be a multiple of 64, d of 4");
+  const int nblk = n / 64;
+  const long sA = (long)n * n, sR = (long)d * n, sL = (long)nblk * 4096;
+  for (int k = 0; k < nblk; ++k) {
+    if (int rc = chol_diag_launch(A, n, sA, Linv, LinvT, k, nblk, batch, st)) return rc;
+    const int mrem = n - (k + 1) * 64;
+    if (mrem <= 0) break;
+    GemmArgs g;
+    g.A = A + (long)(k + 1) * 64 * n + k * 64; g.lda = n; g.sA = sA;
+    g.W = Linv + (long)k * 4096; g.ldw = 64; g.sW = sL;
+    g.C = const_cast<float*>(static_cast<const float*>(g.A)); g.ldc = n; g.sC = sA;
+    g.M = mrem; g.N = 64; g.K = 64; g.batch = batch;
+    if (int rc = gemm_launch(g, st)) return rc;
+    GemmArgs t;
+    t.A = g.A; t.lda = n; t.sA = sA;
+    t.W = g.A; t.ldw = n; t.sW = sA;
+    float* Ct = A + (long)(k + 1) * 64 * n + (k + 1) * 64;
+    t.C = Ct; t.ldc = n; t.sC = sA;
+    t.res = Ct; t.ldr = n; t.sR = sA;
+    t.alpha = -1.f; t.lower_only = 1;
+    t.M = mrem; t.N = mrem; t.K = 64; t.batch = batch;
+    if (int rc = gemm_launch(t, st)) return rc;
+  }
+  if (int rc = transpose_launch(A, LT, n, n, batch, st)) return rc;
+  for (int k = 0; k < nblk; ++k) {  // forward
+    GemmArgs g;
+    g.A = Rt + k * 64; g.lda = n; g.sA = sR;
+    g.W = Linv + (long)k * 4096; g.ldw = 64; g.sW = sL;
+    g.C = Rt + k * 64; g.ldc = n; g.sC = sR;
+    g.M = d; g.N = 64; g.K = 64; g.batch = batch;
+    if (int rc = gemm_launch(g, st)) return rc;
+    const int mrem = n - (k + 1) * 64;
+    if (mrem <= 0) break;
+    GemmArgs u;
+    u.A = Rt + k * 64; u.lda = n; u.sA = sR;
+    u.W = A + (long)(k + 1) * 64 * n + k * 64; u.ldw = n; u.sW = sA;
+    u.C = Rt + (k + 1) * 64; u.ldc = n; u.sC = sR;
+    u.res = Rt + (k + 1) * 64; u.ldr = n; u.sR = sR;
+    u.alpha = -1.f;
+    u.M = d; u.N = mrem; u.K = 64; u.batch = batch;
+    if (int rc = gemm_launch(u, st)) return rc;
+  }
+  for (int k = nblk - 1; k >= 0; --k) {  // backward
+    GemmArgs g;
+    g.A = Rt + k * 64; g.lda = n; g.sA = sR;
+    g.W = LinvT + (long)k * 4096; g.ldw = 64; g.sW = sL;
+    g.C = Rt + k * 64; g.ldc = n; g.sC = sR;
+    g.M = d; g.N = 64; g.K = 64; g.batch = batch;
+    if (int rc = gemm_launch(g, st)) return rc;
+    if (k == 0) break;
+    GemmArgs u;
+    u.A = Rt + k * 64; u.lda = n; u.sA = sR;
+    u.W = LT + k * 64; u.ldw = n; u.sW = sA;
+    u.C = Rt; u.ldc = n; u.sC = sR;
+    u.res = Rt; u.ldr = n; u.sR = sR;
+    u.alpha = -1.f;
+    u.M = d; u.N = k * 64; u.K = 64; u.batch = batch;
+    if (int rc = gemm_launch(u, st)) return rc;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- the match() schedule
+#define RUN(expr)                 \
+  do {                            \
+    if (!dry) {                   \
+      int _rc = (expr);           \
+      if (_rc) return _rc;        \
+    }                             \
+  } while (0)
+
+int Model::match_impl(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr,
+                      float* warp_out, float* cert_out, hipStream_t st, bool dry) {
+  const size_t esz = act_dt == DT_F32 ? 4 : 2;
+  const int nimg = 2 * B;
+  const int ndp = cfg.symmetric ? 2 * B : B;
+  const int shift = B;  // support image of directed pair i = (i + B) % nimg
+  arena.reset();
+  persist.reset();
+  auto AL = [&](size_t elems, size_t es) { return arena.alloc(elems * es); };
+  auto off = [&](void* p, long elems) -> void* { return static_cast<char*>(p) + elems * (long)esz; };
+
+  // ---- persistent, zero-initialised attention workspaces (pads must stay finite)
+  const int th = cfg.coarse_h / 14, tw = cfg.coarse_w / 14, T = th * tw;
+  const int Nd = T + 1, Npd = (int)round_up(Nd, 128), Npt = (int)round_up(T, 128);
+  const size_t qkv_elems = std::max((size_t)nimg * 16 * Npd * 64, (size_t)ndp * 8 * Npt * 128);
+  void* qbuf = persist.alloc(qkv_elems * esz);
+  void* kbuf = persist.alloc(qkv_elems * esz);
+  void* vtbuf = persist.alloc(qkv_elems * esz);
+
+  // ---- results that live across the two passes
+  float* cert16_keep = (float*)AL((size_t)ndp * T, 4);
+  float* flow_p1 = (float*)AL((size_t)ndp * cfg.coarse_h * cfg.coarse_w * 2, 4);
+  float* cert_p1 = (float*)AL((size_t)ndp * cfg.coarse_h * cfg.coarse_w, 4);
+  const int Hfin = cfg.upsample_preds ? cfg.upsample_h : cfg.coarse_h;
+  const int Wfin = cfg.upsample_preds ? cfg.upsample_w : cfg.coarse_w;
+  float* flow_fin = flow_p1;
+  float* cert_fin = cert_p1;
+  if (cfg.upsample_preds) {
+    flow_fin = (float*)AL((size_t)ndp * Hfin * Wfin * 2, 4);
+    cert_fin = (float*)AL((size_t)ndp * Hfin * Wfin, 4);
+  }
+
+  // shared ViT block (DINOv2 and the coordinate decoder): x f32 residual stream, in place
+  auto vit_block = [&](const VitBlockW& w, float* x, long rows, int Bn, int N, int npad, int heads, int hd, float eps,
+                       void* ln, void* ao, void* hid) -> int {
+    RUN(layernorm_launch(x, w.ln1w, w.ln1b, ln, rows, 1024, eps, act_dt, st));
+    {
+      GemmArgs g;
+      g.A = ln; g.lda = 1024; g.W = w.qkv.w; g.ldw = w.qkv.ldw; g.M = (int)rows; g.N = 3072; g.K = 1024;
+      g.in_dt = act_dt; g.out_dt = act_dt; g.bias = w.qkv.b; g.mode = EPI_QKV;
+      g.q = qbuf; g.k = kbuf; g.vt = vtbuf; g.heads = heads; g.hd = hd; g.ntok = N; g.npad = npad;
+      g.qscale = 1.0f / sqrtf((float)hd);
+      RUN(gemm_launch(g, st));
+    }
+    {
+      AttnArgs a;
+      a.q = qbuf; a.k = kbuf; a.vt = vtbuf; a.out = ao; a.B = Bn; a.heads = heads; a.N = N; a.npad = npad; a.hd = hd;
+      a.ldo = 1024; a.in_dt = act_dt; a.out_dt = act_dt;
+      RUN(attention_launch(a, st));
+    }
+    {
+      GemmArgs g;
+      g.A = ao; g.lda = 1024; g.W = w.proj.w; g.ldw = w.proj.ldw; g.C = x; g.ldc = 1024; g.M = (int)rows; g.N = 1024; g.K = 1024;
+      g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = w.proj.b; g.scale = w.ls1; g.res = x; g.ldr = 1024;
+      RUN(gemm_launch(g, st));
+    }
+    RUN(layernorm_launch(x, w.ln2w, w.ln2b, ln, rows, 1024, eps, act_dt, st));
+    {
+      GemmArgs g;
+      g.A = ln; g.lda = 1024; g.W = w.fc1.w; g.ldw = w.fc1.ldw; g.C = hid; g.ldc = 4096; g.M = (int)rows; g.N = 4096; g.K = 1024;
+      g.in_dt = act_dt; g.out_dt = act_dt; g.bias = w.fc1.b; g.act = ACT_GELU;
+      RUN(gemm_launch(g, st));
+    }
+    {
+      GemmArgs g;
+      g.A = hid; g.lda = 4096; g.W = w.fc2.w; g.ldw = w.fc2.ldw; g.C = x; g.ldc = 1024; g.M = (int)rows; g.N = 1024; g.K = 4096;
+      g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = w.fc2.b; g.scale = w.ls2; g.res = x; g.ldr = 1024;
+      RUN(gemm_launch(g, st));
+    }
+    return 0;
+  };
+
+  for (int pass = 0; pass < (cfg.upsample_preds ? 2 : 1); ++pass) {
+    const bool up = pass == 1;
+    const int H = up ? cfg.upsample_h : cfg.coarse_h, W = up ? cfg.upsample_w : cfg.coarse_w;
+    const float* imA = up ? ima_hr : ima;
+    const float* imB = up ? imb_hr : imb;
+    const size_t pass_mark = arena.mark();
+    // =============================== encoder: VGG19-BN pyramid (encoders.py:17-27)
+    void* feat[5] = {nullptr};  // index by log2(stride): 0 -> stride 1 ... 3 -> stride 8 ; [4] = stride 16 (DINOv2)
+    const int fh[4] = {H, H / 2, H / 4, H / 8}, fw[4] = {W, W / 2, W / 4, W / 8};
+    const int fc[4] = {64, 128, 256, 512};
+    for (int l = 0; l < 4; ++l) feat[l] = AL((size_t)nimg * fh[l] * fw[l] * fc[l], esz);
+    {
+      const size_t enc_mark = arena.mark();
+      void* t0 = AL((size_t)nimg * H * W * 64, esz);
+      void* t1 = AL((size_t)nimg * (H / 2) * (W / 2) * 64, esz);
+      RUN(conv3x3_c3_launch(imA, c1_w, c1_b, t0, B, H, W, act_dt, st));
+      RUN(conv3x3_c3_launch(imB, c1_w, c1_b, off(t0, (long)B * H * W * 64), B, H, W, act_dt, st));
+      auto conv = [&](int li, const void* in, void* out, int h, int w) -> int {
+        GemmArgs g;
+        g.A = in; g.W = vgg[li].w; g.ldw = vgg[li].ldw; g.C = out; g.ldc = vgg_cout[li];
+        g.M = nimg * h * w; g.N = vgg_cout[li]; g.K = 9 * vgg_cin[li];
+        g.in_dt = act_dt; g.out_dt = act_dt; g.bias = vgg[li].b; g.act = ACT_RELU;
+        g.conv_h = h; g.conv_w = w; g.conv_c = vgg_cin[li];
+        RUN(gemm_launch(g, st));
+        return 0;
+      };
+      if (int rc = conv(1, t0, feat[0], H, W)) return rc;
+      RUN(maxpool2x2_launch(feat[0], t1, nimg, H, W, 64, act_dt, st));
+      if (int rc = conv(2, t1, t0, H / 2, W / 2)) return rc;
+      if (int rc = conv(3, t0, feat[1], H / 2, W / 2)) return rc;
+      RUN(maxpool2x2_launch(feat[1], t1, nimg, H / 2, W / 2, 128, act_dt, st));
+      if (int rc = conv(4, t1, t0, H / 4, W / 4)) return rc;
+      if (int rc = conv(5, t0, t1, H / 4, W / 4)) return rc;
+      if (int rc = conv(6, t1, t0, H / 4, W / 4)) return rc;
+      if (int rc = conv(7, t0, feat[2], H / 4, W / 4)) return rc;
+      RUN(maxpool2x2_launch(feat[2], t1, nimg, H / 4, W / 4, 256, act_dt, st));
+      if (int rc = conv(8, t1, t0, H / 8, W / 8)) return rc;
+      if (int rc = conv(9, t0, t1, H / 8, W / 8)) return rc;
+      if (int rc = conv(10, t1, t0, H / 8, W / 8)) return rc;
+      if (int rc = conv(11, t0, feat[3], H / 8, W / 8)) return rc;
+      arena.release(enc_mark);
+    }
+    if (debug && !dry && !up) {
+      for (int l = 0; l < 4; ++l) {
+        const std::string nm = "feat" + std::to_string(1 << l);
+        if (int rc = dbg_save(nm.c_str(), feat[l], (size_t)nimg * fh[l] * fw[l] * fc[l] * esz, st)) return rc;
+      }
+    }
+    // shared transformer scratch (DINOv2 rows >= decoder rows)
+    const long rows_d = (long)nimg * Nd, rows_t = (long)ndp * T;
+    void *ln = nullptr, *ao = nullptr, *hid = nullptr;
+    if (!up) {
+      feat[4] = AL((size_t)nimg * T * 1024, esz);
+      const long rmax = std::max(rows_d, rows_t);
+      ln = AL((size_t)rmax * 1024, esz);
+      ao = AL((size_t)rmax * 1024, esz);
+      hid = AL((size_t)rmax * 4096, esz);
+      // =============================== encoder: DINOv2 ViT-L/14 (dinov2.py:192-237)
+      const size_t dmark = arena.mark();
+      void* col = AL((size_t)nimg * T * patch.ldw, esz);
+      float* pt = (float*)AL((size_t)nimg * T * 1024, 4);
+      float* x = (float*)AL((size_t)rows_d * 1024, 4);
+      RUN(im2col_patch14_launch(imA, col, B, H, W, patch.ldw, act_dt, st));
+      RUN(im2col_patch14_launch(imB, off(col, (long)B * T * patch.ldw), B, H, W, patch.ldw, act_dt, st));
+      {
+        GemmArgs g;
+        g.A = col; g.lda = patch.ldw; g.W = patch.w; g.ldw = patch.ldw; g.C = pt; g.ldc = 1024;
+        g.M = nimg * T; g.N = 1024; g.K = patch.ldw; g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = patch.b;
+        RUN(gemm_launch(g, st));
+      }
+      RUN(assemble_tokens_launch(pt, cls_tok, pos_emb, x, nimg, T, 1024, st));
+      for (int i = 0; i < 24; ++i)
+        if (int rc = vit_block(dino[i], x, rows_d, nimg, Nd, Npd, 16, 64, 1e-6f, ln, ao, hid)) return rc;
+      RUN(layernorm_launch(x, dino_nw, dino_nb, ln, rows_d, 1024, 1e-6f, act_dt, st));
+      for (int i = 0; i < nimg; ++i)  // drop the cls token: x_norm_patchtokens
+        RUN(copy2d_launch(off(ln, ((long)i * Nd + 1) * 1024), 1024, act_dt, off(feat[4], (long)i * T * 1024), 1024, act_dt, T, 1024, st));
+      arena.release(dmark);
+      if (debug && !dry)
+        if (int rc = dbg_save("feat16", feat[4], (size_t)nimg * T * 1024 * esz, st)) return rc;
+    }
+
+    // =============================== decoder (matcher.py:395-527)
+    float* flowA = (float*)AL((size_t)ndp * H * W * 2, 4);
+    float* flowB = (float*)AL((size_t)ndp * H * W * 2, 4);
+    float* certA = (float*)AL((size_t)ndp * H * W, 4);
+    float* certB = (float*)AL((size_t)ndp * H * W, 4);
+    float *flow = flowA, *cert = certA, *flow_alt = flowB, *cert_alt = certB;
+    int ch = 0, cw = 0;  // current flow map size
+    if (up) {
+      ch = H / 8; cw = W / 8;
+      RUN(resize_bilinear_launch(flow_p1, flow, ndp, cfg.coarse_h, cfg.coarse_w, ch, cw, 2, st));
+      RUN(resize_bilinear_launch(cert_p1, cert, ndp, cfg.coarse_h, cfg.coarse_w, ch, cw, 1, st));
+    }
+    const double scale_factor = sqrt((double)H * (double)W / (560.0 * 560.0));  // matcher.py:805, 877-881
+    for (int si = up ? 1 : 0; si < 5; ++si) {
+      const int ins = SCALE_INT[si];
+      const int hs = ins == 16 ? th : H / ins, ws = ins == 16 ? tw : W / ins;
+      const long hw = (long)hs * ws;
+      const RefinerW& r = ref[si];
+      const size_t smark = arena.mark();
+      // ---- proj head, once per image (proj(f_s) == swap(proj(f_q)) since it is per-image)
+      const int ldf = (int)round_up(r.Cf, 8);
+      void* pf = AL((size_t)nimg * hw * ldf, esz);
+      {
+        const int lvl = ins == 16 ? 4 : (ins == 8 ? 3 : (ins == 4 ? 2 : (ins == 2 ? 1 : 0)));
+        GemmArgs g;
+        g.A = feat[lvl]; g.lda = PROJ_CIN[si]; g.W = proj[si].w; g.ldw = proj[si].ldw; g.C = pf; g.ldc = ldf;
+        g.M = (int)(nimg * hw); g.N = r.Cf; g.K = PROJ_CIN[si]; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = proj[si].b;
+        RUN(gemm_launch(g, st));
+      }
+      if (ins == 16) {
+        if (debug && !dry)
+          if (int rc = dbg_save("proj16", pf, (size_t)nimg * hw * ldf * esz, st)) return rc;
+        // ================= GP match encoder (matcher.py:291-323), f32
+        const int n = T, npad = (int)round_up(n, 64), nblk = npad / 64;
+        const size_t gmark = arena.mark();
+        float* tokens = (float*)AL((size_t)rows_t * 1024, 4);
+        const size_t gmark2 = arena.mark();
+        float* norms = (float*)AL((size_t)nimg * n, 4);
+        float* Kyy = (float*)AL((size_t)nimg * npad * npad, 4);
+        float* LT = (float*)AL((size_t)nimg * npad * npad, 4);
+        float* Kxy = (float*)AL((size_t)ndp * n * npad, 4);
+        float* Linv = (float*)AL((size_t)nimg * nblk * 4096, 4);
+        float* LinvT = (float*)AL((size_t)nimg * nblk * 4096, 4);
+        float* Ft = (float*)AL((size_t)512 * npad, 4);
+        float* Rt = (float*)AL((size_t)nimg * 512 * npad, 4);
+        RUN(rownorm_launch(pf, ldf, act_dt, norms, (long)nimg * n, 512, st));
+        // support images actually needed: symmetric -> all, else images [B, 2B)
+        const int j0 = cfg.symmetric ? 0 : B, nj = cfg.symmetric ? nimg : B;
+        {
+          GemmArgs g;  // K_yy + sigma^2 I  (cosine kernel, CosKernel matcher.py:191-200)
+          g.A = off(pf, (long)j0 * n * ldf); g.lda = ldf; g.sA = (long)n * ldf;
+          g.W = g.A; g.ldw = ldf; g.sW = g.sA;
+          g.C = Kyy + (long)j0 * npad * npad; g.ldc = npad; g.sC = (long)npad * npad;
+          g.M = n; g.N = n; g.K = 512; g.batch = nj; g.in_dt = act_dt; g.out_dt = DT_F32; g.mode = EPI_COSK;
+          g.nx = norms + (long)j0 * n; g.ny = g.nx; g.sNx = n; g.sNy = n; g.inv_t = 1.0f / 0.2f; g.diag_add = 0.1f;
+          RUN(gemm_launch(g, st));
+        }
+        RUN(pad_identity_launch(Kyy + (long)j0 * npad * npad, npad, (long)npad * npad, n, npad, nj, st));
+        if (!dry) ROMA_CHECK_HIP(hipMemsetAsync(Kxy, 0, (size_t)ndp * n * npad * 4, st));
+        for (int half = 0; half < (cfg.symmetric ? 2 : 1); ++half) {
+          GemmArgs g;  // K_xy for directed pairs [half*B, half*B + B): x = image i, y = image (i + B) % nimg
+          const int i0 = half * B, s0 = (i0 + shift) % nimg;
+          g.A = off(pf, (long)i0 * n * ldf); g.lda = ldf; g.sA = (long)n * ldf;
+          g.W = off(pf, (long)s0 * n * ldf); g.ldw = ldf; g.sW = (long)n * ldf;
+          g.C = Kxy + (long)i0 * n * npad; g.ldc = npad; g.sC = (long)n * npad;
+          g.M = n; g.N = n; g.K = 512; g.batch = B; g.in_dt = act_dt; g.out_dt = DT_F32; g.mode = EPI_COSK;
+          g.nx = norms + (long)i0 * n; g.ny = norms + (long)s0 * n; g.sNx = n; g.sNy = n; g.inv_t = 1.0f / 0.2f;
+          RUN(gemm_launch(g, st));
+        }
+        RUN(gp_basis_launch(gp_w, gp_b, Ft, 512, th, tw, npad, st));
+        for (int j = j0; j < j0 + nj; ++j)
+          if (!dry) ROMA_CHECK_HIP(hipMemcpyAsync(Rt + (long)j * 512 * npad, Ft, (size_t)512 * npad * 4, hipMemcpyDeviceToDevice, st));
+        RUN(cholesky_solve_t(Kyy + (long)j0 * npad * npad, Rt + (long)j0 * 512 * npad, LT + (long)j0 * npad * npad,
+                             Linv + (long)j0 * nblk * 4096, LinvT + (long)j0 * nblk * 4096, npad, 512, nj, st));
+        for (int half = 0; half < (cfg.symmetric ? 2 : 1); ++half) {
+          GemmArgs g;  // mu = K_xy alpha  -> tokens[:, 0:512]
+          const int i0 = half * B, s0 = (i0 + shift) % nimg;
+          g.A = Kxy + (long)i0 * n * npad; g.lda = npad; g.sA = (long)n * npad;
+          g.W = Rt + (long)s0 * 512 * npad; g.ldw = npad; g.sW = (long)512 * npad;
+          g.C = tokens + (long)i0 * n * 1024; g.ldc = 1024; g.sC = (long)n * 1024;
+          g.M = n; g.N = 512; g.K = npad; g.batch = B;
+          RUN(gemm_launch(g, st));
+        }
+        arena.release(gmark2);
+        RUN(copy2d_launch(pf, ldf, act_dt, tokens + 512, 1024, DT_F32, rows_t, 512, st));
+        if (debug && !dry)
+          if (int rc = dbg_save("tokens16", tokens, (size_t)rows_t * 1024 * 4, st)) return rc;
+        // ================= coordinate decoder (transformer/__init__.py:30-46)
+        for (int i = 0; i < 5; ++i)
+          if (int rc = vit_block(tdec[i], tokens, rows_t, ndp, T, Npt, 8, 128, 1e-5f, ln, ao, hid)) return rc;
+        const int ldl = 4104;
+        float* logits = (float*)AL((size_t)rows_t * ldl, 4);
+        const void* zin = tokens;
+        if (act_dt != DT_F32) {
+          RUN(copy2d_launch(tokens, 1024, DT_F32, ln, 1024, act_dt, rows_t, 1024, st));
+          zin = ln;
+        }
+        {
+          GemmArgs g;
+          g.A = zin; g.lda = 1024; g.W = to_out.w; g.ldw = to_out.ldw; g.C = logits; g.ldc = ldl;
+          g.M = (int)rows_t; g.N = 4097; g.K = 1024; g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = to_out.b;
+          RUN(gemm_launch(g, st));
+        }
+        if (debug && !dry)
+          if (int rc = dbg_save("logits16", logits, (size_t)rows_t * ldl * 4, st)) return rc;
+        RUN(cls_to_flow_launch(logits, ldl, flow, cert, rows_t, st));
+        ch = th; cw = tw;
+        if (debug && !dry) {
+          if (int rc = dbg_save("gm_flow16", flow, (size_t)rows_t * 2 * 4, st)) return rc;
+          if (int rc = dbg_save("gm_cert16", cert, (size_t)rows_t * 4, st)) return rc;
+        }
+        arena.release(gmark);
+        // pf must survive (allocated before gmark) - it does.
+      }
+      // ================= ConvRefiner (matcher.py:124-179)
+      {
+        const long M = (long)ndp * hw;
+        void* d0 = AL((size_t)M * r.Cp, esz);
+        void* d1 = AL((size_t)M * r.Cp, esz);
+        RefinerInputArgs ia;
+        ia.feat = pf; ia.ldf = ldf; ia.flow = flow; ia.d = d0; ia.ldd = r.Cp; ia.emb_w = r.emb_w; ia.emb_b = r.emb_b;
+        ia.B = ndp; ia.H = hs; ia.W = ws; ia.C = r.Cf; ia.E = r.E; ia.Kcorr = r.K; ia.nimg = nimg; ia.shift = shift;
+        ia.disp_scale = (float)(40.0 / 32.0 * scale_factor); ia.dt = act_dt;
+        RUN(refiner_input_launch(ia, st));
+        if (r.radius) {
+          LocalCorrArgs lc;
+          lc.f0 = pf; lc.f1 = pf; lc.warp = flow; lc.out = off(d0, 2 * r.Cf + r.E);
+          lc.B = ndp; lc.H = hs; lc.W = ws; lc.C = r.Cf; lc.radius = r.radius; lc.ld0 = ldf; lc.ld1 = ldf; lc.ldo = r.Cp;
+          lc.nimg = nimg; lc.f1_shift = shift; lc.scale = 1.0f / sqrtf((float)r.Cf); lc.in_dt = act_dt; lc.out_dt = act_dt;
+          RUN(local_corr_window_launch(lc, st));
+        }
+        if (debug && !dry) {
+          const std::string nm = std::string("p") + (up ? "2" : "1") + "_din" + SCALES[si];
+          if ((size_t)M * r.Cp * esz <= ((size_t)64 << 20))
+            if (int rc = dbg_save(nm.c_str(), d0, (size_t)M * r.Cp * esz, st)) return rc;
+        }
+        for (int b = 0; b < 9; ++b) {
+          RUN(dwconv5x5_launch(d0, d1, r.dw_w[b], r.dw_b[b], ndp, hs, ws, r.Cp, act_dt, st));
+          GemmArgs g;
+          g.A = d1; g.lda = r.Cp; g.W = r.pw[b].w; g.ldw = r.pw[b].ldw; g.C = d0; g.ldc = r.Cp;
+          g.M = (int)M; g.N = r.Cp; g.K = r.Cp; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = r.pw[b].b;
+          RUN(gemm_launch(g, st));
+        }
+        const float sx = (float)ins / (4.0f * (float)W), sy = (float)ins / (4.0f * (float)H);
+        RUN(refiner_out_launch(d0, r.Cp, act_dt, r.out_w, r.out_b, flow, cert, M, r.Cp, sx, sy, st));
+      }
+      if (debug && !dry) {
+        const std::string pfx = std::string("p") + (up ? "2" : "1");
+        if (int rc = dbg_save((pfx + "_flow" + SCALES[si]).c_str(), flow, (size_t)ndp * hw * 2 * 4, st)) return rc;
+        if (int rc = dbg_save((pfx + "_cert" + SCALES[si]).c_str(), cert, (size_t)ndp * hw * 4, st)) return rc;
+      }
+      if (ins == 16 && !dry)
+        ROMA_CHECK_HIP(hipMemcpyAsync(cert16_keep, cert, (size_t)ndp * hw * 4, hipMemcpyDeviceToDevice, st));
+      arena.release(smark);
+      if (ins != 1) {
+        const int nh = H / (ins / 2), nw = W / (ins / 2);
+        RUN(resize_bilinear_launch(flow, flow_alt, ndp, hs, ws, nh, nw, 2, st));
+        RUN(resize_bilinear_launch(cert, cert_alt, ndp, hs, ws, nh, nw, 1, st));
+        std::swap(flow, flow_alt);
+        std::swap(cert, cert_alt);
+        ch = nh; cw = nw;
+      }
+    }
+    (void)ch; (void)cw;
+    // keep the finest flow / certainty of this pass
+    float* fdst = up ? flow_fin : flow_p1;
+    float* cdst = up ? cert_fin : cert_p1;
+    if (!dry) {
+      ROMA_CHECK_HIP(hipMemcpyAsync(fdst, flow, (size_t)ndp * H * W * 2 * 4, hipMemcpyDeviceToDevice, st));
+      ROMA_CHECK_HIP(hipMemcpyAsync(cdst, cert, (size_t)ndp * H * W * 4, hipMemcpyDeviceToDevice, st));
+    }
+    arena.release(pass_mark);
+  }
+  // =============================== epilogue (matcher.py:839-850, 891-929)
+  FinalArgs fa;
+  fa.flow = cfg.upsample_preds ? flow_fin : flow_p1;
+  fa.cert = cfg.upsample_preds ? cert_fin : cert_p1;
+  fa.cert16 = cfg.attenuate_cert ? cert16_keep : nullptr;
+  fa.warp = warp_out; fa.certainty = cert_out;
+  fa.B = B; fa.H = Hfin; fa.W = Wfin; fa.h16 = th; fa.w16 = tw; fa.symmetric = cfg.symmetric;
+  RUN(final_epilogue_launch(fa, st));
+  return 0;
+}
+
+}  // namespace roma

@@ -1,0 +1,300 @@
+"""Host-side mirror of the reference's matcher API over libroma_hip (ctypes).
+
+Same names, argument meaning and error behaviour as
+  romatch/models/matcher.py:550-934        RegressionMatcher (match / attributes / helpers)
+  romatch/models/model_zoo/roma_models.py:32-205   roma_model
+  romatch/models/model_zoo/__init__.py:31-93       roma_outdoor / roma_indoor
+All arithmetic of match() runs in hand-written HIP kernels; torch is only the tensor
+container (device memory, current stream).  There is no CPU path: a missing library or a
+non-GPU device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Optional, Union
+from warnings import warn
+
+import numpy as np
+import torch
+
+from . import _lib
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def _to_hw(res):
+    if res is None:
+        return None
+    if isinstance(res, int):
+        return (res, res)
+    return (int(res[0]), int(res[1]))
+
+
+def _check_input(im_input):
+    """romatch/models/matcher.py:530-547 (same exceptions)."""
+    from PIL import Image
+    if isinstance(im_input, (str, os.PathLike)):
+        im = Image.open(im_input)
+        if im.mode == "I;16":  # utils.py:655-657
+            raise NotImplementedError("Can't handle 16 bit images")
+        return im.convert("RGB")
+    if isinstance(im_input, Image.Image):
+        if im_input.mode != "RGB":  # utils.py:659-661
+            raise NotImplementedError("Can't handle non-RGB images")
+        return im_input
+    assert isinstance(im_input, torch.Tensor), "im_input must be a string, path, or PIL image"
+    B, Cc, H, W = im_input.shape
+    assert Cc == 3, "im_input must be a RGB image"
+    assert H % 14 == 0, "im_input must be a multiple of 14"
+    assert W % 14 == 0, "im_input must be a multiple of 14"
+    return im_input
+
+
+def _pil_to_normalised(im, hw):
+    """get_tuple_transform_ops(resize=hw, normalize=True) (utils/utils.py:164-173): PIL bicubic resize,
+    /255, ImageNet mean/std."""
+    from PIL import Image
+    h, w = hw
+    im = im.resize((w, h), resample=Image.BICUBIC)
+    a = np.array(im, dtype=np.float32).transpose((2, 0, 1)) / np.float32(255.0)
+    mean = np.array(IMAGENET_MEAN, dtype=np.float32)[:, None, None]
+    std = np.array(IMAGENET_STD, dtype=np.float32)[:, None, None]
+    return torch.from_numpy((a - mean) / std)
+
+
+class RegressionMatcher:
+    """Drop-in for romatch.models.matcher.RegressionMatcher (inference surface)."""
+
+    def __init__(self, weights, dinov2_weights, h=560, w=560, sample_mode="threshold_balanced", upsample_preds=False,
+                 symmetric=False, sample_thresh=0.05, name=None, attenuate_cert=None, upsample_res=None,
+                 device=None, amp_dtype=torch.float16, max_batch=8):
+        _lib.load()
+        dev = torch.device(device if device is not None else "cuda")
+        if dev.type != "cuda":
+            raise _lib.RomaHipError(f"roma_amd runs only on a HIP device (got device={device!r}); there is no CPU fallback")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.attenuate_cert = attenuate_cert
+        self.name = name
+        self.w_resized = w
+        self.h_resized = h
+        self.sample_mode = sample_mode
+        self.upsample_preds = upsample_preds
+        self.upsample_res = _to_hw(upsample_res) or (14 * 16 * 6, 14 * 16 * 6)
+        self.symmetric = symmetric
+        self.sample_thresh = sample_thresh
+        self.amp_dtype = amp_dtype
+        self.max_batch = int(max_batch)
+        self.training = False
+        self.debug = False
+        self._weights = weights
+        self._dinov2_weights = dinov2_weights
+        self._handle = None
+        self._built = None
+        self._ensure_handle()
+
+    # ------------------------------------------------------------------ handle management
+    def _config_key(self):
+        up = tuple(int(v) for v in self.upsample_res) if self.upsample_preds else (0, 0)
+        return (int(self.h_resized), int(self.w_resized), up,
+                _lib.ROMA_F32 if self.amp_dtype == torch.float32 else _lib.ROMA_BF16, self.max_batch, self.device.index)
+
+    def _ensure_handle(self):
+        key = self._config_key()
+        if self._handle is not None and self._built == key:
+            return
+        self._release()
+        lib = _lib.load()
+        uh, uw = key[2]
+        if uh % 8 or uw % 8:
+            raise ValueError("upsample_res must be a multiple of 8 (VGG19 feature pyramid)")
+        cfg = _lib.RomaConfig(key[0], key[1], uh, uw, int(bool(self.symmetric)), int(bool(self.upsample_preds)),
+                              int(bool(self.attenuate_cert)), key[3], self.max_batch, self.device.index)
+        h = C.c_void_p()
+        _lib.check(lib.roma_create(C.byref(cfg), C.byref(h)), exc=AssertionError)
+        try:
+            for prefix, sd in (("", self._weights), ("dinov2.", self._dinov2_weights)):
+                for k, v in sd.items():
+                    t = v.detach().cpu().contiguous()
+                    is_i64 = t.dtype == torch.int64
+                    if not is_i64:
+                        t = t.float().contiguous()
+                    shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+                    _lib.check(lib.roma_set_tensor(h, (prefix + k).encode(), t.dim(), shape, C.c_void_p(t.data_ptr()), int(is_i64)))
+            # strict key/shape contract, as matcher.load_state_dict(weights) (roma_models.py:204)
+            _lib.check(lib.roma_finalize(h), exc=RuntimeError)
+        except Exception:
+            lib.roma_destroy(h)
+            raise
+        self._handle = h
+        self._built = key
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            _lib.load().roma_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ nn.Module-ish surface used by callers
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, device):
+        if torch.device(device).type != "cuda":
+            raise _lib.RomaHipError("roma_amd runs only on a HIP device; there is no CPU fallback")
+        return self
+
+    def _get_device(self):
+        return self.device
+
+    def get_output_resolution(self):
+        if not self.upsample_preds:
+            return self.h_resized, self.w_resized
+        return self.upsample_res
+
+    # ------------------------------------------------------------------ match()
+    @torch.inference_mode()
+    def match(self, im_A_input, im_B_input, *args, im_A_high_res=None, im_B_high_res=None, batched=True, device=None):
+        """romatch/models/matcher.py:779-934.  Returns (warp [B,H,2W,4] | [B,H,W,4], certainty [B,H,2W] | [B,H,W])."""
+        from PIL import Image
+        self.train(False)
+        if not batched:
+            raise ValueError("batched must be True, non-batched inference is no longer supported.")
+        if device is None:
+            device = im_A_input.device if isinstance(im_A_input, torch.Tensor) else self.device
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.RomaHipError(f"roma_amd.match needs CUDA/HIP tensors (got {device}); there is no CPU fallback")
+        im_A = _check_input(im_A_input)
+        im_B = _check_input(im_B_input)
+        hs, ws = self.h_resized, self.w_resized
+        if isinstance(im_A, Image.Image) and isinstance(im_B, Image.Image):
+            a = _pil_to_normalised(im_A, (hs, ws))[None].to(device)
+            b_ = _pil_to_normalised(im_B, (hs, ws))[None].to(device)
+        elif isinstance(im_A, torch.Tensor) and isinstance(im_B, torch.Tensor):
+            b, c, h, w = im_A.shape
+            b, c, h2, w2 = im_B.shape
+            assert w == w2 and h == h2, "For batched images we assume same size"
+            a, b_ = im_A.to(device), im_B.to(device)
+            if h != self.h_resized or self.w_resized != w:
+                warn("Model resolution and batch resolution differ, may produce unexpected results")
+                self.h_resized, self.w_resized = h, w  # the HIP handle is resolution-specific: rebuild it
+        else:
+            raise ValueError(f"Unsupported input type: {type(im_A)=} and {type(im_B)=}")
+        a_hr = b_hr = None
+        if self.upsample_preds and im_A_high_res is None and im_B_high_res is None:
+            assert isinstance(im_A, Image.Image), f"Unsupported input type: {type(im_A_input)=}"
+            assert isinstance(im_B, Image.Image), f"Unsupported input type: {type(im_B_input)=}"
+            a_hr = _pil_to_normalised(im_A, self.upsample_res)[None].to(device)
+            b_hr = _pil_to_normalised(im_B, self.upsample_res)[None].to(device)
+        elif self.upsample_preds and im_A_high_res is not None and im_B_high_res is not None:
+            a_hr, b_hr = im_A_high_res.to(device), im_B_high_res.to(device)
+            if tuple(a_hr.shape[-2:]) != tuple(self.upsample_res):
+                self.upsample_res = tuple(a_hr.shape[-2:])
+        elif self.upsample_preds:
+            raise ValueError(f"Invalid upsample_preds and high_res inputs with {im_A_high_res=} and {im_B_high_res=}")
+        self._ensure_handle()
+        lib = _lib.load()
+        for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug"):
+            _lib.check(lib.roma_set_option(self._handle, k.encode(), int(bool(getattr(self, k)))))
+        B = a.shape[0]
+        Ho, Wo = self.get_output_resolution() if self.upsample_preds else (a.shape[-2], a.shape[-1])
+        Wout = 2 * Wo if self.symmetric else Wo
+        warp = torch.empty((B, Ho, Wout, 4), device=device, dtype=torch.float32)
+        cert = torch.empty((B, Ho, Wout), device=device, dtype=torch.float32)
+        a, b_ = a.float().contiguous(), b_.float().contiguous()
+        if a_hr is not None:
+            a_hr, b_hr = a_hr.float().contiguous(), b_hr.float().contiguous()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            for i0 in range(0, B, self.max_batch):
+                n = min(self.max_batch, B - i0)
+                ptr = lambda t: C.c_void_p(t[i0:i0 + n].data_ptr()) if t is not None else None  # noqa: E731
+                _lib.check(lib.roma_match(self._handle, n, ptr(a), ptr(b_), ptr(a_hr), ptr(b_hr),
+                                          ptr(warp), ptr(cert), C.c_void_p(stream)))
+        return warp, cert
+
+    def debug_fetch(self, name: str, dtype=np.float32) -> np.ndarray:
+        """Intermediate tensor captured by the last match() when `self.debug` is set (tests only)."""
+        lib = _lib.load()
+        n = lib.roma_debug_fetch(self._handle, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(_lib.last_error())
+        buf = np.empty(n // np.dtype(dtype).itemsize, dtype=dtype)
+        got = lib.roma_debug_fetch(self._handle, name.encode(), C.c_void_p(buf.ctypes.data), n)
+        if got < 0:
+            raise _lib.RomaHipError(_lib.last_error())
+        return buf
+
+    # ------------------------------------------------------------------ light post-processing helpers (torch)
+    def to_pixel_coordinates(self, coords, H_A, W_A, H_B=None, W_B=None):
+        """matcher.py:701-717."""
+        if coords.shape[-1] == 2:
+            return self._to_pixel_coordinates(coords, H_A, W_A)
+        if isinstance(coords, (list, tuple)):
+            kpts_A, kpts_B = coords[0], coords[1]
+        else:
+            kpts_A, kpts_B = coords[..., :2], coords[..., 2:]
+        return self._to_pixel_coordinates(kpts_A, H_A, W_A), self._to_pixel_coordinates(kpts_B, H_B, W_B)
+
+    @staticmethod
+    def _to_pixel_coordinates(coords, H, W):
+        return torch.stack((W / 2 * (coords[..., 0] + 1), H / 2 * (coords[..., 1] + 1)), dim=-1)
+
+    def to_normalized_coordinates(self, coords, H_A, W_A, H_B, W_B):
+        """matcher.py:719-730."""
+        if isinstance(coords, (list, tuple)):
+            kpts_A, kpts_B = coords[0], coords[1]
+        else:
+            kpts_A, kpts_B = coords[..., :2], coords[..., 2:]
+        kpts_A = torch.stack((2 / W_A * kpts_A[..., 0] - 1, 2 / H_A * kpts_A[..., 1] - 1), dim=-1)
+        kpts_B = torch.stack((2 / W_B * kpts_B[..., 0] - 1, 2 / H_B * kpts_B[..., 1] - 1), dim=-1)
+        return kpts_A, kpts_B
+
+
+def roma_model(resolution, upsample_preds, device=None, weights=None, dinov2_weights=None,
+               amp_dtype: torch.dtype = torch.float16, use_custom_corr=True, symmetric=True, upsample_res=None,
+               sample_thresh=0.05, sample_mode="threshold_balanced", attenuate_cert=True, max_batch=8, **kwargs):
+    """romatch/models/model_zoo/roma_models.py:32-205.  `use_custom_corr` is accepted for API
+    compatibility; the fused HIP local-correlation kernel is always used."""
+    resolution = _to_hw(resolution)
+    upsample_res = _to_hw(upsample_res)
+    assert resolution[0] % 14 == 0, "Needs to be multiple of 14 for backbone"
+    assert resolution[1] % 14 == 0, "Needs to be multiple of 14 for backbone"
+    if weights is None or dinov2_weights is None:
+        raise ValueError("weights and dinov2_weights state-dicts are required (no network access for torch.hub downloads)")
+    h, w = resolution
+    return RegressionMatcher(weights, dinov2_weights, h=h, w=w, upsample_preds=upsample_preds, upsample_res=upsample_res,
+                             symmetric=symmetric, attenuate_cert=attenuate_cert, sample_mode=sample_mode,
+                             sample_thresh=sample_thresh, device=device, amp_dtype=amp_dtype, max_batch=max_batch, **kwargs)
+
+
+def roma_outdoor(device, weights=None, dinov2_weights=None, coarse_res: Union[int, tuple] = 560,
+                 upsample_res: Union[int, tuple] = 864, amp_dtype: torch.dtype = torch.float16, symmetric=True,
+                 use_custom_corr=True, upsample_preds=True, max_batch=8):
+    """romatch/models/model_zoo/__init__.py:31-61."""
+    return roma_model(resolution=coarse_res, upsample_preds=upsample_preds, weights=weights,
+                      dinov2_weights=dinov2_weights, device=device, amp_dtype=amp_dtype, symmetric=symmetric,
+                      use_custom_corr=use_custom_corr, upsample_res=upsample_res, max_batch=max_batch)
+
+
+def roma_indoor(device, weights=None, dinov2_weights=None, coarse_res: Union[int, tuple] = 560,
+                upsample_res: Union[int, tuple] = 864, amp_dtype: torch.dtype = torch.float16, symmetric=True,
+                use_custom_corr=True, upsample_preds=True, max_batch=8):
+    """romatch/models/model_zoo/__init__.py:64-93 (same graph as roma_outdoor, different weights)."""
+    return roma_model(resolution=coarse_res, upsample_preds=upsample_preds, weights=weights,
+                      dinov2_weights=dinov2_weights, device=device, amp_dtype=amp_dtype, symmetric=symmetric,
+                      use_custom_corr=use_custom_corr, upsample_res=upsample_res, max_batch=max_batch)

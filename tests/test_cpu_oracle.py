@@ -1,0 +1,150 @@
+"""CPU-only suite (`-m "not gpu"`): the oracle against the reference-generated goldens, the synthetic
+state-dict contract, the C-ABI library surface (dlopen + symbols, no compute), and the multi-process
+sharding/gather logic over gloo (world_size 2)."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+
+def test_synthetic_state_dicts_match_reference_contract(weights0):
+    """Keys / shapes of the synthetic dicts == the reference's strict load_state_dict contract."""
+    contract = json.load(open(os.path.join(GOLDEN, "state_dict_contract.json")))
+    sd, dsd = weights0
+    assert {k: list(v.shape) for k, v in sd.items()} == contract["matcher"]
+    assert {k: list(v.shape) for k, v in dsd.items()} == contract["dinov2"]
+    assert len(sd) == 603 and len(dsd) == 343
+
+
+def test_oracle_ops_vs_reference_golden():
+    from oracle import roma_oracle as O
+    g = np.load(os.path.join(GOLDEN, "ops_reference.npz"))
+    for name, r in (("lc_r7", 7), ("lc_r3", 3), ("lc_r2", 2)):
+        f0, f1, warp, ref = [torch.from_numpy(g[f"{name}_{k}"]) for k in ("f0", "f1", "warp", "corr")]
+        out = O.local_correlation(f0, f1, r, warp)
+        assert torch.allclose(out, ref, atol=1e-6), name
+    flow = O.cls_to_flow_refine(torch.from_numpy(g["c2f_cls"]))
+    assert torch.allclose(flow, torch.from_numpy(g["c2f_flow"]), atol=1e-6)
+
+
+def test_oracle_match_vs_reference_golden_tiny(weights0):
+    """Full match() of the oracle == the unmodified reference's output (112 -> 168, symmetric)."""
+    from oracle import roma_oracle as O
+    from roma_amd import synthetic
+    g = np.load(os.path.join(GOLDEN, "match_tiny.npz"))
+    sd, dsd = weights0
+    inp = synthetic.make_inputs(1, 112, 168, seed=1)
+    st = {}
+    warp, cert = O.match(inp["im_A"], inp["im_B"], sd, dsd, inp["im_A_high_res"], inp["im_B_high_res"], stages=st)
+    assert np.abs(warp.numpy() - g["warp"]).max() < 1e-5
+    assert np.abs(cert.numpy() - g["certainty"]).max() < 1e-5
+    assert np.abs(st["gp16"].numpy() - g["gp16"]).max() < 1e-5
+    assert np.array_equal(st["cls16"].argmax(1).numpy(), g["cls16_argmax"])
+
+
+def test_oracle_integer_patch_identity():
+    """The identity the HIP kernel relies on (all window taps share one fractional offset) reproduces the
+    reference's per-tap bilinear evaluation."""
+    from oracle import roma_oracle as O
+    g = np.load(os.path.join(GOLDEN, "ops_reference.npz"))
+    f0, f1, warp, ref = [torch.from_numpy(g[f"lc_r3_{k}"]) for k in ("f0", "f1", "warp", "corr")]
+    B, c, h, w = f0.shape
+    r = 3
+    out = torch.zeros_like(ref)
+    f1p = torch.nn.functional.pad(f1, (r + 2, r + 2, r + 2, r + 2))
+    for b in range(B):
+        for y in range(h):
+            for x in range(w):
+                ix = ((warp[b, 0, y, x] + 1) * w - 1) / 2
+                iy = ((warp[b, 1, y, x] + 1) * h - 1) / 2
+                x0, y0 = int(torch.floor(ix)), int(torch.floor(iy))
+                if not (-r - 2 <= x0 < w + 1 and -r - 2 <= y0 < h + 1):
+                    continue
+                fx, fy = float(ix - x0), float(iy - y0)
+                ys, xs = y0 - r + r + 2, x0 - r + r + 2
+                if ys < 0 or xs < 0 or ys + 2 * r + 2 > f1p.shape[2] or xs + 2 * r + 2 > f1p.shape[3]:
+                    continue
+                patch = f1p[b, :, ys:ys + 2 * r + 2, xs:xs + 2 * r + 2]
+                D = (f0[b, :, y, x, None, None] * patch).sum(0) / c ** 0.5
+                cc = ((1 - fy) * (1 - fx) * D[:-1, :-1] + (1 - fy) * fx * D[:-1, 1:] + fy * (1 - fx) * D[1:, :-1] + fy * fx * D[1:, 1:])
+                out[b, :, y, x] = cc.reshape(-1)
+    mask = out.abs().sum(1) > 0
+    assert (out - ref).abs()[mask[:, None].expand_as(ref)].max() < 1e-4
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    """include/roma_hip.h <-> libroma_hip.so <-> ctypes table: same symbol set; no compute without a GPU."""
+    from roma_amd import _lib
+    header = open(os.path.join(ROOT, "include", "roma_hip.h")).read()
+    declared = set(re.findall(r"\b(roma_[a-z0-9_]+)\s*\(", header)) - {"roma_model"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(built_lib, name), name
+    assert b"gfx950" in built_lib.roma_version()
+
+
+def test_c_abi_argument_validation_without_gpu(built_lib):
+    from roma_amd import _lib
+    h = C.c_void_p()
+    cfg = _lib.RomaConfig(100, 112, 0, 0, 1, 0, 1, 0, 1, 0)  # 100 is not a multiple of 14
+    rc = built_lib.roma_create(C.byref(cfg), C.byref(h))
+    assert rc != 0 and b"multiple of 14" in built_lib.roma_last_error()
+    if not torch.cuda.is_available():
+        cfg = _lib.RomaConfig(112, 112, 0, 0, 1, 0, 1, 0, 1, 0)
+        rc = built_lib.roma_create(C.byref(cfg), C.byref(h))
+        assert rc != 0, "the HIP path must fail loudly without a GPU (no CPU fallback)"
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "roma_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+[\w.]*oracle", src, re.M), f  # never imported by the product
+
+
+def test_pair_sharding_is_a_partition():
+    from roma_amd.distributed import shard_pairs
+    for n in (1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_pairs(n, r, world) for r in range(world)]
+            assert sum(c for _, c in spans) == n
+            pos = 0
+            for s, c in spans:
+                assert s == pos
+                pos += c
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_gloo_world2_gather(tmp_path):
+    """N>1 path on CPU: two processes shard 5 pairs, run a stand-in match and gather (gloo)."""
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from roma_amd.distributed import shard_pairs, gather_results\n"
+        "dist.init_process_group('gloo')\n"
+        "r, w = dist.get_rank(), dist.get_world_size()\n"
+        "n = 5\n"
+        "s, c = shard_pairs(n, r, w)\n"
+        "idx = torch.arange(s, s + c, dtype=torch.float32)\n"
+        "warp = idx[:, None, None, None].expand(c, 4, 6, 4).contiguous()\n"
+        "cert = idx[:, None, None].expand(c, 4, 6).contiguous() * 2\n"
+        "W, Cc = gather_results(warp, cert, n)\n"
+        "if r == 0:\n"
+        "    assert W.shape == (5, 4, 6, 4) and Cc.shape == (5, 4, 6)\n"
+        "    assert torch.equal(W[:, 0, 0, 0], torch.arange(5.)) and torch.equal(Cc[:, 0, 0], 2 * torch.arange(5.))\n"
+        "    print('GATHER_OK')\n"
+        "dist.destroy_process_group()\n")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         capture_output=True, text=True, timeout=300)
+    assert "GATHER_OK" in out.stdout, out.stdout + out.stderr

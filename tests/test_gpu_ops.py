@@ -1,0 +1,263 @@
+"""Operator parity on a real MI355X: every HIP kernel, called through the C ABI (ctypes), against a
+plain torch-CPU fp32/fp64 evaluation of the same operator and - where the reference defines the
+operator - against goldens produced by the reference itself (tests/golden/ops_reference.npz)."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16 = 0, 1
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def rnd(*shape, seed=0, std=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(g.standard_normal(size=shape, dtype=np.float32) * np.float32(std))
+
+
+@pytest.fixture(scope="module")
+def lib(built_lib):
+    assert torch.cuda.is_available()
+    return built_lib
+
+
+def ok(lib, rc):
+    assert rc == 0, lib.roma_last_error().decode()
+
+
+def gemm(lib, A, W, bias=None, scale=None, res=None, act=0, alpha=1.0, dt_in=F32, dt_out=F32, out=None, batch=1,
+         M=None, N=None, K=None, lda=None, ldw=None, ldc=None, sA=0, sW=0, sC=0, ldr=0):
+    M = M or A.shape[-2]
+    K = K or A.shape[-1]
+    N = N or W.shape[-2]
+    if out is None:
+        out = torch.empty((batch, M, N) if batch > 1 else (M, N), device="cuda",
+                          dtype=torch.float32 if dt_out == F32 else torch.bfloat16)
+    ok(lib, lib.roma_op_gemm(P(A), lda or A.stride(-2), P(W), ldw or W.stride(-2), P(out), ldc or out.stride(-2), M, N, K, batch,
+                             sA, sW, sC, P(bias), P(scale), P(res), ldr, act, alpha, dt_in, dt_out, None))
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 72), (128, 128, 32), (1000, 24, 24), (513, 64, 136), (77, 4097, 1024), (260, 1384, 1384)])
+def test_gemm_f32_epilogues(lib, M, N, K):
+    A, W, b, s, r = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(N, seed=4), rnd(M, N, seed=5)
+    ref = (A.double() @ W.double().T + b.double())
+    out = gemm(lib, A.cuda(), W.cuda(), bias=b.cuda())
+    assert torch.allclose(out.cpu().double(), ref, atol=2e-4 * math.sqrt(K), rtol=1e-5)
+    ref2 = F.gelu(ref) * s.double() + r.double()
+    out2 = gemm(lib, A.cuda(), W.cuda(), bias=b.cuda(), scale=s.cuda(), res=r.cuda(), act=2, ldr=N)
+    assert torch.allclose(out2.cpu().double(), ref2, atol=2e-4 * math.sqrt(K), rtol=1e-5)
+    out3 = gemm(lib, A.cuda(), W.cuda(), bias=b.cuda(), act=1)
+    assert torch.allclose(out3.cpu().double(), F.relu(ref), atol=2e-4 * math.sqrt(K), rtol=1e-5)
+
+
+def test_gemm_f32_is_exact_fma_chain(lib):
+    # f32 MFMA == k-ordered fmaf chain (no reduced-precision path): integer-valued data must be exact
+    A = torch.randint(-8, 9, (256, 96)).float()
+    W = torch.randint(-8, 9, (192, 96)).float()
+    out = gemm(lib, A.cuda(), W.cuda())
+    assert torch.equal(out.cpu(), A @ W.T)
+
+
+def test_gemm_batched_strided_accumulate(lib):
+    b, M, N, K = 3, 130, 192, 64
+    A, W, Cm = rnd(b, M, K, seed=1), rnd(b, N, K, seed=2), rnd(b, M, N, seed=3)
+    out = Cm.clone().cuda()
+    gemm(lib, A.cuda(), W.cuda(), res=out, alpha=-1.0, out=out, batch=b, M=M, N=N, K=K, sA=M * K, sW=N * K, sC=M * N, ldr=N)
+    ref = Cm.double() - A.double() @ W.double().transpose(1, 2)
+    assert torch.allclose(out.cpu().double(), ref, atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 72), (1000, 24, 24), (512, 1024, 4096)])
+def test_gemm_bf16(lib, M, N, K):
+    A, W, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2).bfloat16(), rnd(N, seed=3)
+    ref = A.double() @ W.double().T + b.double()
+    out = gemm(lib, A.cuda(), W.cuda(), bias=b.cuda(), dt_in=BF16, dt_out=F32)
+    assert torch.allclose(out.cpu().double(), ref, atol=1e-3 * math.sqrt(K), rtol=1e-4)  # exact products, f32 accumulate
+    outb = gemm(lib, A.cuda(), W.cuda(), bias=b.cuda(), dt_in=BF16, dt_out=BF16)
+    assert torch.allclose(outb.cpu().double(), ref, atol=0.02 * math.sqrt(K), rtol=1e-2)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 11, 64, 128), (1, 16, 16, 128, 64)])
+def test_conv3x3_implicit_gemm(lib, dt, B, H, W, Cin, Cout):
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, std=0.05), rnd(Cout, seed=3)
+    tdt = torch.float32 if dt == F32 else torch.bfloat16
+    xq, wq = x.to(tdt), w.to(tdt)
+    ref = F.relu(F.conv2d(xq.double(), wq.double(), b.double(), padding=1)).permute(0, 2, 3, 1)
+    xin = xq.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = wq.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().cuda()  # [cout][(ky,kx),ci]
+    out = torch.empty((B, H, W, Cout), device="cuda", dtype=tdt)
+    ok(lib, lib.roma_op_conv3x3(P(xin), P(wp), P(b.cuda()), P(out), B, H, W, Cin, Cout, 1, dt, None))
+    torch.cuda.synchronize()
+    tol = 2e-4 if dt == F32 else 3e-2
+    assert torch.allclose(out.cpu().double(), ref, atol=tol, rtol=tol)
+
+
+def _attention_case(lib, B, heads, hd, N, dt):
+    D = heads * hd
+    tdt = torch.float32 if dt == F32 else torch.bfloat16
+    x, w, b = rnd(B * N, D, seed=1).to(tdt), rnd(3 * D, D, seed=2, std=1.5 / math.sqrt(D)).to(tdt), rnd(3 * D, seed=3, std=0.1)
+    npad = (N + 127) // 128 * 128
+    q = torch.zeros((B, heads, npad, hd), device="cuda", dtype=tdt)
+    k = torch.zeros_like(q)
+    vt = torch.zeros((B, heads, hd, npad), device="cuda", dtype=tdt)
+    ok(lib, lib.roma_op_qkv_scatter_gemm(P(x.cuda()), P(w.cuda()), P(b.cuda()), P(q), P(k), P(vt), B, N, npad, heads, hd, D, dt, dt, None))
+    out = torch.empty((B * N, D), device="cuda", dtype=tdt)
+    ok(lib, lib.roma_op_attention(P(q), P(k), P(vt), P(out), B, heads, N, npad, hd, dt, dt, None))
+    torch.cuda.synchronize()
+    qkv = (x.double() @ w.double().T + b.double()).reshape(B, N, 3, heads, hd)
+    qq, kk, vv = [t.transpose(1, 2) for t in torch.unbind(qkv, 2)]
+    ref = F.scaled_dot_product_attention(qq, kk, vv).transpose(1, 2).reshape(B * N, D)
+    # scatter layout check
+    assert torch.allclose(k.cpu().double()[:, :, :N], kk, atol=1e-4 if dt == F32 else 3e-2)
+    assert torch.allclose(vt.cpu().double()[:, :, :, :N], vv.transpose(2, 3), atol=1e-4 if dt == F32 else 3e-2)
+    tol = 2e-5 if dt == F32 else 3e-2
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("B,heads,hd,N", [(2, 16, 64, 65), (1, 16, 64, 257), (2, 8, 128, 64), (1, 8, 128, 200)])
+def test_attention_f32(lib, B, heads, hd, N):
+    _attention_case(lib, B, heads, hd, N, F32)
+
+
+@pytest.mark.parametrize("B,heads,hd,N", [(2, 16, 64, 65), (1, 16, 64, 257), (2, 8, 128, 64), (1, 8, 128, 200)])
+def test_attention_bf16(lib, B, heads, hd, N):
+    _attention_case(lib, B, heads, hd, N, BF16)
+
+
+def test_layernorm(lib):
+    x, w, b = rnd(37, 1024, seed=1, std=3.0) + 0.5, rnd(1024, seed=2), rnd(1024, seed=3)
+    out = torch.empty((37, 1024), device="cuda")
+    ok(lib, lib.roma_op_layernorm(P(x.cuda()), P(w.cuda()), P(b.cuda()), P(out), 37, 1024, 1e-6, F32, None))
+    torch.cuda.synchronize()
+    ref = F.layer_norm(x.double(), (1024,), w.double(), b.double(), 1e-6)
+    assert torch.allclose(out.cpu().double(), ref, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("n,d,batch", [(64, 512, 2), (256, 512, 3), (1600, 512, 1)])
+def test_cholesky_solve(lib, n, d, batch):
+    # SPD matrices shaped like the GP system: exp((cos-1)/0.2) Gram + 0.1 I   (matcher.py:191-200, 301)
+    y = rnd(batch, n, 32, seed=1)
+    yn = y / y.norm(dim=-1, keepdim=True)
+    A = torch.exp((yn @ yn.transpose(1, 2) - 1.0) / 0.2) + 0.1 * torch.eye(n)
+    Fm = rnd(batch, n, d, seed=2)
+    ref = torch.cholesky_solve(Fm.double(), torch.linalg.cholesky(A.double()))
+    Ad = A.clone().cuda()
+    Ft = Fm.transpose(1, 2).contiguous().cuda()
+    LT = torch.empty_like(Ad)
+    Linv = torch.empty((batch, n // 64, 64, 64), device="cuda")
+    LinvT = torch.empty_like(Linv)
+    ok(lib, lib.roma_op_cholesky_solve_t(P(Ad), P(Ft), P(LT), P(Linv), P(LinvT), n, d, batch, None))
+    torch.cuda.synchronize()
+    X = Ft.cpu().transpose(1, 2).double()
+    assert torch.allclose(X, ref, atol=2e-4, rtol=1e-4), (X - ref).abs().max()
+    Lref = torch.linalg.cholesky(A.double())
+    assert torch.allclose(torch.tril(Ad.cpu().double()), Lref, atol=1e-4)
+
+
+def test_cls_to_flow_reference_golden(lib):
+    g = np.load(os.path.join(GOLDEN, "ops_reference.npz"))
+    cls = torch.from_numpy(g["c2f_cls"])  # [B,4096,H,W]
+    B, Cn, H, W = cls.shape
+    logits = torch.zeros((B * H * W, 4104))
+    logits[:, :4096] = cls.permute(0, 2, 3, 1).reshape(-1, 4096)
+    logits[:, 4096] = 7.0
+    flow = torch.empty((B * H * W, 2), device="cuda")
+    cert = torch.empty((B * H * W,), device="cuda")
+    ok(lib, lib.roma_op_cls_to_flow(P(logits.cuda()), 4104, P(flow), P(cert), B * H * W, None))
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(g["c2f_flow"]).reshape(-1, 2)
+    assert torch.allclose(flow.cpu(), ref, atol=1e-5)
+    assert torch.all(cert.cpu() == 7.0)
+
+
+@pytest.mark.parametrize("name,r", [("lc_r7", 7), ("lc_r3", 3), ("lc_r2", 2)])
+def test_local_corr_reference_golden(lib, name, r):
+    """HIP fused kernel vs the reference's own local_correlation (torch fallback) outputs."""
+    from roma_amd.local_correlation import local_corr, local_correlation
+    g = np.load(os.path.join(GOLDEN, "ops_reference.npz"))
+    f0, f1, warp, ref = [torch.from_numpy(g[f"{name}_{k}"]) for k in ("f0", "f1", "warp", "corr")]
+    out = local_correlation(f0.cuda(), f1.cuda(), r, warp.cuda(), use_custom_corr=True)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    assert torch.allclose(out.cpu(), ref, atol=5e-5, rtol=1e-5), (out.cpu() - ref).abs().max()
+    # plugin-signature form (arbitrary per-tap coordinates), as local_corr_wrapper builds them (local_correlation.py:24-32)
+    B, c, h, w = f0.shape
+    K = (2 * r + 1) ** 2
+    lw = torch.meshgrid(torch.linspace(-2 * r / h, 2 * r / h, 2 * r + 1), torch.linspace(-2 * r / w, 2 * r / w, 2 * r + 1), indexing="ij")
+    lw = torch.stack((lw[1], lw[0]), dim=-1).reshape(1, K, 2)
+    coords = (warp.permute(0, 2, 3, 1)[..., None, :] + lw[:, None, None]).reshape(B, h * w, K, 2)
+    out2 = local_corr(f0.reshape(B, c, h * w).permute(0, 2, 1).contiguous().cuda() / (c ** 0.5),
+                      f1.permute(0, 2, 3, 1).contiguous().cuda(), coords.cuda())
+    torch.cuda.synchronize()
+    out2 = out2.permute(0, 2, 1).reshape(B, K, h, w)
+    assert torch.allclose(out2.cpu(), ref, atol=5e-5, rtol=1e-5), (out2.cpu() - ref).abs().max()
+
+
+def test_local_corr_real_shape_vs_oracle(lib):
+    """stride-8 shape of the real model (C=512, r=3) with a smooth + noisy warp, bf16 and f32."""
+    from oracle import roma_oracle
+    from roma_amd.local_correlation import local_correlation
+    B, c, h, w, r = 1, 512, 35, 35, 3
+    f0, f1 = rnd(B, c, h, w, seed=1), rnd(B, c, h, w, seed=2)
+    warp = roma_oracle.pixel_grid(B, h, w) * 0.9 + rnd(B, 2, h, w, seed=3, std=0.02)
+    ref = roma_oracle.local_correlation(f0, f1, r, warp)
+    out = local_correlation(f0.cuda(), f1.cuda(), r, warp.cuda())
+    assert torch.allclose(out.cpu(), ref, atol=1e-4, rtol=1e-5), (out.cpu() - ref).abs().max()
+    outb = local_correlation(f0.cuda().bfloat16(), f1.cuda().bfloat16(), r, warp.cuda())
+    refb = roma_oracle.local_correlation(f0.bfloat16().float(), f1.bfloat16().float(), r, warp)
+    assert torch.allclose(outb.cpu(), refb, atol=1e-3, rtol=1e-4), (outb.cpu() - refb).abs().max()
+
+
+@pytest.mark.parametrize("hin,hout,nc", [(40, 70, 2), (70, 140, 1), (560, 108, 2), (8, 14, 1)])
+def test_resize_bilinear(lib, hin, hout, nc):
+    x = rnd(2, nc, hin, hin, seed=1)
+    ref = F.interpolate(x, size=(hout, hout), mode="bilinear", align_corners=False)
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    out = torch.empty((2, hout, hout, nc), device="cuda")
+    ok(lib, lib.roma_op_resize_bilinear(P(xin), P(out), 2, hin, hin, hout, hout, nc, None))
+    torch.cuda.synchronize()
+    assert torch.allclose(out.cpu().permute(0, 3, 1, 2), ref, atol=2e-5), (out.cpu().permute(0, 3, 1, 2) - ref).abs().max()
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_dwconv5x5(lib, dt):
+    B, H, W, Cp = 2, 13, 10, 24
+    tdt = torch.float32 if dt == F32 else torch.bfloat16
+    x, w, b = rnd(B, Cp, H, W, seed=1).to(tdt), rnd(Cp, 1, 5, 5, seed=2, std=0.2), rnd(Cp, seed=3)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=2, groups=Cp)).permute(0, 2, 3, 1)
+    out = torch.empty((B, H, W, Cp), device="cuda", dtype=tdt)
+    wp = w.reshape(Cp, 25).T.contiguous().cuda()
+    ok(lib, lib.roma_op_dwconv5x5(P(x.permute(0, 2, 3, 1).contiguous().cuda()), P(out), P(wp), P(b.cuda()), B, H, W, Cp, dt, None))
+    torch.cuda.synchronize()
+    tol = 1e-5 if dt == F32 else 2e-2
+    assert torch.allclose(out.cpu().double(), ref, atol=tol, rtol=tol)
+
+
+def test_maxpool_and_first_conv(lib):
+    B, H, W = 2, 16, 24
+    img, w, b = rnd(B, 3, H, W, seed=1), rnd(64, 3, 3, 3, seed=2, std=0.3), rnd(64, seed=3)
+    ref = F.relu(F.conv2d(img.double(), w.double(), b.double(), padding=1)).permute(0, 2, 3, 1)
+    wp = w.permute(1, 2, 3, 0).reshape(27, 64).contiguous().cuda()
+    out = torch.empty((B, H, W, 64), device="cuda")
+    ok(lib, lib.roma_op_conv3x3_c3(P(img.cuda()), P(wp), P(b.cuda()), P(out), B, H, W, F32, None))
+    pooled = torch.empty((B, H // 2, W // 2, 64), device="cuda")
+    ok(lib, lib.roma_op_maxpool2x2(P(out), P(pooled), B, H, W, 64, F32, None))
+    torch.cuda.synchronize()
+    assert torch.allclose(out.cpu().double(), ref, atol=1e-5, rtol=1e-5)
+    refp = F.max_pool2d(ref.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert torch.allclose(pooled.cpu().double(), refp, atol=1e-5)
