@@ -57,6 +57,10 @@ int roma_match(roma_handle_t h, int B, const float* im_a, const float* im_b, con
  * Returns the number of bytes available when dst == NULL. */
 long roma_debug_fetch(roma_handle_t h, const char* name, void* dst_host, long nbytes);
 int roma_destroy(roma_handle_t h);
+/* Per-launch HIP-event timing of the dominant kernels (bench.py roofline pass). roma_profile_report writes a JSON
+ * object {kernel: {calls,total_ms,work,unit}} (work = algorithmic FLOPs or bytes); returns bytes needed when buf==NULL. */
+int roma_profile_enable(int on);
+long roma_profile_report(char* buf, long nbytes);
 
 /* ---- operator entry points (dt: ROMA_F32 / ROMA_BF16) ------------------------------------------------ */
 

@@ -33,6 +33,8 @@ SIGNATURES = {
     "roma_match": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "roma_debug_fetch": (_l, [_vp, C.c_char_p, _vp, _l]),
     "roma_destroy": (_i, [_vp]),
+    "roma_profile_enable": (_i, [_i]),
+    "roma_profile_report": (_l, [C.c_char_p, _l]),
     "roma_op_local_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "roma_op_local_corr_window": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _i, _i, _vp]),
     "roma_op_gemm": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _l, _l, _l, _vp, _vp, _vp, _l, _i, _f, _i, _i, _vp]),

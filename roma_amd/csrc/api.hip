@@ -1,5 +1,8 @@
 // extern "C" boundary of libroma_hip (declarations + reference citations: include/roma_hip.h)
 #include <mutex>
+#include <map>
+#include <vector>
+#include <string.h>
 
 #include "../../include/roma_hip.h"
 #include "attention.h"
@@ -11,6 +14,22 @@
 namespace roma {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace roma
+
+namespace roma {
+struct ProfRec { std::string name, unit; double work; hipEvent_t e0, e1; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+bool prof_enabled() { return g_prof_on; }
+void prof_begin(const char* kernel, double work, const char* unit, hipStream_t s) {
+  ProfRec r;
+  r.name = kernel; r.unit = unit; r.work = work;
+  (void)hipEventCreate(&r.e0);
+  (void)hipEventCreate(&r.e1);
+  (void)hipEventRecord(r.e0, s);
+  g_prof.push_back(r);
+}
+void prof_end(hipStream_t s) { (void)hipEventRecord(g_prof.back().e1, s); }
 }  // namespace roma
 
 struct roma_model {
@@ -97,6 +116,39 @@ long roma_debug_fetch(roma_handle_t h, const char* name, void* dst_host, long nb
 int roma_destroy(roma_handle_t h) {
   delete h;
   return 0;
+}
+
+int roma_profile_enable(int on) {
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return 0;
+}
+
+long roma_profile_report(char* buf, long nbytes) {
+  if (hipDeviceSynchronize() != hipSuccess) return ROMA_ERR_HIP;
+  struct Agg { long calls = 0; double ms = 0, work = 0; std::string unit; };
+  std::map<std::string, Agg> agg;
+  for (auto& r : g_prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    Agg& a = agg[r.name];
+    a.calls++; a.ms += ms; a.work += r.work; a.unit = r.unit;
+  }
+  std::string js = "{";
+  bool first = true;
+  for (auto& kv : agg) {
+    char tmp[512];
+    snprintf(tmp, sizeof tmp, "%s\"%s\": {\"calls\": %ld, \"total_ms\": %.6f, \"work\": %.6e, \"unit\": \"%s\"}", first ? "" : ", ",
+             kv.first.c_str(), kv.second.calls, kv.second.ms, kv.second.work, kv.second.unit.c_str());
+    js += tmp;
+    first = false;
+  }
+  js += "}";
+  if (!buf) return (long)js.size() + 1;
+  if (nbytes < (long)js.size() + 1) return ROMA_ERR_ARG;
+  memcpy(buf, js.c_str(), js.size() + 1);
+  return (long)js.size() + 1;
 }
 
 // ------------------------------------------------------------------------------------ operators

@@ -9,6 +9,7 @@
 // order inside a k-step is a free permutation as long as V^T is read with the same one),
 // so P never leaves registers and the running max / rescale factor is one scalar per lane.
 #include "attention.h"
+#include <stdio.h>
 #include "gemm.h"  // DT_*
 
 namespace roma {
@@ -249,6 +250,9 @@ int attention_launch(const AttnArgs& a, hipStream_t stream) {
   ROMA_REQUIRE(a.npad % 128 == 0 && a.npad >= a.N, "attention: Npad must be a multiple of 128 and >= N");
   ROMA_REQUIRE(a.ldo % 4 == 0, "attention: ldo must be a multiple of 4");
   dim3 grid((unsigned)((a.N + 127) / 128), (unsigned)a.heads, (unsigned)a.B);
+  char pname[64];
+  snprintf(pname, sizeof pname, "attn_%s_kernel<%d>", a.in_dt == DT_F32 ? "f32" : "bf16", a.hd);
+  ProfScope ps(pname, 4.0 * (double)a.B * a.heads * (double)a.N * a.N * a.hd, "flop", stream);
 #define ROMA_ATTN(KERNEL, HDV, TOUT) hipLaunchKernelGGL((KERNEL<HDV, TOUT>), grid, dim3(256), 0, stream, a)
   if (a.in_dt == DT_F32) {
     if (a.hd == 64) { if (a.out_dt == DT_F32) ROMA_ATTN(attn_f32_kernel, 64, float); else ROMA_ATTN(attn_f32_kernel, 64, bf16_t); }

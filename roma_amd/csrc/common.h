@@ -73,6 +73,22 @@ template <> struct ElemIO<bf16_t> {
   }
 };
 
+// ---- optional per-launch HIP-event timing (bench.py roofline pass; off by default) ----
+// work = algorithmic FLOPs (unit "flop") or algorithmic HBM bytes (unit "byte") of this launch.
+bool prof_enabled();
+void prof_begin(const char* kernel, double work, const char* unit, hipStream_t s);
+void prof_end(hipStream_t s);
+struct ProfScope {
+  hipStream_t s;
+  bool on;
+  ProfScope(const char* kernel, double work, const char* unit, hipStream_t st) : s(st), on(prof_enabled()) {
+    if (on) prof_begin(kernel, work, unit, st);
+  }
+  ~ProfScope() {
+    if (on) prof_end(s);
+  }
+};
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 

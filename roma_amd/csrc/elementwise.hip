@@ -598,6 +598,8 @@ int dwconv5x5_launch(const void* in, void* out, const float* w, const float* bia
   ROMA_REQUIRE(Cp % 4 == 0, "dwconv5x5: padded channel count must be a multiple of 4");
   const long total = (long)B * H * ((W + 3) / 4) * (Cp / 4);
   dim3 grid((unsigned)std::min<long>((total + 255) / 256, 1 << 20));
+  ProfScope ps(dt == DT_F32 ? "dwconv5x5_kernel<f32>" : "dwconv5x5_kernel<bf16>",
+               2.0 * (double)B * H * W * Cp * (dt == DT_F32 ? 4.0 : 2.0), "byte", s);
   ROMA_DT_SWITCH(dt, T, hipLaunchKernelGGL(dwconv5x5_kernel<T>, grid, dim3(256), 0, s, (const T*)in, (T*)out, w, bias, B, H, W, Cp));
   ROMA_LAUNCH_CHECK();
   return 0;

@@ -12,6 +12,7 @@
 //   * f32 path: v_mfma_f32_32x32x2_f32; the k-order inside a slab is permuted (lane half h takes
 //     k = 8g+4h+s) which is legal because A and B use the same permutation.
 #include "gemm.h"
+#include <stdio.h>
 
 namespace roma {
 
@@ -273,6 +274,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN), (unsigned)a.batch);
   size_t lds = (size_t)(BM + BN) * LDS_ROW;
+  char pname[96];
+  snprintf(pname, sizeof pname, "gemm_kernel<%s,%s,%d,%d,%d,%d,%s>", sizeof(TIN) == 4 ? "f32" : "bf16",
+           sizeof(TOUT) == 4 ? "f32" : "bf16", WM, WN, TM, TN, CONV ? "conv3x3" : "dense");
+  ProfScope ps(pname, 2.0 * (double)a.M * a.N * a.K * a.batch * (a.lower_only ? 0.5 : 1.0), "flop", stream);
   hipLaunchKernelGGL((gemm_kernel<TIN, TOUT, WM, WN, TM, TN, CONV>), grid, dim3(256), lds, stream, a);
   ROMA_LAUNCH_CHECK();
   return 0;

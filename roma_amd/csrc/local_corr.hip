@@ -14,6 +14,7 @@
 // split the channels in interleaved 16-byte chunks, so one wave load instruction touches
 // (2r+2) fully used 64..128-byte segments.  f0 is staged once per wave in LDS as f32.
 #include "local_corr.h"
+#include <stdio.h>
 #include "gemm.h"  // DT_*
 
 namespace roma {
@@ -185,6 +186,11 @@ static int launch_window_r(const LocalCorrArgs& a, hipStream_t stream) {
   const long total = (long)a.B * a.H * a.W;
   dim3 grid((unsigned)((total + 3) / 4));
   size_t lds = (size_t)4 * a.C * sizeof(float);
+  // algorithmic bytes: f0 + f1 read once, centre warp, K outputs
+  const double es_in = a.in_dt == DT_F32 ? 4.0 : 2.0, es_out = a.out_dt == DT_F32 ? 4.0 : 2.0;
+  char pname[64];
+  snprintf(pname, sizeof pname, "local_corr_window_kernel<%d,%s>", R, a.in_dt == DT_F32 ? "f32" : "bf16");
+  ProfScope ps(pname, (double)total * (2.0 * a.C * es_in + 8.0 + (2.0 * R + 1) * (2.0 * R + 1) * es_out), "byte", stream);
 #define ROMA_LC(T, TOUT) hipLaunchKernelGGL((local_corr_window_kernel<R, T, TOUT>), grid, dim3(256), lds, stream, a)
   if (a.in_dt == DT_F32 && a.out_dt == DT_F32) ROMA_LC(float, float);
   else if (a.in_dt == DT_F32) ROMA_LC(float, bf16_t);

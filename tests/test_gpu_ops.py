@@ -17,8 +17,18 @@ pytestmark = pytest.mark.gpu
 F32, BF16 = 0, 1
 
 
+_KEEP = []
+
+
 def P(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    """device pointer; keeps the tensor alive (inline `.cuda()` temporaries must outlive the async launch)"""
+    if t is None:
+        return None
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:-64]
+    return C.c_void_p(t.data_ptr())
 
 
 def rnd(*shape, seed=0, std=1.0):
