@@ -134,7 +134,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle (CPU restatement of the reference) on the host cores, ONE pair of the same workload
         from oracle import roma_oracle
-        torch.set_num_threads(os.cpu_count())
+        torch.set_num_threads(min(os.cpu_count(), 32))  # MKL/oneDNN stop scaling (and regress) beyond ~32 threads at these sizes
         cin = synthetic.make_inputs(1, args.coarse, args.upsample, seed=1)
         t0 = time.perf_counter()
         roma_oracle.match(cin["im_A"], cin["im_B"], sd, dsd, cin["im_A_high_res"], cin["im_B_high_res"])

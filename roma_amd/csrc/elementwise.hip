@@ -547,60 +547,112 @@ int refiner_input_launch(const RefinerInputArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ depthwise 5x5 + BN(folded) + ReLU
+// One thread = one 16-byte channel vector (4 f32 / 8 bf16) x 4 consecutive x positions of one row; the 5x8 input
+// window is walked row by row so each loaded vector feeds up to 4 outputs.  Workgroups are remapped so that each
+// XCD (private L2) owns a contiguous band of image rows: the 5-row vertical reuse then hits that XCD's L2 instead of
+// being replicated in all eight.
+template <typename T> struct VecIO;
+template <> struct VecIO<float> {
+  static constexpr int CV = 4;
+  __device__ static inline void ld(const float* p, float* v) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(p);
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+  }
+  __device__ static inline void st(float* p, const float* v) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
+};
+template <> struct VecIO<bf16_t> {
+  static constexpr int CV = 8;
+  __device__ static inline void ld(const bf16_t* p, float* v) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+  }
+  __device__ static inline void st(bf16_t* p, const float* v) {
+    uint4 u;
+    u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    u.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    u.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = u;
+  }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv5x5_kernel(const T* in, T* out, const float* w, const float* bias, int B,
-                                                        int H, int W, int Cp) {
-  const int C4 = Cp / 4;
+                                                        int H, int W, int Cp, long total, int nblocks) {
+  constexpr int CV = VecIO<T>::CV;
+  // XCD-aware remap (dispatcher places block b on XCD b % 8)
+  const int per_xcd = (nblocks + 7) / 8;
+  const long lb = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const long idx = lb * 256 + threadIdx.x;
+  if (lb >= nblocks || idx >= total) return;
+  const int CG = Cp / CV;
   const int xt = (W + 3) / 4;
-  const long total = (long)B * H * xt * C4;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int c = (int)(idx % C4) * 4;
-    long r = idx / C4;
-    const int xb = (int)(r % xt) * 4;
-    r /= xt;
-    const int y = (int)(r % H);
-    const int b = (int)(r / H);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
-    f32x4 acc[4] = {bv, bv, bv, bv};
+  const int c = (int)(idx % CG) * CV;
+  long r = idx / CG;
+  const int xb = (int)(r % xt) * 4;
+  r /= xt;
+  const int y = (int)(r % H);
+  const int b = (int)(r / H);
+  float acc[4][CV];
 #pragma unroll
-    for (int ky = 0; ky < 5; ++ky) {
-      const int yy = y + ky - 2;
-      if (yy < 0 || yy >= H) continue;
-      const T* rowp = in + (((long)b * H + yy) * W) * Cp + c;
-      f32x4 v[8];
+  for (int j = 0; j < CV; ++j) {
+    const float bv = bias[c + j];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int xx = xb - 2 + j;
-        if (xx >= 0 && xx < W) v[j] = ElemIO<T>::ld4(rowp + (long)xx * Cp);
-        else v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+    for (int px = 0; px < 4; ++px) acc[px][j] = bv;
+  }
 #pragma unroll
-      for (int kx = 0; kx < 5; ++kx) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (long)(ky * 5 + kx) * Cp + c);
+  for (int ky = 0; ky < 5; ++ky) {
+    const int yy = y + ky - 2;
+    if (yy < 0 || yy >= H) continue;
+    const T* rowp = in + (((long)b * H + yy) * W) * Cp + c;
+    float v[8][CV];
 #pragma unroll
-        for (int px = 0; px < 4; ++px) acc[px] += v[px + kx] * wv;
+    for (int j = 0; j < 8; ++j) {
+      const int xx = xb - 2 + j;
+      if (xx >= 0 && xx < W) {
+        VecIO<T>::ld(rowp + (long)xx * Cp, v[j]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < CV; ++q) v[j][q] = 0.f;
       }
     }
 #pragma unroll
-    for (int px = 0; px < 4; ++px) {
-      if (xb + px < W) {
-        f32x4 o;
+    for (int kx = 0; kx < 5; ++kx) {
+      float wv[CV];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = fmaxf(acc[px][j], 0.f);
-        ElemIO<T>::st4(out + (((long)b * H + y) * W + xb + px) * Cp + c, o);
+      for (int q = 0; q < CV; q += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(w + (long)(ky * 5 + kx) * Cp + c + q);
+        wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3];
       }
+#pragma unroll
+      for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int q = 0; q < CV; ++q) acc[px][q] = fmaf(v[px + kx][q], wv[q], acc[px][q]);
+    }
+  }
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+    if (xb + px < W) {
+#pragma unroll
+      for (int q = 0; q < CV; ++q) acc[px][q] = fmaxf(acc[px][q], 0.f);
+      VecIO<T>::st(out + (((long)b * H + y) * W + xb + px) * Cp + c, acc[px]);
     }
   }
 }
 
 int dwconv5x5_launch(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp,
                      int dt, hipStream_t s) {
-  ROMA_REQUIRE(Cp % 4 == 0, "dwconv5x5: padded channel count must be a multiple of 4");
-  const long total = (long)B * H * ((W + 3) / 4) * (Cp / 4);
-  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 1 << 20));
+  const int cv = dt == DT_F32 ? 4 : 8;
+  ROMA_REQUIRE(Cp % cv == 0, "dwconv5x5: padded channel count must be a multiple of the 16-byte vector");
+  const long total = (long)B * H * ((W + 3) / 4) * (Cp / cv);
+  const int nblocks = (int)((total + 255) / 256);
+  dim3 grid((unsigned)(((nblocks + 7) / 8) * 8));
   ProfScope ps(dt == DT_F32 ? "dwconv5x5_kernel<f32>" : "dwconv5x5_kernel<bf16>",
                2.0 * (double)B * H * W * Cp * (dt == DT_F32 ? 4.0 : 2.0), "byte", s);
-  ROMA_DT_SWITCH(dt, T, hipLaunchKernelGGL(dwconv5x5_kernel<T>, grid, dim3(256), 0, s, (const T*)in, (T*)out, w, bias, B, H, W, Cp));
+  ROMA_DT_SWITCH(dt, T, hipLaunchKernelGGL(dwconv5x5_kernel<T>, grid, dim3(256), 0, s, (const T*)in, (T*)out, w, bias, B, H, W, Cp, total, nblocks));
   ROMA_LAUNCH_CHECK();
   return 0;
 }

@@ -1,29 +1,36 @@
 // MFMA GEMM for gfx950 (see gemm.h).  One 256-thread workgroup = 4 wave64s.
 //
 // Tile anatomy (CDNA4):
-//   * K is staged through LDS in slabs of 8 x 16-byte chunks per row (32 f32 / 64 bf16) with one
-//     16-byte pad chunk per row (row stride 144 B): a ds_read_b128 lane group {16 rows x one chunk}
-//     then touches 16 distinct 16-B bank slots -> conflict free, and the 128-B row writes are linear.
-//   * next slab's global loads are issued into registers before the MFMAs of the current slab
-//     (issue-early / write-late staging), one LDS buffer, two barriers per slab.
+//   * K is staged in slabs of 8 x 16-byte chunks per row (32 f32 / 64 bf16 = 128-byte LDS rows) with
+//     `global_load_lds_dwordx4` (direct HBM->LDS DMA, no VGPR round trip, no ds_write pass).  The DMA
+//     writes lane-linear (wave-uniform base + lane*16 B), so the bank-conflict fix is an XOR swizzle applied
+//     to the per-lane SOURCE address and again on the ds_read side (same involution on both):
+//         LDS slot(row, chunk) = chunk ^ ((row >> 1) & 7)
+//     a ds_read_b128 lane group then touches 16 distinct 16-B slots of the 256-B bank row: conflict free.
+//   * out-of-range rows / K tail / 3x3-conv zero padding are DMA'd from a 256-byte zero page, so every
+//     tail is exact without predicated stores into LDS.
+//   * two LDS buffers, ONE raw `s_barrier` per slab: the DMA of slab t+1 is issued after slab t's fragments
+//     are in registers and runs under slab t's MFMAs.
 //   * MFMA operand roles are SWAPPED: the weight tile feeds the A operand (rows = n) and the
 //     activation tile the B operand (cols = m).  D[n][m] then puts 4 CONSECUTIVE n of one output
 //     row m in each lane's register quad, so bias/scale/residual/output move as 16-byte vectors.
-//   * f32 path: v_mfma_f32_32x32x2_f32; the k-order inside a slab is permuted (lane half h takes
-//     k = 8g+4h+s) which is legal because A and B use the same permutation.
+//   * f32 path: v_mfma_f32_32x32x2_f32 (exact f32); the k-order inside a slab is permuted (lane half h
+//     takes k = 8g+4h+s) which is legal because A and B use the same permutation.
 #include "gemm.h"
+
 #include <stdio.h>
 
 namespace roma {
 
-constexpr int CHUNKS = 8;
-constexpr int LDS_ROW = 9 * 16;
+constexpr int ROWB = 128;  // bytes per LDS row = 8 chunks of 16 B
 
 template <typename T> struct InTraits;
 template <> struct InTraits<float> { static constexpr int CE = 4; };
 template <> struct InTraits<bf16_t> { static constexpr int CE = 8; };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
 
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
@@ -36,18 +43,22 @@ template <typename TOUT> __device__ inline void store4(TOUT* p, f32x4 v, bool ve
   }
 }
 
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 template <typename TIN, typename TOUT, int WM, int WN, int TM, int TN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
   constexpr int CE = InTraits<TIN>::CE;
-  constexpr int BKE = CHUNKS * CE;
+  constexpr int BKE = 8 * CE;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int A_PER_T = (BM * CHUNKS + 255) / 256;
-  constexpr int W_PER_T = (BN * CHUNKS + 255) / 256;
+  constexpr int NA = BM / 32, NW = BN / 32;  // DMA instructions per wave per slab (8 rows x 128 B each)
+  constexpr int BUF = (BM + BN) * ROWB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* As = smem;
-  char* Ws = smem + BM * LDS_ROW;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
   const int bz = blockIdx.z;
@@ -57,83 +68,72 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 
   const TIN* Ab = reinterpret_cast<const TIN*>(a.A) + (long)bz * a.sA;
   const TIN* Wb = reinterpret_cast<const TIN*>(a.W) + (long)bz * a.sW;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
-  // ---- per-thread staging descriptors
-  long a_off[A_PER_T];
-  bool a_ok[A_PER_T];
-  int a_y[A_PER_T], a_x[A_PER_T];
+  // ---- per-lane DMA descriptors: lane -> (row = 8q + lane/8, slot = lane%8), source chunk = slot ^ swizzle(row)
+  const int r8 = lane >> 3, slot = lane & 7;
+  const char* a_src[NA];
+  int a_chunk[NA], a_y[NA], a_x[NA];
 #pragma unroll
-  for (int i = 0; i < A_PER_T; ++i) {
-    const int c = tid + 256 * i;
-    const int row = c >> 3;
+  for (int j = 0; j < NA; ++j) {
+    const int row = 8 * (wave * NA + j) + r8;
+    const int chunk = slot ^ ((row >> 1) & 7);
     const long gm = m0 + row;
-    a_ok[i] = (row < BM) && (gm < a.M);
-    if (CONV) {
-      const long hw = (long)a.conv_h * a.conv_w;
-      const long gmc = a_ok[i] ? gm : 0;
-      const long b = gmc / hw;
-      const int rem = (int)(gmc - b * hw);
-      a_y[i] = rem / a.conv_w;
-      a_x[i] = rem - a_y[i] * a.conv_w;
-      a_off[i] = gmc * a.conv_c + (c & 7) * CE;  // pixel base (tap offset added per slab)
-    } else {
-      a_y[i] = a_x[i] = 0;
-      a_off[i] = gm * a.lda + (c & 7) * CE;
-    }
-  }
-  long w_off[W_PER_T];
-  bool w_ok[W_PER_T];
-#pragma unroll
-  for (int i = 0; i < W_PER_T; ++i) {
-    const int c = tid + 256 * i;
-    const int row = c >> 3;
-    w_ok[i] = (row < BN) && (n0 + row < a.N);
-    w_off[i] = (long)(n0 + row) * a.ldw + (c & 7) * CE;
-  }
-
-  uint4 ra[A_PER_T], rw[W_PER_T];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-  auto load_slab = [&](int kt) {
-    const int k0 = kt * BKE;
-    if (CONV) {
-      const int tap = k0 / a.conv_c;
-      const int c0 = k0 - tap * a.conv_c;
-      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-      const long toff = ((long)dy * a.conv_w + dx) * a.conv_c + c0;
-#pragma unroll
-      for (int i = 0; i < A_PER_T; ++i) {
-        const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-        const bool ok = a_ok[i] && yy >= 0 && yy < a.conv_h && xx >= 0 && xx < a.conv_w;
-        ra[i] = ok ? *reinterpret_cast<const uint4*>(Ab + a_off[i] + toff) : zero4;
+    a_chunk[j] = chunk;
+    if (gm < a.M) {
+      if (CONV) {
+        const long hw = (long)a.conv_h * a.conv_w;
+        const long b = gm / hw;
+        const int rem = (int)(gm - b * hw);
+        a_y[j] = rem / a.conv_w;
+        a_x[j] = rem - a_y[j] * a.conv_w;
+        a_src[j] = reinterpret_cast<const char*>(Ab + gm * a.conv_c + chunk * CE);
+      } else {
+        a_y[j] = a_x[j] = 0;
+        a_src[j] = reinterpret_cast<const char*>(Ab + gm * a.lda + chunk * CE);
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < A_PER_T; ++i) {
-        const int c = tid + 256 * i;
-        const bool ok = a_ok[i] && (k0 + (c & 7) * CE < a.K);
-        ra[i] = ok ? *reinterpret_cast<const uint4*>(Ab + a_off[i] + k0) : zero4;
-      }
+      a_y[j] = -100000;  // conv: every tap out of range
+      a_x[j] = 0;
+      a_src[j] = nullptr;
     }
+  }
+  const char* w_src[NW];
+  int w_chunk[NW];
 #pragma unroll
-    for (int i = 0; i < W_PER_T; ++i) {
-      const int c = tid + 256 * i;
-      const bool ok = w_ok[i] && (k0 + (c & 7) * CE < a.K);
-      rw[i] = ok ? *reinterpret_cast<const uint4*>(Wb + w_off[i] + k0) : zero4;
-    }
-  };
-  auto store_slab = [&]() {
-#pragma unroll
-    for (int i = 0; i < A_PER_T; ++i) {
-      const int c = tid + 256 * i;
-      if (c < BM * CHUNKS) *reinterpret_cast<uint4*>(As + (c >> 3) * LDS_ROW + (c & 7) * 16) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < W_PER_T; ++i) {
-      const int c = tid + 256 * i;
-      if (c < BN * CHUNKS) *reinterpret_cast<uint4*>(Ws + (c >> 3) * LDS_ROW + (c & 7) * 16) = rw[i];
-    }
-  };
+  for (int j = 0; j < NW; ++j) {
+    const int row = 8 * (wave * NW + j) + r8;
+    const int chunk = slot ^ ((row >> 1) & 7);
+    w_chunk[j] = chunk;
+    w_src[j] = (n0 + row < a.N) ? reinterpret_cast<const char*>(Wb + (long)(n0 + row) * a.ldw + chunk * CE) : nullptr;
+  }
+
+#define ROMA_ISSUE_SLAB(KT, BUFI)                                                                           \
+  {                                                                                                         \
+    const int k0_ = (KT) * BKE;                                                                             \
+    char* abuf_ = smem + (BUFI) * BUF;                                                                      \
+    char* wbuf_ = abuf_ + BM * ROWB;                                                                        \
+    if (CONV) {                                                                                             \
+      const int tap_ = k0_ / a.conv_c;                                                                      \
+      const int c0_ = k0_ - tap_ * a.conv_c;                                                                \
+      const int dy_ = tap_ / 3 - 1, dx_ = tap_ % 3 - 1;                                                     \
+      const long toff_ = (((long)dy_ * a.conv_w + dx_) * a.conv_c + c0_) * (long)sizeof(TIN);               \
+      _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                      \
+        const int yy_ = a_y[j] + dy_, xx_ = a_x[j] + dx_;                                                   \
+        const bool ok_ = yy_ >= 0 && yy_ < a.conv_h && xx_ >= 0 && xx_ < a.conv_w;                         \
+        glds16(ok_ ? a_src[j] + toff_ : zero, abuf_ + (wave * NA + j) * 1024);                              \
+      }                                                                                                     \
+    } else {                                                                                                \
+      _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                      \
+        const bool ok_ = a_src[j] != nullptr && (k0_ + a_chunk[j] * CE < a.K);                              \
+        glds16(ok_ ? a_src[j] + (long)k0_ * sizeof(TIN) : zero, abuf_ + (wave * NA + j) * 1024);            \
+      }                                                                                                     \
+    }                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                                        \
+      const bool ok_ = w_src[j] != nullptr && (k0_ + w_chunk[j] * CE < a.K);                                \
+      glds16(ok_ ? w_src[j] + (long)k0_ * sizeof(TIN) : zero, wbuf_ + (wave * NW + j) * 1024);              \
+    }                                                                                                       \
+  }
 
   f32x16 acc[TN][TM];
 #pragma unroll
@@ -143,38 +143,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // fragment read offsets: row = tile_row0 + l31 (tile_row0 % 32 == 0), slot = (2g + h) ^ ((l31 >> 1) & 7)
+  const int sw = (l31 >> 1) & 7;
+  int rd_off[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) rd_off[g] = l31 * ROWB + (((2 * g + h) ^ sw) << 4);
+
   const int nk = (a.K + BKE - 1) / BKE;
-  load_slab(0);
+  ROMA_ISSUE_SLAB(0, 0);
+  // One barrier per slab: [slab kt landed] -> barrier -> all fragments of slab kt to registers -> DMA of slab kt+1
+  // into the other buffer (every wave has finished reading it before it passed this iteration's barrier) -> MFMAs
+  // of slab kt run under that DMA.  (hipcc drains vmcnt before any ds_read that may alias an LDS-DMA target, so
+  // the DMA is issued after the fragment reads rather than before them.)
   for (int kt = 0; kt < nk; ++kt) {
-    store_slab();
-    __syncthreads();
-    if (kt + 1 < nk) load_slab(kt + 1);
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* As = smem + cur * BUF;
+    const char* Ws = As + BM * ROWB;
+    uint4 wv[4][TN], av[4][TM];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      uint4 wv[TN], av[TM];
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
-        wv[tn] = *reinterpret_cast<const uint4*>(Ws + ((wn * TN + tn) * 32 + l31) * LDS_ROW + (2 * g + h) * 16);
+        wv[g][tn] = *reinterpret_cast<const uint4*>(Ws + (wn * TN + tn) * 32 * ROWB + rd_off[g]);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
-        av[tm] = *reinterpret_cast<const uint4*>(As + ((wm * TM + tm) * 32 + l31) * LDS_ROW + (2 * g + h) * 16);
+        av[g][tm] = *reinterpret_cast<const uint4*>(As + (wm * TM + tm) * 32 * ROWB + rd_off[g]);
+    }
+    if (kt + 1 < nk) ROMA_ISSUE_SLAB(kt + 1, cur ^ 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
           if constexpr (sizeof(TIN) == 4) {
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[tn].x), __uint_as_float(av[tm].x), acc[tn][tm], 0, 0, 0);
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[tn].y), __uint_as_float(av[tm].y), acc[tn][tm], 0, 0, 0);
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[tn].z), __uint_as_float(av[tm].z), acc[tn][tm], 0, 0, 0);
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[tn].w), __uint_as_float(av[tm].w), acc[tn][tm], 0, 0, 0);
+            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[g][tn].x), __uint_as_float(av[g][tm].x), acc[tn][tm], 0, 0, 0);
+            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[g][tn].y), __uint_as_float(av[g][tm].y), acc[tn][tm], 0, 0, 0);
+            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[g][tn].z), __uint_as_float(av[g][tm].z), acc[tn][tm], 0, 0, 0);
+            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[g][tn].w), __uint_as_float(av[g][tm].w), acc[tn][tm], 0, 0, 0);
           } else {
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wv[tn]),
-                                                                  __builtin_bit_cast(bf16x8_t, av[tm]), acc[tn][tm], 0, 0, 0);
+            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wv[g][tn]),
+                                                                  __builtin_bit_cast(bf16x8_t, av[g][tm]), acc[tn][tm], 0, 0, 0);
           }
         }
     }
-    __syncthreads();
   }
+#undef ROMA_ISSUE_SLAB
 
   // ---------------------------------------------------------------- epilogue
   TOUT* Cb = reinterpret_cast<TOUT*>(a.C) + (long)bz * a.sC;
@@ -217,9 +233,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
           continue;
         }
         if (a.bias) {
+          if (nvalid >= 4) {
+            v += *reinterpret_cast<const f32x4*>(a.bias + n);
+          } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < nvalid) v[j] += a.bias[n + j];
+            for (int j = 0; j < 4; ++j)
+              if (j < nvalid) v[j] += a.bias[n + j];
+          }
         }
         if (a.mode == EPI_QKV) {
           const int D = a.heads * a.hd;
@@ -249,14 +269,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
           for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
         }
         if (a.scale) {
+          if (nvalid >= 4) {
+            v *= *reinterpret_cast<const f32x4*>(a.scale + n);
+          } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < nvalid) v[j] *= a.scale[n + j];
+            for (int j = 0; j < 4; ++j)
+              if (j < nvalid) v[j] *= a.scale[n + j];
+          }
         }
         if (Rb) {
           if (vecR && nvalid >= 4) {
-            f32x4 r = *reinterpret_cast<const f32x4*>(Rb + m * a.ldr + n);
-            v += r;
+            v += *reinterpret_cast<const f32x4*>(Rb + m * a.ldr + n);
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -273,11 +296,17 @@ template <typename TIN, typename TOUT, int WM, int WN, int TM, int TN, bool CONV
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN), (unsigned)a.batch);
-  size_t lds = (size_t)(BM + BN) * LDS_ROW;
+  size_t lds = (size_t)2 * (BM + BN) * ROWB;
   char pname[96];
   snprintf(pname, sizeof pname, "gemm_kernel<%s,%s,%d,%d,%d,%d,%s>", sizeof(TIN) == 4 ? "f32" : "bf16",
            sizeof(TOUT) == 4 ? "f32" : "bf16", WM, WN, TM, TN, CONV ? "conv3x3" : "dense");
   ProfScope ps(pname, 2.0 * (double)a.M * a.N * a.K * a.batch * (a.lower_only ? 0.5 : 1.0), "flop", stream);
+  static bool attr_set = false;
+  if (!attr_set) {
+    ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TIN, TOUT, WM, WN, TM, TN, CONV>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
   hipLaunchKernelGGL((gemm_kernel<TIN, TOUT, WM, WN, TM, TN, CONV>), grid, dim3(256), lds, stream, a);
   ROMA_LAUNCH_CHECK();
   return 0;
@@ -285,7 +314,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 
 template <typename TIN, typename TOUT, bool CONV>
 static int launch_shape(const GemmArgs& a, hipStream_t stream) {
-  if (a.N <= 32) return launch_cfg<TIN, TOUT, 4, 1, 2, 1, CONV>(a, stream);       // 256 x 32
+  if (a.N <= 32) return launch_cfg<TIN, TOUT, 4, 1, 1, 1, CONV>(a, stream);       // 128 x 32
   if (a.N <= 64 || (a.N % 128 != 0 && a.N <= 192))
     return launch_cfg<TIN, TOUT, 4, 1, 1, 2, CONV>(a, stream);                    // 128 x 64
   return launch_cfg<TIN, TOUT, 2, 2, 2, 2, CONV>(a, stream);                      // 128 x 128
@@ -298,6 +327,8 @@ int gemm_launch(const GemmArgs& a, hipStream_t stream) {
   ROMA_REQUIRE(a.ldw % ce == 0 && (reinterpret_cast<uintptr_t>(a.W) & 15) == 0, "gemm: W not 16-byte aligned");
   ROMA_REQUIRE((reinterpret_cast<uintptr_t>(a.A) & 15) == 0, "gemm: A not 16-byte aligned");
   ROMA_REQUIRE(a.sA % ce == 0 && a.sW % ce == 0, "gemm: batch strides must keep 16-byte alignment");
+  if (a.bias) ROMA_REQUIRE((reinterpret_cast<uintptr_t>(a.bias) & 15) == 0, "gemm: bias not 16-byte aligned");
+  if (a.scale) ROMA_REQUIRE((reinterpret_cast<uintptr_t>(a.scale) & 15) == 0, "gemm: scale not 16-byte aligned");
   const bool conv = a.conv_c > 0;
   if (conv) {
     ROMA_REQUIRE(a.conv_c % (8 * ce) == 0, "gemm(conv3x3): Cin must be a multiple of the K slab");
@@ -313,7 +344,6 @@ int gemm_launch(const GemmArgs& a, hipStream_t stream) {
   if (a.in_dt == DT_F32 && a.out_dt == DT_F32) { ROMA_GEMM_DISPATCH(float, float); }
   if (a.in_dt == DT_BF16 && a.out_dt == DT_BF16) { ROMA_GEMM_DISPATCH(bf16_t, bf16_t); }
   if (a.in_dt == DT_BF16 && a.out_dt == DT_F32) { ROMA_GEMM_DISPATCH(bf16_t, float); }
-  if (a.in_dt == DT_F32 && a.out_dt == DT_BF16) { ROMA_GEMM_DISPATCH(float, bf16_t); }
 #undef ROMA_GEMM_DISPATCH
   set_error("gemm: unsupported dtype combination");
   return -1;

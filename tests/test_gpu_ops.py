@@ -134,7 +134,7 @@ def _attention_case(lib, B, heads, hd, N, dt):
     # scatter layout check
     assert torch.allclose(k.cpu().double()[:, :, :N], kk, atol=1e-4 if dt == F32 else 3e-2)
     assert torch.allclose(vt.cpu().double()[:, :, :, :N], vv.transpose(2, 3), atol=1e-4 if dt == F32 else 3e-2)
-    tol = 2e-5 if dt == F32 else 3e-2
+    tol = 2e-5 if dt == F32 else 6e-2  # bf16: P and V are quantised to bf16 before the second MFMA
     err = (out.cpu().double() - ref).abs().max().item()
     assert err < tol, err
 

@@ -18,7 +18,7 @@ fi
 if [[ $WHAT == prof || $WHAT == all ]]; then
   REPO=$PWD
   cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof_bf16" -o bench -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > "$OUT/prof_bf16.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bf16" -o bench -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > "$OUT/prof_bf16.log" 2>&1
   cd "$REPO"
   find "$OUT/prof_bf16" -name "*stats*" | head;
   for f in $(find "$OUT/prof_bf16" -name "*kernel_stats.csv"); do head -25 "$f"; done
