@@ -14,6 +14,9 @@ int layernorm_launch(const float* x, const float* w, const float* b, void* out, 
 int conv3x3_c3_launch(const float* img, const float* w, const float* bias, void* out, int B, int H, int W,
                       int dt_out, hipStream_t s);
 
+// im2col of the first layer: NCHW f32 image -> A[B*H*W, 32], k = ci*9 + ky*3 + kx (zero padding, k >= 27 zero)
+int im2col3x3_c3_launch(const float* img, void* out, int B, int H, int W, int dt_out, hipStream_t s);
+
 // MaxPool 2x2 stride 2 (floor), NHWC
 int maxpool2x2_launch(const void* in, void* out, int B, int H, int W, int C, int dt, hipStream_t s);
 

@@ -125,6 +125,41 @@ int conv3x3_c3_launch(const float* img, const float* w, const float* bias, void*
   return 0;
 }
 
+// ------------------------------------------------------------------ im2col for the first 3x3 layer (K = 27 -> 32)
+template <typename TOUT>
+__global__ __launch_bounds__(256) void im2col3x3_c3_kernel(const float* img, TOUT* out, int B, int H, int W) {
+  const long HW = (long)H * W;
+  const long total = (long)B * HW * 8;  // 8 quads of 4 taps per pixel
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int quad = (int)(idx & 7);
+    const long pix = idx >> 3;
+    const int b = (int)(pix / HW);
+    const int rem = (int)(pix - (long)b * HW);
+    const int y = rem / W, x = rem - y * W;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = quad * 4 + j;
+      float val = 0.f;
+      if (k < 27) {
+        const int ci = k / 9, t = k - ci * 9, ky = t / 3, kx = t - ky * 3;
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) val = img[((long)(b * 3 + ci) * H + yy) * W + xx];
+      }
+      v[j] = val;
+    }
+    ElemIO<TOUT>::st4(out + pix * 32 + quad * 4, v);
+  }
+}
+
+int im2col3x3_c3_launch(const float* img, void* out, int B, int H, int W, int dt_out, hipStream_t s) {
+  const long total = (long)B * H * W * 8;
+  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 1 << 20));
+  ROMA_DT_SWITCH(dt_out, T, hipLaunchKernelGGL(im2col3x3_c3_kernel<T>, grid, dim3(256), 0, s, img, (T*)out, B, H, W));
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------ MaxPool 2x2
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_kernel(const T* in, T* out, int B, int H, int W, int C) {
@@ -579,66 +614,86 @@ template <> struct VecIO<bf16_t> {
   }
 };
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// The stencil is VALU-bound on MI355X (25 MAC per 2-byte element ~ 12.5 FLOP/B > the f32-VALU : HBM ratio), so the
+// work is arranged for the packed-f32 pipe: channel pairs ride in f32x2 (v_pk_fma_f32), and one thread produces a
+// 4 (x) x 2 (y) output patch so every loaded + converted input vector feeds up to 2 x 5 taps.
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv5x5_kernel(const T* in, T* out, const float* w, const float* bias, int B,
                                                         int H, int W, int Cp, long total, int nblocks) {
-  constexpr int CV = VecIO<T>::CV;
+  constexpr int CV = VecIO<T>::CV, C2 = CV / 2;
   // XCD-aware remap (dispatcher places block b on XCD b % 8)
   const int per_xcd = (nblocks + 7) / 8;
   const long lb = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   const long idx = lb * 256 + threadIdx.x;
   if (lb >= nblocks || idx >= total) return;
   const int CG = Cp / CV;
-  const int xt = (W + 3) / 4;
+  const int xt = (W + 3) / 4, yt = (H + 1) / 2;
   const int c = (int)(idx % CG) * CV;
   long r = idx / CG;
   const int xb = (int)(r % xt) * 4;
   r /= xt;
-  const int y = (int)(r % H);
-  const int b = (int)(r / H);
-  float acc[4][CV];
+  const int y0 = (int)(r % yt) * 2;
+  const int b = (int)(r / yt);
+  f32x2 acc[2][4][C2];
 #pragma unroll
-  for (int j = 0; j < CV; ++j) {
-    const float bv = bias[c + j];
+  for (int q = 0; q < C2; ++q) {
+    const f32x2 bv = *reinterpret_cast<const f32x2*>(bias + c + 2 * q);
 #pragma unroll
-    for (int px = 0; px < 4; ++px) acc[px][j] = bv;
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 4; ++px) acc[py][px][q] = bv;
   }
 #pragma unroll
-  for (int ky = 0; ky < 5; ++ky) {
-    const int yy = y + ky - 2;
+  for (int ry = 0; ry < 6; ++ry) {  // input rows y0-2 .. y0+3
+    const int yy = y0 - 2 + ry;
     if (yy < 0 || yy >= H) continue;
     const T* rowp = in + (((long)b * H + yy) * W) * Cp + c;
-    float v[8][CV];
+    f32x2 v[8][C2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int xx = xb - 2 + j;
+      float t[CV];
       if (xx >= 0 && xx < W) {
-        VecIO<T>::ld(rowp + (long)xx * Cp, v[j]);
+        VecIO<T>::ld(rowp + (long)xx * Cp, t);
       } else {
 #pragma unroll
-        for (int q = 0; q < CV; ++q) v[j][q] = 0.f;
+        for (int q = 0; q < CV; ++q) t[q] = 0.f;
       }
+#pragma unroll
+      for (int q = 0; q < C2; ++q) v[j][q] = f32x2{t[2 * q], t[2 * q + 1]};
     }
 #pragma unroll
-    for (int kx = 0; kx < 5; ++kx) {
-      float wv[CV];
+    for (int py = 0; py < 2; ++py) {
+      const int ky = ry - py;  // compile-time after unrolling
+      if (ky < 0 || ky > 4) continue;
 #pragma unroll
-      for (int q = 0; q < CV; q += 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(w + (long)(ky * 5 + kx) * Cp + c + q);
-        wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3];
+      for (int kx = 0; kx < 5; ++kx) {
+        f32x2 wv[C2];
+#pragma unroll
+        for (int q = 0; q < C2; ++q) wv[q] = *reinterpret_cast<const f32x2*>(w + (long)(ky * 5 + kx) * Cp + c + 2 * q);
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+#pragma unroll
+          for (int q = 0; q < C2; ++q) acc[py][px][q] = v[px + kx][q] * wv[q] + acc[py][px][q];
       }
-#pragma unroll
-      for (int px = 0; px < 4; ++px)
-#pragma unroll
-        for (int q = 0; q < CV; ++q) acc[px][q] = fmaf(v[px + kx][q], wv[q], acc[px][q]);
     }
   }
 #pragma unroll
-  for (int px = 0; px < 4; ++px) {
-    if (xb + px < W) {
+  for (int py = 0; py < 2; ++py) {
+    if (y0 + py >= H) continue;
 #pragma unroll
-      for (int q = 0; q < CV; ++q) acc[px][q] = fmaxf(acc[px][q], 0.f);
-      VecIO<T>::st(out + (((long)b * H + y) * W + xb + px) * Cp + c, acc[px]);
+    for (int px = 0; px < 4; ++px) {
+      if (xb + px < W) {
+        float o[CV];
+#pragma unroll
+        for (int q = 0; q < C2; ++q) {
+          o[2 * q] = fmaxf(acc[py][px][q][0], 0.f);
+          o[2 * q + 1] = fmaxf(acc[py][px][q][1], 0.f);
+        }
+        VecIO<T>::st(out + (((long)b * H + y0 + py) * W + xb + px) * Cp + c, o);
+      }
     }
   }
 }
@@ -647,7 +702,7 @@ int dwconv5x5_launch(const void* in, void* out, const float* w, const float* bia
                      int dt, hipStream_t s) {
   const int cv = dt == DT_F32 ? 4 : 8;
   ROMA_REQUIRE(Cp % cv == 0, "dwconv5x5: padded channel count must be a multiple of the 16-byte vector");
-  const long total = (long)B * H * ((W + 3) / 4) * (Cp / cv);
+  const long total = (long)B * ((H + 1) / 2) * ((W + 3) / 4) * (Cp / cv);
   const int nblocks = (int)((total + 255) / 256);
   dim3 grid((unsigned)(((nblocks + 7) / 8) * 8));
   ProfScope ps(dt == DT_F32 ? "dwconv5x5_kernel<f32>" : "dwconv5x5_kernel<bf16>",

@@ -62,8 +62,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
   const int bz = blockIdx.z;
-  const long m0 = (long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware tile order (the dispatcher places workgroup b on XCD b % 8, each XCD has a private L2): every XCD
+  // walks a contiguous band of m-tiles with n fastest, so the n-tiles sharing one activation tile - and, for the
+  // 3x3 convolution, the vertically adjacent image rows - hit the same L2 instead of re-reading HBM 8 times.
+  const int NT = (a.N + BN - 1) / BN;
+  const long nblk = (long)((a.M + BM - 1) / BM) * NT;
+  const long per_xcd = (nblk + 7) / 8;
+  const long L = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (L >= nblk) return;
+  const long m0 = (L / NT) * BM;
+  const int n0 = (int)(L % NT) * BN;
   if (a.lower_only && n0 > m0 + BM - 1) return;
 
   const TIN* Ab = reinterpret_cast<const TIN*>(a.A) + (long)bz * a.sA;
@@ -295,7 +303,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 template <typename TIN, typename TOUT, int WM, int WN, int TM, int TN, bool CONV>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN), (unsigned)a.batch);
+  const long nblk = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  dim3 grid((unsigned)(((nblk + 7) / 8) * 8), 1, (unsigned)a.batch);
   size_t lds = (size_t)2 * (BM + BN) * ROWB;
   char pname[96];
   snprintf(pname, sizeof pname, "gemm_kernel<%s,%s,%d,%d,%d,%d,%s>", sizeof(TIN) == 4 ? "f32" : "bf16",
@@ -315,8 +324,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 template <typename TIN, typename TOUT, bool CONV>
 static int launch_shape(const GemmArgs& a, hipStream_t stream) {
   if (a.N <= 32) return launch_cfg<TIN, TOUT, 4, 1, 1, 1, CONV>(a, stream);       // 128 x 32
-  if (a.N <= 64 || (a.N % 128 != 0 && a.N <= 192))
-    return launch_cfg<TIN, TOUT, 4, 1, 1, 2, CONV>(a, stream);                    // 128 x 64
+  if (a.N <= 64) return launch_cfg<TIN, TOUT, 4, 1, 1, 2, CONV>(a, stream);       // 128 x 64
+  if constexpr (!CONV) {
+    if (a.N > 128 && a.N <= 160) return launch_cfg<TIN, TOUT, 4, 1, 1, 5, false>(a, stream);  // 128 x 160: one n-tile
+  }
   return launch_cfg<TIN, TOUT, 2, 2, 2, 2, CONV>(a, stream);                      // 128 x 128
 }
 

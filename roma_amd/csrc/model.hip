@@ -268,6 +268,11 @@ int Model::pack_weights() {
           for (int k = 0; k < 9; ++k) wp[(ci * 9 + k) * 64 + o] = w[(o * 3 + ci) * 9 + k] * s[o];
       if (int rc = upload_f32(wp, &c1_w)) return rc;
       if (int rc = upload_f32(bf, &c1_b)) return rc;
+      // MFMA form of the first layer: [64][32] with k = ci*9 + ky*3 + kx (27 real taps, zero padded to 32)
+      std::vector<float> wg(64 * 27);
+      for (int o = 0; o < 64; ++o)
+        for (int k = 0; k < 27; ++k) wg[o * 27 + k] = w[o * 27 + k] * s[o];
+      if (int rc = make_lin(wg, &bf, 64, 27, &vgg[0])) return rc;
     } else {
       std::vector<float> wp((size_t)cout * 9 * cin);
       for (int o = 0; o < cout; ++o)
@@ -333,7 +338,9 @@ int Model::pack_weights() {
     r.radius = REF_RAD[s];
     r.K = r.radius ? (2 * r.radius + 1) * (2 * r.radius + 1) : 0;
     r.C = 2 * r.Cf + r.E + r.K;
-    r.Cp = (int)round_up(r.C, 8);
+    // channel padding: whole 128-byte rows for the wide (MFMA-bound) refiners so every GEMM slab row is one aligned
+    // cache line; 16-byte granularity for the narrow HBM-bound ones (144, 24 channels)
+    r.Cp = (int)(r.C >= 256 ? round_up(r.C, 64) : round_up(r.C, 8));
     const std::string p = std::string("decoder.conv_refiner.") + SCALES[s];
     if (int rc = upload_f32(H(p + ".disp_emb.weight"), &r.emb_w)) return rc;
     if (int rc = upload_f32(H(p + ".disp_emb.bias"), &r.emb_b)) return rc;
@@ -590,8 +597,15 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       const size_t enc_mark = arena.mark();
       void* t0 = AL((size_t)nimg * H * W * 64, esz);
       void* t1 = AL((size_t)nimg * (H / 2) * (W / 2) * 64, esz);
-      RUN(conv3x3_c3_launch(imA, c1_w, c1_b, t0, B, H, W, act_dt, st));
-      RUN(conv3x3_c3_launch(imB, c1_w, c1_b, off(t0, (long)B * H * W * 64), B, H, W, act_dt, st));
+      {  // first layer (Cin = 3): im2col to K = 32, then the same MFMA GEMM as every other layer
+        void* col1 = AL((size_t)nimg * H * W * 32, esz);
+        RUN(im2col3x3_c3_launch(imA, col1, B, H, W, act_dt, st));
+        RUN(im2col3x3_c3_launch(imB, off(col1, (long)B * H * W * 32), B, H, W, act_dt, st));
+        GemmArgs g;
+        g.A = col1; g.lda = 32; g.W = vgg[0].w; g.ldw = vgg[0].ldw; g.C = t0; g.ldc = 64;
+        g.M = nimg * H * W; g.N = 64; g.K = 32; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = vgg[0].b; g.act = ACT_RELU;
+        RUN(gemm_launch(g, st));
+      }
       auto conv = [&](int li, const void* in, void* out, int h, int w) -> int {
         GemmArgs g;
         g.A = in; g.W = vgg[li].w; g.ldw = vgg[li].ldw; g.C = out; g.ldc = vgg_cout[li];
