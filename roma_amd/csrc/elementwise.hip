@@ -616,98 +616,176 @@ template <> struct VecIO<bf16_t> {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-// The stencil is VALU-bound on MI355X (25 MAC per 2-byte element ~ 12.5 FLOP/B > the f32-VALU : HBM ratio), so the
-// work is arranged for the packed-f32 pipe: channel pairs ride in f32x2 (v_pk_fma_f32), and one thread produces a
-// 4 (x) x 2 (y) output patch so every loaded + converted input vector feeds up to 2 x 5 taps.
+// Rolling-window form.  The stencil is NOT HBM-bound on MI355X when written naively: 25 MAC per 2-byte element put
+// it on the VALU / vector-L1 path (a first version re-loaded the 25 weight vectors and 6 input rows per 8 outputs
+// and ran at 1.4 TB/s with the texture path saturated).  Here one thread owns 4 channels x 4 x-positions and walks a
+// strip of rows top to bottom:
+//   * its 25 x 4 weights stay in registers for the whole strip (one load per thread, not per output),
+//   * each input row is loaded ONCE (8 vectors) and feeds the 5 output rows it touches (5 rolling accumulator
+//     slots, static indices by unrolling the row loop 5x), i.e. 200 packed-f32 FMAs (v_pk_fma_f32) per 8 loads,
+//   * the next input row is prefetched while the current one is multiplied.
+// Workgroups are remapped so each XCD owns a contiguous band of strips (private L2 sees the 4-row halo once).
+template <typename T> struct RawVec;
+template <> struct RawVec<float> {
+  typedef f32x4 raw;
+  __device__ static inline raw ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  __device__ static inline raw zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __device__ static inline raw mask(raw r, uint32_t m) {  // bitwise AND keeps the load unconditional (no branch)
+    return f32x4{__uint_as_float(__float_as_uint(r[0]) & m), __uint_as_float(__float_as_uint(r[1]) & m),
+                 __uint_as_float(__float_as_uint(r[2]) & m), __uint_as_float(__float_as_uint(r[3]) & m)};
+  }
+  __device__ static inline void cvt(raw r, f32x2& a, f32x2& b) { a = f32x2{r[0], r[1]}; b = f32x2{r[2], r[3]}; }
+  __device__ static inline void st(float* p, f32x2 a, f32x2 b) { *reinterpret_cast<f32x4*>(p) = f32x4{a[0], a[1], b[0], b[1]}; }
+};
+template <> struct RawVec<bf16_t> {
+  typedef uint2 raw;
+  __device__ static inline raw ld(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+  __device__ static inline raw zero() { return make_uint2(0, 0); }
+  __device__ static inline raw mask(raw r, uint32_t m) { return make_uint2(r.x & m, r.y & m); }
+  __device__ static inline void cvt(raw r, f32x2& a, f32x2& b) {
+    a = f32x2{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
+    b = f32x2{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+  }
+  __device__ static inline void st(bf16_t* p, f32x2 a, f32x2 b) {
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16(a[0]) | ((uint32_t)f32_to_bf16(a[1]) << 16);
+    u.y = (uint32_t)f32_to_bf16(b[0]) | ((uint32_t)f32_to_bf16(b[1]) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+  }
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv5x5_kernel(const T* in, T* out, const float* w, const float* bias, int B,
-                                                        int H, int W, int Cp, long total, int nblocks) {
-  constexpr int CV = VecIO<T>::CV, C2 = CV / 2;
-  // XCD-aware remap (dispatcher places block b on XCD b % 8)
+__global__ __launch_bounds__(256, 2) void dwconv5x5_kernel(const T* in, T* out, const float* w, const float* bias, int B,
+                                                           int H, int W, int Cp, int SY, int GC, int nchunk, int nxg,
+                                                           int nblocks) {
+  typedef typename RawVec<T>::raw raw_t;
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [25][GC*4] weights + [GC*4] bias of this channel chunk
   const int per_xcd = (nblocks + 7) / 8;
   const long lb = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-  const long idx = lb * 256 + threadIdx.x;
-  if (lb >= nblocks || idx >= total) return;
-  const int CG = Cp / CV;
-  const int xt = (W + 3) / 4, yt = (H + 1) / 2;
-  const int c = (int)(idx % CG) * CV;
-  long r = idx / CG;
-  const int xb = (int)(r % xt) * 4;
-  r /= xt;
-  const int y0 = (int)(r % yt) * 2;
+  if (lb >= nblocks) return;
+  const int chunk = (int)(lb % nchunk);
+  long r = lb / nchunk;
+  const int xg = (int)(r % nxg);
+  r /= nxg;
+  const int yt = (H + SY - 1) / SY;
+  const int ys = (int)(r % yt) * SY;
   const int b = (int)(r / yt);
-  f32x2 acc[2][4][C2];
-#pragma unroll
-  for (int q = 0; q < C2; ++q) {
-    const f32x2 bv = *reinterpret_cast<const f32x2*>(bias + c + 2 * q);
-#pragma unroll
-    for (int py = 0; py < 2; ++py)
-#pragma unroll
-      for (int px = 0; px < 4; ++px) acc[py][px][q] = bv;
+  const int XQ = 256 / GC;
+  const int cg = threadIdx.x % GC, xq = threadIdx.x / GC;
+  const int c0 = chunk * GC * 4;
+  constexpr int cw = 256;  // fixed LDS row stride: weight reads become base + immediate offset
+  for (int i = threadIdx.x; i < 26 * cw; i += 256) {  // (columns >= GC*4 are never read)
+    const int t = i / cw, cc = i - t * cw;
+    const int ch = c0 + cc;
+    wsm[i] = ch < Cp ? (t < 25 ? w[(long)t * Cp + ch] : bias[ch]) : 0.f;
   }
+  __syncthreads();
+  const int c = c0 + cg * 4;
+  const int xb = (xg * XQ + xq) * 4;
+  if (xq >= XQ || c >= Cp || xb >= W) return;
+  const int sy = min(SY, H - ys);
+
+  const f32x4 bx = *reinterpret_cast<const f32x4*>(&wsm[25 * cw + cg * 4]);
+  const f32x2 bias0 = f32x2{bx[0], bx[1]}, bias1 = f32x2{bx[2], bx[3]};
+  f32x2 acc[5][4][2];
 #pragma unroll
-  for (int ry = 0; ry < 6; ++ry) {  // input rows y0-2 .. y0+3
-    const int yy = y0 - 2 + ry;
-    if (yy < 0 || yy >= H) continue;
-    const T* rowp = in + (((long)b * H + yy) * W) * Cp + c;
-    f32x2 v[8][C2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int xx = xb - 2 + j;
-      float t[CV];
-      if (xx >= 0 && xx < W) {
-        VecIO<T>::ld(rowp + (long)xx * Cp, t);
-      } else {
-#pragma unroll
-        for (int q = 0; q < CV; ++q) t[q] = 0.f;
-      }
-#pragma unroll
-      for (int q = 0; q < C2; ++q) v[j][q] = f32x2{t[2 * q], t[2 * q + 1]};
-    }
-#pragma unroll
-    for (int py = 0; py < 2; ++py) {
-      const int ky = ry - py;  // compile-time after unrolling
-      if (ky < 0 || ky > 4) continue;
-#pragma unroll
-      for (int kx = 0; kx < 5; ++kx) {
-        f32x2 wv[C2];
-#pragma unroll
-        for (int q = 0; q < C2; ++q) wv[q] = *reinterpret_cast<const f32x2*>(w + (long)(ky * 5 + kx) * Cp + c + 2 * q);
-#pragma unroll
-        for (int px = 0; px < 4; ++px)
-#pragma unroll
-          for (int q = 0; q < C2; ++q) acc[py][px][q] = v[px + kx][q] * wv[q] + acc[py][px][q];
-      }
-    }
-  }
-#pragma unroll
-  for (int py = 0; py < 2; ++py) {
-    if (y0 + py >= H) continue;
+  for (int s5 = 0; s5 < 5; ++s5)
 #pragma unroll
     for (int px = 0; px < 4; ++px) {
-      if (xb + px < W) {
-        float o[CV];
+      acc[s5][px][0] = bias0;
+      acc[s5][px][1] = bias1;
+    }
+  bool colok[8];
 #pragma unroll
-        for (int q = 0; q < C2; ++q) {
-          o[2 * q] = fmaxf(acc[py][px][q][0], 0.f);
-          o[2 * q + 1] = fmaxf(acc[py][px][q][1], 0.f);
+  for (int j = 0; j < 8; ++j) colok[j] = (xb - 2 + j >= 0) && (xb - 2 + j < W);
+  long colofs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) colofs[j] = (long)min(max(xb - 2 + j, 0), W - 1) * Cp;
+  const T* base = in + ((long)b * H * W) * Cp + c;
+  T* obase = out + ((long)b * H * W) * Cp + c;
+
+// branch-free row load: out-of-image taps read a clamped (valid) address and are zeroed by a select afterwards
+#define ROMA_DW_LOAD_ROW(TT, DST)                                                                         \
+  {                                                                                                       \
+    const int yy_ = ys - 2 + (TT);                                                                        \
+    const bool rok_ = yy_ >= 0 && yy_ < H;                                                                \
+    const T* rowp_ = base + (long)min(max(yy_, 0), H - 1) * W * Cp;                                       \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
+      DST[j] = RawVec<T>::mask(RawVec<T>::ld(rowp_ + colofs[j]), (rok_ && colok[j]) ? 0xffffffffu : 0u);  \
+    }                                                                                                     \
+  }
+
+  // acc[k] holds output row o = t - 4 + k while input row t is processed (tap row ky = 4 - k)
+  raw_t cur[8], nxt[8];
+  ROMA_DW_LOAD_ROW(0, cur);
+#pragma nounroll
+  for (int t = 0; t < sy + 4; ++t) {
+    ROMA_DW_LOAD_ROW(t + 1, nxt);
+    f32x2 v[8][2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) RawVec<T>::cvt(cur[j], v[j][0], v[j][1]);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int ky = 4 - k;
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        const f32x4 wx = *reinterpret_cast<const f32x4*>(&wsm[(ky * 5 + kx) * cw + cg * 4]);
+        const f32x2 w0 = f32x2{wx[0], wx[1]}, w1 = f32x2{wx[2], wx[3]};
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          acc[k][px][0] = v[px + kx][0] * w0 + acc[k][px][0];
+          acc[k][px][1] = v[px + kx][1] * w1 + acc[k][px][1];
         }
-        VecIO<T>::st(out + (((long)b * H + y0 + py) * W + xb + px) * Cp + c, o);
       }
     }
+    const int o = t - 4;
+    if (o >= 0) {
+      T* orow = obase + ((long)(ys + o) * W + xb) * Cp;
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        if (xb + px < W) {
+          f32x2 a0 = acc[0][px][0], a1 = acc[0][px][1];
+          a0 = f32x2{fmaxf(a0[0], 0.f), fmaxf(a0[1], 0.f)};
+          a1 = f32x2{fmaxf(a1[0], 0.f), fmaxf(a1[1], 0.f)};
+          RawVec<T>::st(orow + (long)px * Cp, a0, a1);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        acc[k][px][0] = acc[k + 1][px][0];
+        acc[k][px][1] = acc[k + 1][px][1];
+      }
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      acc[4][px][0] = bias0;
+      acc[4][px][1] = bias1;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
   }
 }
 
+#undef ROMA_DW_LOAD_ROW
+
 int dwconv5x5_launch(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp,
                      int dt, hipStream_t s) {
-  const int cv = dt == DT_F32 ? 4 : 8;
-  ROMA_REQUIRE(Cp % cv == 0, "dwconv5x5: padded channel count must be a multiple of the 16-byte vector");
-  const long total = (long)B * ((H + 1) / 2) * ((W + 3) / 4) * (Cp / cv);
-  const int nblocks = (int)((total + 255) / 256);
+  ROMA_REQUIRE(Cp % 4 == 0, "dwconv5x5: padded channel count must be a multiple of 4");
+  const int SY = H >= 256 ? 36 : 16;  // strip height (SY + 4 input rows per strip; SY + 4 divisible by the 5x unroll)
+  const int CG = Cp / 4;
+  const int nchunk = (CG + 63) / 64;
+  const int GC = (CG + nchunk - 1) / nchunk;  // channel groups (of 4) per workgroup, <= 64
+  const int XQ = 256 / GC;                    // x tiles (of 4 pixels) per workgroup
+  const int nxg = ((W + 3) / 4 + XQ - 1) / XQ;
+  const long nb = (long)B * ((H + SY - 1) / SY) * nxg * nchunk;
+  const int nblocks = (int)nb;
   dim3 grid((unsigned)(((nblocks + 7) / 8) * 8));
+  const size_t lds = (size_t)26 * 256 * sizeof(float);  // fixed 256-float rows (see kernel)
   ProfScope ps(dt == DT_F32 ? "dwconv5x5_kernel<f32>" : "dwconv5x5_kernel<bf16>",
                2.0 * (double)B * H * W * Cp * (dt == DT_F32 ? 4.0 : 2.0), "byte", s);
-  ROMA_DT_SWITCH(dt, T, hipLaunchKernelGGL(dwconv5x5_kernel<T>, grid, dim3(256), 0, s, (const T*)in, (T*)out, w, bias, B, H, W, Cp, total, nblocks));
+  ROMA_DT_SWITCH(dt, T, hipLaunchKernelGGL(dwconv5x5_kernel<T>, grid, dim3(256), lds, s, (const T*)in, (T*)out, w, bias, B, H, W, Cp, SY, GC, nchunk, nxg, nblocks));
   ROMA_LAUNCH_CHECK();
   return 0;
 }
