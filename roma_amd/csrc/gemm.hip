@@ -49,11 +49,13 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
 }
 
 template <typename TIN, typename TOUT, int WM, int WN, int TM, int TN, bool CONV>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs a) {
   constexpr int CE = InTraits<TIN>::CE;
   constexpr int BKE = 8 * CE;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int NA = BM / 32, NW = BN / 32;  // DMA instructions per wave per slab (8 rows x 128 B each)
+  constexpr int NWAVES = WM * WN;
+  constexpr int NA = BM / (8 * NWAVES), NW = BN / (8 * NWAVES);  // DMA instructions per wave per slab (8 rows x 128 B each)
+  static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "tile rows must split evenly over the waves");
   constexpr int BUF = (BM + BN) * ROWB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -316,15 +318,29 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<TIN, TOUT, WM, WN, TM, TN, CONV>), grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((gemm_kernel<TIN, TOUT, WM, WN, TM, TN, CONV>), grid, dim3(WM * WN * 64), lds, stream, a);
   ROMA_LAUNCH_CHECK();
   return 0;
 }
 
+// Tile selection.  The DMA'd operand traffic is 2*(BM+BN)*K bytes per BM*BN*K MACs, and ~13 TB/s of L2->LDS
+// traffic is what the chip sustains, so the large MFMA-bound problems need the 256-row tiles (8 waves, 128 KB LDS):
+// 128x128 caps at ~0.4-0.6 PF/s (64 FLOP/B), 256x192 / 256x256 at 110 / 128 FLOP/B.
 template <typename TIN, typename TOUT, bool CONV>
 static int launch_shape(const GemmArgs& a, hipStream_t stream) {
   if (a.N <= 32) return launch_cfg<TIN, TOUT, 4, 1, 1, 1, CONV>(a, stream);       // 128 x 32
-  if (a.N <= 64) return launch_cfg<TIN, TOUT, 4, 1, 1, 2, CONV>(a, stream);       // 128 x 64
+  const bool big_m = (long)a.M * a.batch >= 8192 && a.M >= 1024;
+  if (big_m && a.N >= 384) {
+    const long w256 = ((a.N + 255) / 256) * 256, w192 = ((a.N + 191) / 192) * 192;
+    if (w192 < w256) return launch_cfg<TIN, TOUT, 4, 2, 2, 3, CONV>(a, stream);    // 256 x 192
+    return launch_cfg<TIN, TOUT, 2, 4, 4, 2, CONV>(a, stream);                     // 256 x 256
+  }
+  if (big_m && a.N > 192 && a.N <= 256) return launch_cfg<TIN, TOUT, 2, 4, 4, 2, CONV>(a, stream);  // 256 x 256
+  if (a.N <= 64) {
+    if (big_m) return launch_cfg<TIN, TOUT, 8, 1, 1, 2, CONV>(a, stream);         // 256 x 64
+    return launch_cfg<TIN, TOUT, 4, 1, 1, 2, CONV>(a, stream);                    // 128 x 64
+  }
+  if (big_m && a.N <= 128) return launch_cfg<TIN, TOUT, 4, 2, 2, 2, CONV>(a, stream);  // 256 x 128
   if constexpr (!CONV) {
     if (a.N > 128 && a.N <= 160) return launch_cfg<TIN, TOUT, 4, 1, 1, 5, false>(a, stream);  // 128 x 160: one n-tile
   }

@@ -60,7 +60,8 @@ def gemm(lib, A, W, bias=None, scale=None, res=None, act=0, alpha=1.0, dt_in=F32
     return out
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 200, 72), (128, 128, 32), (1000, 24, 24), (513, 64, 136), (77, 4097, 1024), (260, 1384, 1384)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 72), (128, 128, 32), (1000, 24, 24), (513, 64, 136), (77, 4097, 1024), (260, 1384, 1384),
+                                   (4100, 576, 136), (3000, 1024, 96), (9000, 64, 72), (8200, 128, 64), (2500, 144, 144)])
 def test_gemm_f32_epilogues(lib, M, N, K):
     A, W, b, s, r = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(N, seed=4), rnd(M, N, seed=5)
     ref = (A.double() @ W.double().T + b.double())
@@ -90,7 +91,7 @@ def test_gemm_batched_strided_accumulate(lib):
     assert torch.allclose(out.cpu().double(), ref, atol=1e-3, rtol=1e-5)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 200, 72), (1000, 24, 24), (512, 1024, 4096)])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 72), (1000, 24, 24), (512, 1024, 4096), (4100, 1152, 256), (3000, 1024, 192), (9000, 64, 72), (2500, 144, 144)])
 def test_gemm_bf16(lib, M, N, K):
     A, W, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2).bfloat16(), rnd(N, seed=3)
     ref = A.double() @ W.double().T + b.double()
@@ -101,7 +102,7 @@ def test_gemm_bf16(lib, M, N, K):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 11, 64, 128), (1, 16, 16, 128, 64)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 11, 64, 128), (1, 16, 16, 128, 64), (3, 56, 60, 64, 64), (3, 56, 60, 64, 128), (2, 72, 70, 64, 256)])
 def test_conv3x3_implicit_gemm(lib, dt, B, H, W, Cin, Cout):
     x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, std=0.05), rnd(Cout, seed=3)
     tdt = torch.float32 if dt == F32 else torch.bfloat16
