@@ -20,6 +20,8 @@
 
 #include <stdio.h>
 
+#include <algorithm>
+
 namespace roma {
 
 constexpr int ROWB = 128;  // bytes per LDS row = 8 chunks of 16 B
@@ -207,6 +209,73 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs a) {
   const float* Rb = a.res ? a.res + (long)bz * a.sR : nullptr;
   const bool vecC = ((a.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
   const bool vecR = Rb && ((a.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(Rb) & 15) == 0);
+
+  if constexpr (sizeof(TOUT) == 2) {
+    // bf16 output, plain epilogue: the MFMA layout gives each lane 4 consecutive n of ONE row, i.e. a wave store
+    // would scatter 8-byte pieces over 32 rows (measured 0.56 TB/s).  Stage the wave's tile through its private
+    // LDS slice instead and write whole rows: 16 B per lane, 128..384 contiguous bytes per row.
+    constexpr int RS = TN * 64 + 16;  // LDS row stride in bytes (16-byte aligned; the pad staggers the banks)
+    if (a.mode == EPI_STD && Rb == nullptr && (a.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0) {
+      __builtin_amdgcn_s_barrier();  // every wave is done with the operand buffers
+      char* ws = smem + wave * (TM * 32 * RS);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int nl = tn * 32 + 8 * rg + 4 * h;  // local column
+            const int n = n0 + wn * TN * 32 + nl;
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = a.alpha * acc[tn][tm][4 * rg + j];
+            if (a.bias && n + 3 < a.N) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+            else if (a.bias) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (n + j < a.N) v[j] += a.bias[n + j];
+            }
+            if (a.act == ACT_RELU) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            } else if (a.act == ACT_GELU) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            }
+            if (a.scale) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (n + j < a.N) v[j] *= a.scale[n + j];
+            }
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(ws + (tm * 32 + l31) * RS + nl * 2) = pk;
+          }
+      // the slice is wave-private: LDS ops of one wave complete in order, no barrier needed
+      constexpr int CPR = TN * 4;  // 16-byte chunks per row
+      const long mw = m0 + wm * TM * 32;
+      const int nw0 = n0 + wn * TN * 32;
+#pragma unroll 4
+      for (int c = lane; c < TM * 32 * CPR; c += 64) {
+        const int row = c / CPR, ch = c - row * CPR;
+        const long m = mw + row;
+        const int n = nw0 + ch * 8;
+        if (m >= a.M || n >= a.N) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RS + ch * 16);
+        bf16_t* dst = reinterpret_cast<bf16_t*>(Cb) + m * a.ldc + n;
+        if (n + 8 <= a.N) {
+          *reinterpret_cast<uint4*>(dst) = v;
+        } else {
+          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+          for (int j = 0; j < 8; ++j)
+            if (n + j < a.N) dst[j] = e[j];
+        }
+      }
+      return;
+    }
+  }
+
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const long m = m0 + (wm * TM + tm) * 32 + l31;
@@ -308,6 +377,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   const long nblk = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   dim3 grid((unsigned)(((nblk + 7) / 8) * 8), 1, (unsigned)a.batch);
   size_t lds = (size_t)2 * (BM + BN) * ROWB;
+  if (sizeof(TOUT) == 2) lds = std::max(lds, (size_t)WM * WN * TM * 32 * (TN * 64 + 16));  // bf16 epilogue staging
   char pname[96];
   snprintf(pname, sizeof pname, "gemm_kernel<%s,%s,%d,%d,%d,%d,%s>", sizeof(TIN) == 4 ? "f32" : "bf16",
            sizeof(TOUT) == 4 ? "f32" : "bf16", WM, WN, TM, TN, CONV ? "conv3x3" : "dense");
