@@ -39,6 +39,7 @@ struct GemmArgs {
   const float *nx = nullptr, *ny = nullptr;
   long sNx = 0, sNy = 0;
   float inv_t = 0.f, diag_add = 0.f;
+  int dbg = 0;  // tuning experiments only (ROMA_GEMM_DBG): 1 = skip output stores, 2 = skip the K loop
 };
 
 // Launches on `stream`; returns 0 or a negative error code (message via roma_last_error()).

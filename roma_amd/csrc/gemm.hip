@@ -19,6 +19,7 @@
 #include "gemm.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
 }
 
 template <typename TIN, typename TOUT, int WM, int WN, int TM, int TN, bool CONV>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a) {
   constexpr int CE = InTraits<TIN>::CE;
   constexpr int BKE = 8 * CE;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -72,11 +73,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs a) {
   const int NT = (a.N + BN - 1) / BN;
   const long nblk = (long)((a.M + BM - 1) / BM) * NT;
   const long per_xcd = (nblk + 7) / 8;
-  const long L = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-  if (L >= nblk) return;
-  const long m0 = (L / NT) * BM;
-  const int n0 = (int)(L % NT) * BN;
-  if (a.lower_only && n0 > m0 + BM - 1) return;
+  // Persistent workgroups: each walks the tiles li, li + wg_per_xcd, ... of its XCD band.  While the last K slab
+  // of a tile is multiplied the FIRST slab of the workgroup's next tile is already DMA'd, and it keeps flying
+  // under the epilogue (which stages through its own LDS slice), so launch latency, the cold first slab and the
+  // epilogue are no longer serialised per tile (they cost ~15 us per 256x256 tile with one workgroup per CU).
+  const int xcd = blockIdx.x % 8;
+  const long wg_per_xcd = gridDim.x / 8;
+  long li = blockIdx.x / 8;
+  if (li >= per_xcd || (long)xcd * per_xcd + li >= nblk) return;
 
   const TIN* Ab = reinterpret_cast<const TIN*>(a.A) + (long)bz * a.sA;
   const TIN* Wb = reinterpret_cast<const TIN*>(a.W) + (long)bz * a.sW;
@@ -86,38 +90,43 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs a) {
   const int r8 = lane >> 3, slot = lane & 7;
   const char* a_src[NA];
   int a_chunk[NA], a_y[NA], a_x[NA];
-#pragma unroll
-  for (int j = 0; j < NA; ++j) {
-    const int row = 8 * (wave * NA + j) + r8;
-    const int chunk = slot ^ ((row >> 1) & 7);
-    const long gm = m0 + row;
-    a_chunk[j] = chunk;
-    if (gm < a.M) {
-      if (CONV) {
-        const long hw = (long)a.conv_h * a.conv_w;
-        const long b = gm / hw;
-        const int rem = (int)(gm - b * hw);
-        a_y[j] = rem / a.conv_w;
-        a_x[j] = rem - a_y[j] * a.conv_w;
-        a_src[j] = reinterpret_cast<const char*>(Ab + gm * a.conv_c + chunk * CE);
-      } else {
-        a_y[j] = a_x[j] = 0;
-        a_src[j] = reinterpret_cast<const char*>(Ab + gm * a.lda + chunk * CE);
-      }
-    } else {
-      a_y[j] = -100000;  // conv: every tap out of range
-      a_x[j] = 0;
-      a_src[j] = nullptr;
-    }
-  }
   const char* w_src[NW];
   int w_chunk[NW];
-#pragma unroll
-  for (int j = 0; j < NW; ++j) {
-    const int row = 8 * (wave * NW + j) + r8;
-    const int chunk = slot ^ ((row >> 1) & 7);
-    w_chunk[j] = chunk;
-    w_src[j] = (n0 + row < a.N) ? reinterpret_cast<const char*>(Wb + (long)(n0 + row) * a.ldw + chunk * CE) : nullptr;
+  long d_m0 = 0;  // tile the descriptors currently describe
+  int d_n0 = 0;
+#define ROMA_TILE_SETUP(LTILE)                                                                              \
+  {                                                                                                         \
+    d_m0 = ((LTILE) / NT) * BM;                                                                             \
+    d_n0 = (int)((LTILE) % NT) * BN;                                                                        \
+    _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                        \
+      const int row = 8 * (wave * NA + j) + r8;                                                             \
+      const int chunk = slot ^ ((row >> 1) & 7);                                                            \
+      const long gm = d_m0 + row;                                                                           \
+      a_chunk[j] = chunk;                                                                                   \
+      if (gm < a.M) {                                                                                       \
+        if (CONV) {                                                                                         \
+          const long hw = (long)a.conv_h * a.conv_w;                                                        \
+          const long b = gm / hw;                                                                           \
+          const int rem = (int)(gm - b * hw);                                                               \
+          a_y[j] = rem / a.conv_w;                                                                          \
+          a_x[j] = rem - a_y[j] * a.conv_w;                                                                 \
+          a_src[j] = reinterpret_cast<const char*>(Ab + gm * a.conv_c + chunk * CE);                        \
+        } else {                                                                                            \
+          a_y[j] = a_x[j] = 0;                                                                              \
+          a_src[j] = reinterpret_cast<const char*>(Ab + gm * a.lda + chunk * CE);                           \
+        }                                                                                                   \
+      } else {                                                                                              \
+        a_y[j] = -100000; /* conv: every tap out of range */                                                \
+        a_x[j] = 0;                                                                                         \
+        a_src[j] = nullptr;                                                                                 \
+      }                                                                                                     \
+    }                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                                        \
+      const int row = 8 * (wave * NW + j) + r8;                                                             \
+      const int chunk = slot ^ ((row >> 1) & 7);                                                            \
+      w_chunk[j] = chunk;                                                                                   \
+      w_src[j] = (d_n0 + row < a.N) ? reinterpret_cast<const char*>(Wb + (long)(d_n0 + row) * a.ldw + chunk * CE) : nullptr; \
+    }                                                                                                       \
   }
 
 #define ROMA_ISSUE_SLAB(KT, BUFI)                                                                           \
@@ -147,6 +156,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs a) {
     }                                                                                                       \
   }
 
+  // fragment read offsets: row = tile_row0 + l31 (tile_row0 % 32 == 0), slot = (2g + h) ^ ((l31 >> 1) & 7)
+  const int sw = (l31 >> 1) & 7;
+  int rd_off[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) rd_off[g] = l31 * ROWB + (((2 * g + h) ^ sw) << 4);
+
+  const int nk = (a.dbg & 2) ? 1 : (a.K + BKE - 1) / BKE;
+  ROMA_TILE_SETUP((long)xcd * per_xcd + li);
+  ROMA_ISSUE_SLAB(0, 0);
+  int bsel = 0;  // LDS buffer holding slab 0 of the current tile
+  for (;;) {
+  const long m0 = d_m0;
+  const int n0 = d_n0;
+  const long li_next = li + wg_per_xcd;
+  const bool has_next = li_next < per_xcd && (long)xcd * per_xcd + li_next < nblk;
+  const bool skip_tile = a.lower_only && n0 > m0 + BM - 1;  // (lower_only launches are never persistent)
+
   f32x16 acc[TN][TM];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -155,54 +181,75 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // fragment read offsets: row = tile_row0 + l31 (tile_row0 % 32 == 0), slot = (2g + h) ^ ((l31 >> 1) & 7)
-  const int sw = (l31 >> 1) & 7;
-  int rd_off[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) rd_off[g] = l31 * ROWB + (((2 * g + h) ^ sw) << 4);
-
-  const int nk = (a.K + BKE - 1) / BKE;
-  ROMA_ISSUE_SLAB(0, 0);
-  // One barrier per slab: [slab kt landed] -> barrier -> all fragments of slab kt to registers -> DMA of slab kt+1
-  // into the other buffer (every wave has finished reading it before it passed this iteration's barrier) -> MFMAs
-  // of slab kt run under that DMA.  (hipcc drains vmcnt before any ds_read that may alias an LDS-DMA target, so
-  // the DMA is issued after the fragment reads rather than before them.)
+  // One barrier per slab: [slab kt landed] -> barrier -> DMA of slab kt+1 (or of the next tile's slab 0) into the
+  // other buffer, which every wave finished reading before it passed this barrier -> fragments + MFMAs of slab kt
+  // under that DMA.  The fragment reads are inline asm: hipcc drains the DMA queue (vmcnt(0)) before any ds_read
+  // it can see (the read may alias an LDS-DMA target), which would serialise DMA and math; hidden reads also let
+  // the fragments be fetched per k-group (2 x (TM+TN) registers, double buffered with counted lgkmcnt) instead of
+  // holding the whole slab - the registers that the cross-tile prefetch state needs.
+#define ROMA_READ_G(WV, AV, G)                                                                              \
+  {                                                                                                         \
+    const unsigned wa_ = sb + woff + rd_off[G], aa_ = sb + aoff + rd_off[G];                                \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn)                                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(WV[tn]) : "v"(wa_), "n"(tn * 32 * ROWB));       \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(AV[tm]) : "v"(aa_), "n"(tm * 32 * ROWB));       \
+  }
+#define ROMA_MFMA_G(WV, AV)                                                                                 \
+  _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) {     \
+    if constexpr (sizeof(TIN) == 4) {                                                                       \
+      acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(WV[tn].x), __uint_as_float(AV[tm].x), acc[tn][tm], 0, 0, 0); \
+      acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(WV[tn].y), __uint_as_float(AV[tm].y), acc[tn][tm], 0, 0, 0); \
+      acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(WV[tn].z), __uint_as_float(AV[tm].z), acc[tn][tm], 0, 0, 0); \
+      acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(WV[tn].w), __uint_as_float(AV[tm].w), acc[tn][tm], 0, 0, 0); \
+    } else {                                                                                                \
+      acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, WV[tn]),           \
+                                                            __builtin_bit_cast(bf16x8_t, AV[tm]), acc[tn][tm], 0, 0, 0); \
+    }                                                                                                       \
+  }
+#define ROMA_WAIT_LGKM(N)                                  \
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); \
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  const unsigned aoff = (wm * TM) * 32 * ROWB, woff = BM * ROWB + (wn * TN) * 32 * ROWB;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
+    const int cur = (bsel + kt) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const char* As = smem + cur * BUF;
-    const char* Ws = As + BM * ROWB;
-    uint4 wv[4][TN], av[4][TM];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-        wv[g][tn] = *reinterpret_cast<const uint4*>(Ws + (wn * TN + tn) * 32 * ROWB + rd_off[g]);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-        av[g][tm] = *reinterpret_cast<const uint4*>(As + (wm * TM + tm) * 32 * ROWB + rd_off[g]);
+    if (kt + 1 < nk) {
+      ROMA_ISSUE_SLAB(kt + 1, cur ^ 1);
+    } else if (has_next) {
+      ROMA_TILE_SETUP((long)xcd * per_xcd + li_next);
+      ROMA_ISSUE_SLAB(0, cur ^ 1);
     }
-    if (kt + 1 < nk) ROMA_ISSUE_SLAB(kt + 1, cur ^ 1);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          if constexpr (sizeof(TIN) == 4) {
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[g][tn].x), __uint_as_float(av[g][tm].x), acc[tn][tm], 0, 0, 0);
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[g][tn].y), __uint_as_float(av[g][tm].y), acc[tn][tm], 0, 0, 0);
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[g][tn].z), __uint_as_float(av[g][tm].z), acc[tn][tm], 0, 0, 0);
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[g][tn].w), __uint_as_float(av[g][tm].w), acc[tn][tm], 0, 0, 0);
-          } else {
-            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wv[g][tn]),
-                                                                  __builtin_bit_cast(bf16x8_t, av[g][tm]), acc[tn][tm], 0, 0, 0);
-          }
-        }
-    }
+    if (skip_tile) continue;
+    const unsigned sb = lds0 + cur * BUF;
+    uint4 wvA[TN], avA[TM], wvB[TN], avB[TM];
+    ROMA_READ_G(wvA, avA, 0);
+    ROMA_READ_G(wvB, avB, 1);
+    ROMA_WAIT_LGKM(TN + TM);
+    ROMA_MFMA_G(wvA, avA);
+    __builtin_amdgcn_sched_barrier(0);
+    ROMA_READ_G(wvA, avA, 2);
+    ROMA_WAIT_LGKM(TN + TM);
+    ROMA_MFMA_G(wvB, avB);
+    __builtin_amdgcn_sched_barrier(0);
+    ROMA_READ_G(wvB, avB, 3);
+    ROMA_WAIT_LGKM(TN + TM);
+    ROMA_MFMA_G(wvA, avA);
+    ROMA_WAIT_LGKM(0);
+    ROMA_MFMA_G(wvB, avB);
+    __builtin_amdgcn_sched_barrier(0);
   }
-#undef ROMA_ISSUE_SLAB
+#undef ROMA_WAIT_LGKM
+#undef ROMA_MFMA_G
+#undef ROMA_READ_G
+  bsel = (bsel + nk) & 1;
+  li = li_next;
+  if (skip_tile) {
+    if (!has_next) break;
+    continue;
+  }
 
   // ---------------------------------------------------------------- epilogue
   TOUT* Cb = reinterpret_cast<TOUT*>(a.C) + (long)bz * a.sC;
@@ -214,18 +261,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs a) {
     // bf16 output, plain epilogue: the MFMA layout gives each lane 4 consecutive n of ONE row, i.e. a wave store
     // would scatter 8-byte pieces over 32 rows (measured 0.56 TB/s).  Stage the wave's tile through its private
     // LDS slice instead and write whole rows: 16 B per lane, 128..384 contiguous bytes per row.
-    constexpr int RS = TN * 64 + 16;  // LDS row stride in bytes (16-byte aligned; the pad staggers the banks)
+    constexpr int RB = TN * 64;    // staged row: TN*32 bf16
+    constexpr int CPR = TN * 4;    // 16-byte chunks per row
+    constexpr int SWM = ((CPR & (CPR - 1)) == 0) ? CPR - 1 : 0;  // XOR swizzle of the chunk index (power-of-two rows)
     if (a.mode == EPI_STD && Rb == nullptr && (a.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0) {
-      __builtin_amdgcn_s_barrier();  // every wave is done with the operand buffers
-      char* ws = smem + wave * (TM * 32 * RS);
+      char* ws = smem + 2 * BUF + wave * (32 * RB);  // wave-private: LDS ops of one wave complete in order
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
+      for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
-            const int nl = tn * 32 + 8 * rg + 4 * h;  // local column
-            const int n = n0 + wn * TN * 32 + nl;
+            const int n = n0 + wn * TN * 32 + tn * 32 + 8 * rg + 4 * h;
             f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = a.alpha * acc[tn][tm][4 * rg + j];
@@ -250,29 +297,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs a) {
             uint2 pk;
             pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
             pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-            *reinterpret_cast<uint2*>(ws + (tm * 32 + l31) * RS + nl * 2) = pk;
+            const int ch = tn * 4 + rg;
+            *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ (l31 & SWM)) << 4) + 8 * h) = pk;
           }
-      // the slice is wave-private: LDS ops of one wave complete in order, no barrier needed
-      constexpr int CPR = TN * 4;  // 16-byte chunks per row
-      const long mw = m0 + wm * TM * 32;
-      const int nw0 = n0 + wn * TN * 32;
-#pragma unroll 4
-      for (int c = lane; c < TM * 32 * CPR; c += 64) {
-        const int row = c / CPR, ch = c - row * CPR;
-        const long m = mw + row;
-        const int n = nw0 + ch * 8;
-        if (m >= a.M || n >= a.N) continue;
-        const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RS + ch * 16);
-        bf16_t* dst = reinterpret_cast<bf16_t*>(Cb) + m * a.ldc + n;
-        if (n + 8 <= a.N) {
-          *reinterpret_cast<uint4*>(dst) = v;
-        } else {
-          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
-          for (int j = 0; j < 8; ++j)
-            if (n + j < a.N) dst[j] = e[j];
+        const long mw = m0 + (wm * TM + tm) * 32;
+        const int nw0 = n0 + wn * TN * 32;
+#pragma unroll
+        for (int c = lane; c < 32 * CPR; c += 64) {
+          const int row = c / CPR, ch = c - row * CPR;
+          const long m = mw + row;
+          const int n = nw0 + ch * 8;
+          const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ (row & SWM)) << 4));
+          if (m >= a.M || n >= a.N || (a.dbg & 1)) continue;
+          bf16_t* dst = reinterpret_cast<bf16_t*>(Cb) + m * a.ldc + n;
+          if (n + 8 <= a.N) {
+            *reinterpret_cast<uint4*>(dst) = v;
+          } else {
+            const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+            for (int j = 0; j < 8; ++j)
+              if (n + j < a.N) dst[j] = e[j];
+          }
         }
       }
-      return;
+      if (!has_next) break;
+      continue;  // next tile
     }
   }
 
@@ -369,15 +417,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs a) {
       }
     }
   }
+  if (!has_next) break;
+  }  // tile loop
+#undef ROMA_ISSUE_SLAB
+#undef ROMA_TILE_SETUP
 }
 
 template <typename TIN, typename TOUT, int WM, int WN, int TM, int TN, bool CONV>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const long nblk = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  dim3 grid((unsigned)(((nblk + 7) / 8) * 8), 1, (unsigned)a.batch);
   size_t lds = (size_t)2 * (BM + BN) * ROWB;
-  if (sizeof(TOUT) == 2) lds = std::max(lds, (size_t)WM * WN * TM * 32 * (TN * 64 + 16));  // bf16 epilogue staging
+  if (sizeof(TOUT) == 2) lds += (size_t)WM * WN * 32 * TN * 64;  // bf16 epilogue staging slices (one per wave)
+  // persistent grid: the co-resident workgroups (256 CUs x LDS-limited occupancy), a multiple of the 8 XCDs;
+  // lower_only (skipped tiles) and batched launches keep one tile per workgroup
+  long gx = ((nblk + 7) / 8) * 8;
+  if (!a.lower_only && a.batch == 1) {
+    const long occ = std::max<long>(1, std::min<long>(8, (160 * 1024) / (long)lds));
+    gx = std::min<long>(gx, 256 * occ);
+  }
+  dim3 grid((unsigned)gx, 1, (unsigned)a.batch);
   char pname[96];
   snprintf(pname, sizeof pname, "gemm_kernel<%s,%s,%d,%d,%d,%d,%s>", sizeof(TIN) == 4 ? "f32" : "bf16",
            sizeof(TOUT) == 4 ? "f32" : "bf16", WM, WN, TM, TN, CONV ? "conv3x3" : "dense");
@@ -417,7 +476,10 @@ static int launch_shape(const GemmArgs& a, hipStream_t stream) {
   return launch_cfg<TIN, TOUT, 2, 2, 2, 2, CONV>(a, stream);                      // 128 x 128
 }
 
-int gemm_launch(const GemmArgs& a, hipStream_t stream) {
+int gemm_launch(const GemmArgs& a0, hipStream_t stream) {
+  GemmArgs a = a0;
+  static const int dbg_env = getenv("ROMA_GEMM_DBG") ? atoi(getenv("ROMA_GEMM_DBG")) : 0;
+  a.dbg = dbg_env;
   const int ce = a.in_dt == DT_F32 ? 4 : 8;
   ROMA_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "gemm: empty problem");
   ROMA_REQUIRE(a.K % ce == 0, "gemm: K must be a multiple of the 16-byte chunk");

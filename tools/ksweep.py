@@ -1,0 +1,5 @@
+import sys, os
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
+import bench_gemm as bg
+for K in (64, 1024, 4096):
+    bg.run(65536, 1024, K, 1, 1)
