@@ -216,30 +216,57 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
     const int cur = (bsel + kt) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) {
-      ROMA_ISSUE_SLAB(kt + 1, cur ^ 1);
-    } else if (has_next) {
-      ROMA_TILE_SETUP((long)xcd * per_xcd + li_next);
-      ROMA_ISSUE_SLAB(0, cur ^ 1);
+    if constexpr (NWAVES == 8) {
+      // large MFMA-bound tiles: DMA first, fragments per k-group from inline asm (see above)
+      if (kt + 1 < nk) {
+        ROMA_ISSUE_SLAB(kt + 1, cur ^ 1);
+      } else if (has_next) {
+        ROMA_TILE_SETUP((long)xcd * per_xcd + li_next);
+        ROMA_ISSUE_SLAB(0, cur ^ 1);
+      }
+      if (skip_tile) continue;
+      const unsigned sb = lds0 + cur * BUF;
+      uint4 wvA[TN], avA[TM], wvB[TN], avB[TM];
+      ROMA_READ_G(wvA, avA, 0);
+      ROMA_READ_G(wvB, avB, 1);
+      ROMA_WAIT_LGKM(TN + TM);
+      ROMA_MFMA_G(wvA, avA);
+      __builtin_amdgcn_sched_barrier(0);
+      ROMA_READ_G(wvA, avA, 2);
+      ROMA_WAIT_LGKM(TN + TM);
+      ROMA_MFMA_G(wvB, avB);
+      __builtin_amdgcn_sched_barrier(0);
+      ROMA_READ_G(wvB, avB, 3);
+      ROMA_WAIT_LGKM(TN + TM);
+      ROMA_MFMA_G(wvA, avA);
+      ROMA_WAIT_LGKM(0);
+      ROMA_MFMA_G(wvB, avB);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      // small / HBM-bound tiles (4 waves, several workgroups per CU): compiler-scheduled reads of the whole slab,
+      // then the DMA of the next slab (hipcc would drain the DMA queue before a visible ds_read otherwise), then MFMAs
+      const char* As = smem + cur * BUF;
+      const char* Ws = As + BM * ROWB;
+      uint4 wv[4][TN], av[4][TM];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          wv[g][tn] = *reinterpret_cast<const uint4*>(Ws + (wn * TN + tn) * 32 * ROWB + rd_off[g]);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          av[g][tm] = *reinterpret_cast<const uint4*>(As + (wm * TM + tm) * 32 * ROWB + rd_off[g]);
+      }
+      if (kt + 1 < nk) {
+        ROMA_ISSUE_SLAB(kt + 1, cur ^ 1);
+      } else if (has_next) {
+        ROMA_TILE_SETUP((long)xcd * per_xcd + li_next);
+        ROMA_ISSUE_SLAB(0, cur ^ 1);
+      }
+      if (skip_tile) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) ROMA_MFMA_G(wv[g], av[g]);
     }
-    if (skip_tile) continue;
-    const unsigned sb = lds0 + cur * BUF;
-    uint4 wvA[TN], avA[TM], wvB[TN], avB[TM];
-    ROMA_READ_G(wvA, avA, 0);
-    ROMA_READ_G(wvB, avB, 1);
-    ROMA_WAIT_LGKM(TN + TM);
-    ROMA_MFMA_G(wvA, avA);
-    __builtin_amdgcn_sched_barrier(0);
-    ROMA_READ_G(wvA, avA, 2);
-    ROMA_WAIT_LGKM(TN + TM);
-    ROMA_MFMA_G(wvB, avB);
-    __builtin_amdgcn_sched_barrier(0);
-    ROMA_READ_G(wvB, avB, 3);
-    ROMA_WAIT_LGKM(TN + TM);
-    ROMA_MFMA_G(wvA, avA);
-    ROMA_WAIT_LGKM(0);
-    ROMA_MFMA_G(wvB, avB);
-    __builtin_amdgcn_sched_barrier(0);
   }
 #undef ROMA_WAIT_LGKM
 #undef ROMA_MFMA_G
@@ -265,7 +292,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
     constexpr int CPR = TN * 4;    // 16-byte chunks per row
     constexpr int SWM = ((CPR & (CPR - 1)) == 0) ? CPR - 1 : 0;  // XOR swizzle of the chunk index (power-of-two rows)
     if (a.mode == EPI_STD && Rb == nullptr && (a.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0) {
-      char* ws = smem + 2 * BUF + wave * (32 * RB);  // wave-private: LDS ops of one wave complete in order
+      // 8-wave (persistent) tiles stage in their own slice behind the operand buffers (the next tile's first slab is
+      // already being DMA'd into those); 4-wave tiles reuse the operand buffers after a barrier (keeps 2+ WGs per CU)
+      if constexpr (NWAVES != 8) __builtin_amdgcn_s_barrier();
+      char* ws = smem + (NWAVES == 8 ? 2 * BUF : 0) + wave * (32 * RB);  // wave-private: one wave's LDS ops complete in order
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -428,11 +458,16 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const long nblk = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   size_t lds = (size_t)2 * (BM + BN) * ROWB;
-  if (sizeof(TOUT) == 2) lds += (size_t)WM * WN * 32 * TN * 64;  // bf16 epilogue staging slices (one per wave)
+  if (sizeof(TOUT) == 2) {  // bf16 epilogue staging slices (one per wave)
+    const size_t stg = (size_t)WM * WN * 32 * TN * 64;
+    lds = (WM * WN == 8) ? lds + stg : std::max(lds, stg);
+  }
   // persistent grid: the co-resident workgroups (256 CUs x LDS-limited occupancy), a multiple of the 8 XCDs;
   // lower_only (skipped tiles) and batched launches keep one tile per workgroup
   long gx = ((nblk + 7) / 8) * 8;
-  if (!a.lower_only && a.batch == 1) {
+  // (the 4-wave tiles serve the small / HBM-bound problems: several short-lived workgroups per CU overlap their
+  //  store drain with each other better than one persistent workgroup that waits on its own stores)
+  if (!a.lower_only && a.batch == 1 && WM * WN == 8) {
     const long occ = std::max<long>(1, std::min<long>(8, (160 * 1024) / (long)lds));
     gx = std::min<long>(gx, 256 * occ);
   }
