@@ -211,3 +211,35 @@ def test_bf16_mode_statistical(built_lib, weights0):
           f"median|dcert|={ec.median():.3e} max={ec.max():.3e}")
     assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
     assert ew.median() < 5e-3 and ec.median() < 5e-2
+
+
+def test_non_square_and_pil_inputs(built_lib, weights0, tmp_path):
+    """Non-square resolutions (different token grid h != w) and the path / PIL input route (matcher.py:806-816, 853-868)."""
+    from PIL import Image
+    from oracle import roma_oracle as O
+    from roma_amd import roma_model, synthetic
+    from roma_amd.matcher import _pil_to_normalised
+    sd, dsd = weights0
+    m = roma_model((112, 168), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=torch.float32,
+                   symmetric=True, upsample_res=(160, 240), max_batch=1)
+    inp = synthetic.make_inputs(1, (112, 168), (160, 240), seed=5)
+    d = _to_dev(inp)
+    warp, cert = m.match(d["im_A"], d["im_B"], im_A_high_res=d["im_A_high_res"], im_B_high_res=d["im_B_high_res"])
+    w_ref, c_ref = O.match(inp["im_A"], inp["im_B"], sd, dsd, inp["im_A_high_res"], inp["im_B_high_res"])
+    assert warp.shape == (1, 160, 480, 4)
+    assert (warp.cpu() - w_ref).abs().max() < TOL and (cert.cpu() - c_ref).abs().max() < TOL
+    # PIL / path inputs: B = 1, bicubic resize + ImageNet normalisation on the host
+    g = np.random.Generator(np.random.PCG64(3))
+    ims = [Image.fromarray(g.integers(0, 255, size=(90, 130, 3), dtype=np.uint8), "RGB") for _ in range(2)]
+    pa, pb = str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    ims[0].save(pa)
+    ims[1].save(pb)
+    w1, c1 = m.match(ims[0], ims[1])
+    w2, c2 = m.match(pa, pb)
+    assert torch.equal(w1, w2) and torch.equal(c1, c2)
+    a, b = _pil_to_normalised(ims[0], (112, 168))[None], _pil_to_normalised(ims[1], (112, 168))[None]
+    ah, bh = _pil_to_normalised(ims[0], (160, 240))[None], _pil_to_normalised(ims[1], (160, 240))[None]
+    w_ref, c_ref = O.match(a, b, sd, dsd, ah, bh)
+    assert (w1.cpu() - w_ref).abs().max() < TOL and (c1.cpu() - c_ref).abs().max() < TOL
+    with pytest.raises(NotImplementedError):  # utils.py:659-661
+        m.match(ims[0].convert("L"), ims[1])
