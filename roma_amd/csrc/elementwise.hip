@@ -674,10 +674,31 @@ __global__ __launch_bounds__(256, 2) void dwconv5x5_kernel(const T* in, T* out, 
   const int cg = threadIdx.x % GC, xq = threadIdx.x / GC;
   const int c0 = chunk * GC * 4;
   constexpr int cw = 256;  // fixed LDS row stride: weight reads become base + immediate offset
-  for (int i = threadIdx.x; i < 26 * cw; i += 256) {  // (columns >= GC*4 are never read)
-    const int t = i / cw, cc = i - t * cw;
-    const int ch = c0 + cc;
-    wsm[i] = ch < Cp ? (t < 25 ? w[(long)t * Cp + ch] : bias[ch]) : 0.f;
+  // stage this chunk's 25 x (GC*4) weights + bias as float4s; all loads are issued before the first LDS write
+  // (a dword-at-a-time loop serialised 26 dependent global loads = ~40 us per workgroup)
+  {
+    const int q4 = GC;                   // float4 columns actually used per row
+    const int nvec = 26 * q4;            // <= 26 * 64
+    f32x4 tmp[7];
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+      const int i = threadIdx.x + 256 * it;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < nvec) {
+        const int t = i / q4, cq = i - t * q4;
+        const int ch = c0 + cq * 4;
+        if (ch < Cp) v = *reinterpret_cast<const f32x4*>(t < 25 ? w + (long)t * Cp + ch : bias + ch);
+      }
+      tmp[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+      const int i = threadIdx.x + 256 * it;
+      if (i < nvec) {
+        const int t = i / q4, cq = i - t * q4;
+        *reinterpret_cast<f32x4*>(&wsm[t * cw + cq * 4]) = tmp[it];
+      }
+    }
   }
   __syncthreads();
   const int c = c0 + cg * 4;
