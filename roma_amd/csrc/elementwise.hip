@@ -341,52 +341,49 @@ int transpose_launch(const float* in, float* out, int n, long ld, int batch, hip
 }
 
 // ------------------------------------------------------------------ 64x64 Cholesky + triangular inverse
-__global__ __launch_bounds__(256) void chol_diag_kernel(float* A, long ld, long strideA, float* Linv, float* LinvT,
-                                                        int k, int nblk) {
+// ONE wave64 per diagonal block: lane i owns row i of the factor (and later column i of the inverse) in LDS.
+// A single wave needs no barriers (its LDS operations complete in order), pivots / multipliers are LDS broadcast
+// reads, rows are stride-65 so lane-parallel accesses are conflict free.  The previous 256-thread version spent
+// 127 us per call on 192 __syncthreads(); the blocked Cholesky issues 25 such calls on the GP's critical path.
+// (A fully unrolled register/readlane variant was correct but ~70 KB of straight-line code: instruction-fetch bound.)
+__global__ __launch_bounds__(64) void chol_diag_kernel(float* A, long ld, long strideA, float* Linv, float* LinvT,
+                                                       int k, int nblk) {
   __shared__ float L[64][65];
   __shared__ float X[64][65];
   float* Ab = A + (long)blockIdx.x * strideA + ((long)k * 64) * ld + (long)k * 64;
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < 64 * 64; idx += 256) L[idx >> 6][idx & 63] = Ab[(long)(idx >> 6) * ld + (idx & 63)];
-  __syncthreads();
+  const int i = threadIdx.x;
+  for (int idx = i; idx < 64 * 16; idx += 64) {  // coalesced float4 loads
+    const int row = idx >> 4, c4 = idx & 15;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(Ab + (long)row * ld + c4 * 4);
+    L[row][c4 * 4 + 0] = v[0]; L[row][c4 * 4 + 1] = v[1]; L[row][c4 * 4 + 2] = v[2]; L[row][c4 * 4 + 3] = v[3];
+  }
   for (int j = 0; j < 64; ++j) {
-    if (tid == 0) L[j][j] = sqrtf(L[j][j]);
-    __syncthreads();
-    const float dj = L[j][j];
-    if (tid > j && tid < 64) L[tid][j] /= dj;
-    __syncthreads();
-    // trailing update of the lower triangle: L[i][c] -= L[i][j] * L[c][j], c in (j, i]
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-      const int i = idx >> 6, c = idx & 63;
-      if (c > j && i >= c) L[i][c] -= L[i][j] * L[c][j];
-    }
-    __syncthreads();
+    const float d = sqrtf(L[j][j]);
+    const float lij = (i == j) ? d : L[i][j] / d;
+    L[i][j] = lij;  // rows < j: harmless garbage in the strictly upper part
+    for (int c = j + 1; c < 64; ++c) L[i][c] -= lij * L[c][j];  // a_ic -= l_ij * l_cj  (L[c][j] is a broadcast read)
   }
-  // inverse of the lower-triangular factor: column c by forward substitution
-  if (tid < 64) {
-    const int c = tid;
-    for (int i = 0; i < c; ++i) X[i][c] = 0.f;
-    X[c][c] = 1.0f / L[c][c];
-    for (int i = c + 1; i < 64; ++i) {
-      float sacc = 0.f;
-      for (int t = c; t < i; ++t) sacc = fmaf(L[i][t], X[t][c], sacc);
-      X[i][c] = -sacc / L[i][i];
-    }
+  // inverse: lane c solves L x = e_c by forward substitution, x kept in X[.][c]
+  const int c = i;
+  for (int r = 0; r < 64; ++r) {
+    float sacc = (r == c) ? 1.f : 0.f;
+    for (int t = 0; t < r; ++t) sacc -= L[r][t] * X[t][c];
+    X[r][c] = sacc / L[r][r];
   }
-  __syncthreads();
   float* Li = Linv + ((long)blockIdx.x * nblk + k) * 4096;
   float* LiT = LinvT + ((long)blockIdx.x * nblk + k) * 4096;
-  for (int idx = tid; idx < 64 * 64; idx += 256) {
-    const int i = idx >> 6, c = idx & 63;
-    Ab[(long)i * ld + c] = (c <= i) ? L[i][c] : 0.f;
-    Li[idx] = X[i][c];
-    LiT[idx] = X[c][i];
+  for (int idx = i; idx < 64 * 64; idx += 64) {
+    const int row = idx >> 6, col = idx & 63;
+    Ab[(long)row * ld + col] = (col <= row) ? L[row][col] : 0.f;
+    const float xv = (col <= row) ? X[row][col] : 0.f;
+    Li[idx] = xv;                 // Linv[row][col]
+    LiT[col * 64 + row] = xv;     // LinvT[col][row]
   }
 }
 
 int chol_diag_launch(float* A, long ld, long strideA, float* Linv, float* LinvT, int k, int nblk, int batch,
                      hipStream_t s) {
-  hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)batch), dim3(256), 0, s, A, ld, strideA, Linv, LinvT, k, nblk);
+  hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)batch), dim3(64), 0, s, A, ld, strideA, Linv, LinvT, k, nblk);
   ROMA_LAUNCH_CHECK();
   return 0;
 }
@@ -565,8 +562,75 @@ __global__ __launch_bounds__(256) void refiner_input_small_kernel(const RefinerI
   }
 }
 
+// stride-1 refiner (C = 9, E = 6, 24 output channels): one thread per pixel, whole rows as 16-byte vectors
+template <typename T, int C, int E>
+__global__ __launch_bounds__(256) void refiner_input_pix_kernel(const RefinerInputArgs a) {
+  constexpr int LDF = 16, LDD = 24;
+  const long HW = (long)a.H * a.W;
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= (long)a.B * HW) return;
+  const int b = (int)(pix / HW);
+  const long p = pix - (long)b * HW;
+  const int y = (int)(p / a.W), x = (int)(p - (long)y * a.W);
+  const T* feat = reinterpret_cast<const T*>(a.feat);
+  const T* fq = feat + ((long)b * HW + p) * LDF;
+  const int simg = (b + a.shift) % a.nimg;
+  const T* fs = feat + (long)simg * HW * LDF;
+  float q[12], xh[12];
+#pragma unroll
+  for (int c4 = 0; c4 < 3; ++c4) {
+    const f32x4 v = ElemIO<T>::ld4(fq + c4 * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      q[c4 * 4 + j] = v[j];
+      xh[c4 * 4 + j] = 0.f;
+    }
+  }
+  const float wx = a.flow[pix * 2 + 0], wy = a.flow[pix * 2 + 1];
+  float ix = ((wx + 1.f) * a.W - 1.f) * 0.5f, iy = ((wy + 1.f) * a.H - 1.f) * 0.5f;
+  ix = fminf(fmaxf(ix, -1.0e6f), 1.0e6f);
+  iy = fminf(fmaxf(iy, -1.0e6f), 1.0e6f);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float tx = ix - fx0, ty = iy - fy0;
+  const float wgt[4] = {(1.f - tx) * (1.f - ty), tx * (1.f - ty), (1.f - tx) * ty, tx * ty};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
+    if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+      const T* r = fs + ((long)yy * a.W + xx) * LDF;
+#pragma unroll
+      for (int c4 = 0; c4 < 3; ++c4) {
+        const f32x4 v = ElemIO<T>::ld4(r + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xh[c4 * 4 + j] += wgt[t] * v[j];
+      }
+    }
+  }
+  const float dx = a.disp_scale * (wx - pix_coord(x, a.W)), dy = a.disp_scale * (wy - pix_coord(y, a.H));
+  float o[LDD];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    o[c] = q[c];
+    o[C + c] = xh[c];
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) o[2 * C + e] = a.emb_w[e * 2 + 0] * dx + a.emb_w[e * 2 + 1] * dy + a.emb_b[e];
+#pragma unroll
+  for (int c = 2 * C + E; c < LDD; ++c) o[c] = 0.f;
+  T* d = reinterpret_cast<T*>(a.d) + pix * LDD;
+#pragma unroll
+  for (int c4 = 0; c4 < LDD / 4; ++c4) ElemIO<T>::st4(d + c4 * 4, f32x4{o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3]});
+}
+
 int refiner_input_launch(const RefinerInputArgs& a, hipStream_t s) {
   const long npix = (long)a.B * a.H * a.W;
+  if (a.C == 9 && a.E == 6 && a.Kcorr == 0 && a.ldf == 16 && a.ldd == 24) {
+    dim3 grid((unsigned)((npix + 255) / 256));
+    ROMA_DT_SWITCH(a.dt, T, hipLaunchKernelGGL((refiner_input_pix_kernel<T, 9, 6>), grid, dim3(256), 0, s, a));
+    ROMA_LAUNCH_CHECK();
+    return 0;
+  }
   if (a.C % 4 != 0 || a.C < 32) {
     const long total = npix * a.ldd;
     dim3 grid((unsigned)std::min<long>((total + 255) / 256, 1 << 20));
