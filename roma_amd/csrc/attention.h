@@ -14,6 +14,7 @@ struct AttnArgs {
   int B = 0, heads = 0, N = 0, npad = 0, hd = 0;
   long ldo = 0;
   int in_dt = 0, out_dt = 0;  // DT_F32 / DT_BF16
+  int exp2_domain = 0;        // bf16 kernel: q was pre-scaled by log2(e)/sqrt(hd), softmax uses v_exp_f32 (2^x) directly
 };
 int attention_launch(const AttnArgs& a, hipStream_t stream);
 }  // namespace roma

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a) {
 }
 
 // bf16 inputs, f32 softmax/accumulate; v_mfma_f32_32x32x16_bf16.
-template <int HD, typename TOUT>
+template <int HD, typename TOUT, bool EXP2>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
   constexpr int KV = 64;
   constexpr int KS = HD + 8, VS = KV + 8;  // bf16 elements per LDS row
@@ -180,25 +180,29 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
                                                         __builtin_bit_cast(bf16x8_t, qf[st]), s[kt], 0, 0, 0);
       }
     }
+    if (kv0 + KV > a.N) {  // only the last tile has keys >= N to mask (uniform branch)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (key >= a.N) s[kt][r] = -INFINITY;
+        }
+    }
     float tmax = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float sv = key < a.N ? s[kt][r] : -INFINITY;
-        s[kt][r] = sv;
-        tmax = fmaxf(tmax, sv);
-      }
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kt][r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = EXP2 ? __builtin_amdgcn_exp2f(m_run - m_new) : __expf(m_run - m_new);
     float lsum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __expf(s[kt][r] - m_new);
+        const float p = EXP2 ? __builtin_amdgcn_exp2f(s[kt][r] - m_new) : __expf(s[kt][r] - m_new);
         s[kt][r] = p;
         lsum += p;
       }
@@ -213,10 +217,10 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         uint4 pk;
-        pk.x = (uint32_t)f32_to_bf16(s[kt][8 * u + 0]) | ((uint32_t)f32_to_bf16(s[kt][8 * u + 1]) << 16);
-        pk.y = (uint32_t)f32_to_bf16(s[kt][8 * u + 2]) | ((uint32_t)f32_to_bf16(s[kt][8 * u + 3]) << 16);
-        pk.z = (uint32_t)f32_to_bf16(s[kt][8 * u + 4]) | ((uint32_t)f32_to_bf16(s[kt][8 * u + 5]) << 16);
-        pk.w = (uint32_t)f32_to_bf16(s[kt][8 * u + 6]) | ((uint32_t)f32_to_bf16(s[kt][8 * u + 7]) << 16);
+        pk.x = pack_bf16x2(s[kt][8 * u + 0], s[kt][8 * u + 1]);
+        pk.y = pack_bf16x2(s[kt][8 * u + 2], s[kt][8 * u + 3]);
+        pk.z = pack_bf16x2(s[kt][8 * u + 4], s[kt][8 * u + 5]);
+        pk.w = pack_bf16x2(s[kt][8 * u + 6], s[kt][8 * u + 7]);
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
           const bf16_t* vrow = &Vs[(32 * d + l31) * VS + 32 * kt + 16 * u + 4 * h];
@@ -254,14 +258,20 @@ int attention_launch(const AttnArgs& a, hipStream_t stream) {
   snprintf(pname, sizeof pname, "attn_%s_kernel<%d>", a.in_dt == DT_F32 ? "f32" : "bf16", a.hd);
   ProfScope ps(pname, 4.0 * (double)a.B * a.heads * (double)a.N * a.N * a.hd, "flop", stream);
 #define ROMA_ATTN(KERNEL, HDV, TOUT) hipLaunchKernelGGL((KERNEL<HDV, TOUT>), grid, dim3(256), 0, stream, a)
+#define ROMA_ATTNB(HDV, TOUT)                                                                         \
+  {                                                                                                   \
+    if (a.exp2_domain) hipLaunchKernelGGL((attn_bf16_kernel<HDV, TOUT, true>), grid, dim3(256), 0, stream, a);  \
+    else hipLaunchKernelGGL((attn_bf16_kernel<HDV, TOUT, false>), grid, dim3(256), 0, stream, a);     \
+  }
   if (a.in_dt == DT_F32) {
     if (a.hd == 64) { if (a.out_dt == DT_F32) ROMA_ATTN(attn_f32_kernel, 64, float); else ROMA_ATTN(attn_f32_kernel, 64, bf16_t); }
     else            { if (a.out_dt == DT_F32) ROMA_ATTN(attn_f32_kernel, 128, float); else ROMA_ATTN(attn_f32_kernel, 128, bf16_t); }
   } else {
-    if (a.hd == 64) { if (a.out_dt == DT_F32) ROMA_ATTN(attn_bf16_kernel, 64, float); else ROMA_ATTN(attn_bf16_kernel, 64, bf16_t); }
-    else            { if (a.out_dt == DT_F32) ROMA_ATTN(attn_bf16_kernel, 128, float); else ROMA_ATTN(attn_bf16_kernel, 128, bf16_t); }
+    if (a.hd == 64) { if (a.out_dt == DT_F32) ROMA_ATTNB(64, float) else ROMA_ATTNB(64, bf16_t) }
+    else            { if (a.out_dt == DT_F32) ROMA_ATTNB(128, float) else ROMA_ATTNB(128, bf16_t) }
   }
 #undef ROMA_ATTN
+#undef ROMA_ATTNB
   ROMA_LAUNCH_CHECK();
   return 0;
 }

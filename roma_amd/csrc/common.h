@@ -46,6 +46,18 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
   return (bf16_t)((x.u + r) >> 16);
 }
 
+// two f32 -> packed bf16x2 (round-to-nearest-even) in ONE instruction: gfx950's v_cvt_pk_bf16_f32 (no builtin;
+// the software rounding costs ~6 VALU ops per element and made the attention softmax / GEMM epilogues VALU-bound)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+#else
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+#endif
+}
+
 template <typename T> struct ElemIO;
 template <> struct ElemIO<float> {
   __device__ static inline float ld(const float* p) { return *p; }
@@ -67,8 +79,8 @@ template <> struct ElemIO<bf16_t> {
   }
   __device__ static inline void st4(bf16_t* p, f32x4 v) {
     uint2 u;
-    u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    u.x = pack_bf16x2(v[0], v[1]);
+    u.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = u;
   }
 };

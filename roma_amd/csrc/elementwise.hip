@@ -670,10 +670,10 @@ template <> struct VecIO<bf16_t> {
   }
   __device__ static inline void st(bf16_t* p, const float* v) {
     uint4 u;
-    u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-    u.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-    u.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    u.x = pack_bf16x2(v[0], v[1]);
+    u.y = pack_bf16x2(v[2], v[3]);
+    u.z = pack_bf16x2(v[4], v[5]);
+    u.w = pack_bf16x2(v[6], v[7]);
     *reinterpret_cast<uint4*>(p) = u;
   }
 };
@@ -712,8 +712,8 @@ template <> struct RawVec<bf16_t> {
   }
   __device__ static inline void st(bf16_t* p, f32x2 a, f32x2 b) {
     uint2 u;
-    u.x = (uint32_t)f32_to_bf16(a[0]) | ((uint32_t)f32_to_bf16(a[1]) << 16);
-    u.y = (uint32_t)f32_to_bf16(b[0]) | ((uint32_t)f32_to_bf16(b[1]) << 16);
+    u.x = pack_bf16x2(a[0], a[1]);
+    u.y = pack_bf16x2(b[0], b[1]);
     *reinterpret_cast<uint2*>(p) = u;
   }
 };

@@ -325,8 +325,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
                 if (n + j < a.N) v[j] *= a.scale[n + j];
             }
             uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            pk.x = pack_bf16x2(v[0], v[1]);
+            pk.y = pack_bf16x2(v[2], v[3]);
             const int ch = tn * 4 + rg;
             *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ (l31 & SWM)) << 4) + 8 * h) = pk;
           }

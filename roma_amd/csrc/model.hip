@@ -551,13 +551,14 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       g.A = ln; g.lda = 1024; g.W = w.qkv.w; g.ldw = w.qkv.ldw; g.M = (int)rows; g.N = 3072; g.K = 1024;
       g.in_dt = act_dt; g.out_dt = act_dt; g.bias = w.qkv.b; g.mode = EPI_QKV;
       g.q = qbuf; g.k = kbuf; g.vt = vtbuf; g.heads = heads; g.hd = hd; g.ntok = N; g.npad = npad;
-      g.qscale = 1.0f / sqrtf((float)hd);
+      // bf16 mode: fold log2(e) into the query scale so the softmax is a bare v_exp_f32 (2^x) per element
+      g.qscale = (act_dt == DT_BF16 ? 1.4426950408889634f : 1.0f) / sqrtf((float)hd);
       RUN(gemm_launch(g, st));
     }
     {
       AttnArgs a;
       a.q = qbuf; a.k = kbuf; a.vt = vtbuf; a.out = ao; a.B = Bn; a.heads = heads; a.N = N; a.npad = npad; a.hd = hd;
-      a.ldo = 1024; a.in_dt = act_dt; a.out_dt = act_dt;
+      a.ldo = 1024; a.in_dt = act_dt; a.out_dt = act_dt; a.exp2_domain = act_dt == DT_BF16 ? 1 : 0;
       RUN(attention_launch(a, st));
     }
     {
