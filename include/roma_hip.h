@@ -47,7 +47,8 @@ int roma_create(const roma_config_t* cfg, roma_handle_t* out);
 int roma_set_tensor(roma_handle_t h, const char* name, int ndim, const int64_t* shape, const void* data, int is_int64);
 /* strict key/shape check (as load_state_dict strict=True), BN folding, repacking, upload. */
 int roma_finalize(roma_handle_t h);
-/* mutable attributes of RegressionMatcher (README.md:82-90): "symmetric", "upsample_preds", "attenuate_cert", "debug" */
+/* mutable attributes of RegressionMatcher (README.md:82-90): "symmetric", "upsample_preds", "attenuate_cert", "debug";
+ * tuning: "fuse_refiner_blocks" (default 1; 0 = separate dwconv + GEMM kernels at every scale) */
 int roma_set_option(roma_handle_t h, const char* key, int value);
 /* im_*: [B,3,H,W] float32 normalised images (already on the device). *_hr may be NULL when
  * upsample_preds == 0.  warp_out: [B,Ho,2*Wo,4] (symmetric) or [B,Ho,Wo,4]; cert_out: [B,Ho,2*Wo] / [B,Ho,Wo]. */
@@ -97,6 +98,10 @@ int roma_op_resize_bilinear(const float* in, float* out, int B, int Hin, int Win
                             void* stream);
 int roma_op_dwconv5x5(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp, int dt,
                       void* stream);
+/* One fused ConvRefiner block (matcher.py:88-117 create_block): out = conv1x1(relu(bn(dwconv5x5(in)))), BN folded into
+ * dw_w/dw_b.  bf16 only, Cp in {24, 144}; in/out [B,H,W,Cp] must not alias; pw bf16 [Cp][Cp], pw_b f32 [Cp]. */
+int roma_op_refiner_block(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw,
+                          const float* pw_b, int B, int H, int W, int Cp, int dt, void* stream);
 int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream);
 int roma_op_conv3x3_c3(const float* img, const float* w, const float* bias, void* out, int B, int H, int W, int dt_out,
                        void* stream);

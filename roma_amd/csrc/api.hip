@@ -10,6 +10,7 @@
 #include "gemm.h"
 #include "local_corr.h"
 #include "model.h"
+#include "refiner_block.h"
 
 namespace roma {
 static thread_local std::string g_err;
@@ -83,6 +84,7 @@ int roma_set_option(roma_handle_t h, const char* key, int value) {
     h->m.cfg.upsample_preds = value ? 1 : 0;
   } else if (k == "attenuate_cert") h->m.cfg.attenuate_cert = value ? 1 : 0;
   else if (k == "debug") h->m.debug = value != 0;
+  else if (k == "fuse_refiner_blocks") h->m.fuse_refiner_blocks = value != 0;
   else {
     set_error("roma_set_option: unknown key " + k);
     return ROMA_ERR_ARG;
@@ -227,6 +229,11 @@ int roma_op_resize_bilinear(const float* in, float* out, int B, int Hin, int Win
 int roma_op_dwconv5x5(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp, int dt,
                       void* stream) {
   return dwconv5x5_launch(in, out, w, bias, B, H, W, Cp, DT(dt), S(stream));
+}
+
+int roma_op_refiner_block(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw,
+                          const float* pw_b, int B, int H, int W, int Cp, int dt, void* stream) {
+  return refiner_block_launch(in, out, dw_w, dw_b, pw, Cp, pw_b, B, H, W, Cp, DT(dt), S(stream));
 }
 
 int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream) {

@@ -50,9 +50,12 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
 // the software rounding costs ~6 VALU ops per element and made the attention softmax / GEMM epilogues VALU-bound)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  // fptrunc <2 x float> -> <2 x bfloat> selects v_cvt_pk_bf16_f32 (RNE) on gfx950.  Deliberately NOT inline asm: the
+  // compiler must see the instruction to insert the MFMA-result read wait states when this is the first consumer.
+  typedef __attribute__((ext_vector_type(2))) float pk_f32x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 pk_bf16x2;
+  const pk_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pk_bf16x2));
 #else
   return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 #endif

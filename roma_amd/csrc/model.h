@@ -64,6 +64,7 @@ class Model {
   int act_dt = 0;  // DT_F32 / DT_BF16
   bool finalized = false;
   bool debug = false;
+  bool fuse_refiner_blocks = true;  // bf16 mode: fused dw5x5+1x1 kernel at the narrow scales (option "fuse_refiner_blocks")
   std::map<std::string, HostTensor> host;
 
   // packed weights (device)

@@ -11,6 +11,7 @@
 #include "elementwise.h"
 #include "gemm.h"
 #include "local_corr.h"
+#include "refiner_block.h"
 
 namespace roma {
 
@@ -807,15 +808,23 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           if ((size_t)M * r.Cp * esz <= ((size_t)64 << 20))
             if (int rc = dbg_save(nm.c_str(), d0, (size_t)M * r.Cp * esz, st)) return rc;
         }
+        void *dcur = d0, *dalt = d1;
+        const bool fused = fuse_refiner_blocks && refiner_block_supported(r.Cp, act_dt);
         for (int b = 0; b < 9; ++b) {
-          RUN(dwconv5x5_launch(d0, d1, r.dw_w[b], r.dw_b[b], ndp, hs, ws, r.Cp, act_dt, st));
+          if (fused) {  // narrow scales: dw5x5 + 1x1 in one pass over HBM (refiner_block.hip)
+            RUN(refiner_block_launch(dcur, dalt, r.dw_w[b], r.dw_b[b], r.pw[b].w, r.pw[b].ldw, r.pw[b].b, ndp, hs, ws,
+                                     r.Cp, act_dt, st));
+            std::swap(dcur, dalt);
+            continue;
+          }
+          RUN(dwconv5x5_launch(dcur, dalt, r.dw_w[b], r.dw_b[b], ndp, hs, ws, r.Cp, act_dt, st));
           GemmArgs g;
-          g.A = d1; g.lda = r.Cp; g.W = r.pw[b].w; g.ldw = r.pw[b].ldw; g.C = d0; g.ldc = r.Cp;
+          g.A = dalt; g.lda = r.Cp; g.W = r.pw[b].w; g.ldw = r.pw[b].ldw; g.C = dcur; g.ldc = r.Cp;
           g.M = (int)M; g.N = r.Cp; g.K = r.Cp; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = r.pw[b].b;
           RUN(gemm_launch(g, st));
         }
         const float sx = (float)ins / (4.0f * (float)W), sy = (float)ins / (4.0f * (float)H);
-        RUN(refiner_out_launch(d0, r.Cp, act_dt, r.out_w, r.out_b, flow, cert, M, r.Cp, sx, sy, st));
+        RUN(refiner_out_launch(dcur, r.Cp, act_dt, r.out_w, r.out_b, flow, cert, M, r.Cp, sx, sy, st));
       }
       if (debug && !dry) {
         const std::string pfx = std::string("p") + (up ? "2" : "1");

@@ -1,0 +1,16 @@
+// Fused ConvRefiner block for the narrow fine scales (reference: romatch/models/matcher.py:88-117 create_block):
+//   out = conv1x1( relu( bn( dwconv5x5(in) ) ) )      BN folded into the depthwise weights at pack time.
+// The separate dwconv + GEMM pair moves the activation through HBM twice per block; at the fine scales (C = 144 at
+// stride 2, C = 24 at stride 1) both kernels are purely bandwidth bound, so this kernel keeps the depthwise result
+// in LDS, runs the 1x1 on MFMA out of LDS and writes the block output once (2 x instead of 4 x the tensor bytes).
+// bf16 activations only (throughput mode); the exact-f32 mode keeps the two-kernel path.
+#pragma once
+#include "common.h"
+
+namespace roma {
+// in/out: [B,H,W,Cp] bf16 channels-last (must not alias); dw_w f32 [25][Cp], dw_b f32 [Cp] (BN folded);
+// pw bf16 [Cp][ldpw] (K contiguous), pw_b f32 [Cp].  Supported Cp: 24, 144.  Returns 0 / negative error code.
+bool refiner_block_supported(int Cp, int dt);
+int refiner_block_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
+                         const float* pw_b, int B, int H, int W, int Cp, int dt, hipStream_t s);
+}  // namespace roma

@@ -1,0 +1,402 @@
+// Fused depthwise-5x5 (+folded BN, ReLU) -> 1x1 convolution for the narrow ConvRefiner scales.  See refiner_block.h.
+//
+// One 256-thread workgroup owns a strip of SY image rows x PX pixels and all CP channels:
+//   * depthwise phase: the rolling-window stencil of dwconv5x5_kernel (elementwise.hip) - one thread = 4 channels x
+//     4 x-positions, each input row loaded once and fed to the 5 output rows it touches (v_pk_fma_f32), next input
+//     row prefetched.  The finished output row (after ReLU) is packed to bf16 into an LDS tile Xt[row][px][k]
+//     (80 / 304 byte pixel rows: conflict-free for the 16-byte MFMA fragment reads) instead of HBM;
+//   * every R = 2 output rows: barrier, the 4 waves run out[ch][px] = Wpw[ch][:] . Xt[px][:] on
+//     v_mfma_f32_32x32x16_bf16 (channels on the MFMA "i" side, so every lane ends up with 4 consecutive channels of
+//     one pixel), add the bias, pack to bf16 into a contiguous LDS image of the output rows, barrier, and the whole
+//     workgroup streams those rows to HBM with 16-byte lane-contiguous stores (a row segment PX*CP*2 B is contiguous).
+//   * C = 144: wave w keeps the weights of output channels [32w, 32w+32) in registers for the whole strip; the
+//     16-channel remainder block comes from LDS.  C = 24: the single (padded) 32-channel block comes from LDS.
+// The in-flight prefetch of the next input row spans the MFMA phase, which is what hides the HBM latency.
+#include "refiner_block.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "gemm.h"  // DT_*
+
+namespace roma {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// explicit LDS address-space types: 32-bit address arithmetic (generic pointers cost 64-bit VGPR pairs here)
+#define ROMA_LDS __attribute__((address_space(3)))
+typedef ROMA_LDS unsigned char lds_u8;
+typedef ROMA_LDS float lds_f32;
+typedef ROMA_LDS f32x4 lds_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;  // native vectors (HIP's u32x4_t is a struct:
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;  //  no address-space-qualified copies)
+typedef ROMA_LDS u32x4_t lds_u32x4;
+typedef ROMA_LDS u32x2_t lds_u32x2;
+
+__device__ __attribute__((aligned(256))) unsigned int g_rb_zero_page[64];  // source of every out-of-image DMA chunk
+
+template <int CP> struct RBCfg {
+  static constexpr int GC = CP / 4;                        // channel groups of 4
+  static constexpr int XQ = CP == 24 ? 36 : 256 / GC;      // x quads per workgroup row   (36 ; 7)
+  static constexpr int PX = 4 * XQ;                        // pixels per workgroup row    (144 ; 28)
+  static constexpr int PXB = (PX + 31) / 32;               // 32-pixel MFMA blocks / row  (5 ; 1)
+  static constexpr int KS = (CP + 15) / 16;                // MFMA k-steps                (2 ; 9)
+  static constexpr int KP = KS * 16;                       // padded K                    (32 ; 144)
+  static constexpr int NBF = CP / 32;                      // full 32-channel blocks      (0 ; 4)
+  static constexpr int TAIL = CP % 32;                     // channels of the last block  (24 ; 16)
+  static constexpr int XROW = KP * 2 + 16;                 // bytes per pixel row of Xt   (80 ; 304)
+  static constexpr int NR = CP == 24 ? 6 : 4;              // input rows in the LDS ring (DMA runs NR-1 rows ahead)
+  static constexpr int IN_ROWB = (PX + 4) * CP * 2;        // bytes of one input row segment incl. halo (7104 ; 9216)
+  static constexpr int NDMA = (IN_ROWB + 1023) / 1024;     // 1 KiB DMA instructions per row (7 ; 9)
+  static constexpr int RSTRIDE = NDMA * 1024;
+  static constexpr int KW = (NDMA + 3) / 4;                // max DMA instructions per wave per row (2 ; 3)
+  static constexpr int OROW = PX * CP * 2;                 // bytes of one output row segment (6912 ; 8064)
+  static constexpr int ROW16 = OROW / 16;
+  static constexpr int OFF_PWB = 26 * CP * 4;
+  static constexpr int OFF_WT = OFF_PWB + CP * 4;
+  static constexpr int OFF_XT = OFF_WT + TAIL * XROW;
+  static constexpr int OFF_OT = OFF_XT + PXB * 32 * XROW;
+  static constexpr int WORK_BYTES = OFF_OT + OROW;
+  static constexpr int RING_BYTES = NR * RSTRIDE;
+  static_assert(NBF == 0 || NBF == 4, "one wave per full channel block");
+  static_assert(GC * XQ <= 256 && OROW % 16 == 0 && TAIL % 8 == 0 && ROW16 <= 512, "layout");
+  static_assert(OFF_PWB % 16 == 0 && OFF_WT % 16 == 0 && OFF_XT % 16 == 0 && OFF_OT % 16 == 0, "alignment");
+  static_assert(WORK_BYTES + RING_BYTES <= 80 * 1024, "two workgroups per CU");
+  static_assert((NR - 1) * (KW + 2) < 64, "vmcnt range");
+};
+
+__device__ __forceinline__ void rb_glds16(const char* src, lds_u8* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (ROMA_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+#define ROMA_RB_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+// LDS writes of this wave retired, then the raw barrier (no __syncthreads: its release fence would drain vmcnt and
+// with it the whole DMA prefetch queue)
+#define ROMA_RB_BARRIER()                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
+  __builtin_amdgcn_s_barrier();                             \
+  asm volatile("" ::: "memory")
+
+template <int CP>
+__global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                               const float* __restrict__ dww, const float* __restrict__ dwb,
+                                                               const bf16_t* __restrict__ pw, long ldpw,
+                                                               const float* __restrict__ pwb, int B, int H, int W, int SY,
+                                                               int nxg, int nblocks, int dbg) {
+  typedef RBCfg<CP> Cf;
+  constexpr int GC = Cf::GC, XQ = Cf::XQ, PX = Cf::PX, PXB = Cf::PXB, KS = Cf::KS, NR = Cf::NR, KW = Cf::KW;
+  constexpr int XROW = Cf::XROW, OROW = Cf::OROW, NDMA = Cf::NDMA, RSTRIDE = Cf::RSTRIDE;
+  // Two distinct LDS objects on purpose: the compiler orders plain LDS reads against in-flight LDS-DMA only when they
+  // may alias, so everything in `work` is read with ordinary code while `ring` (the DMA target) is read with inline asm.
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[Cf::RING_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char work[Cf::WORK_BYTES];
+  lds_u8* const wk = (lds_u8*)work;
+  lds_f32* const wsm = (lds_f32*)wk;                         // [26][CP] depthwise taps + bias
+  lds_f32* const pbs = (lds_f32*)(wk + Cf::OFF_PWB);         // [CP] 1x1 bias
+  lds_u8* const Wt = wk + Cf::OFF_WT;                        // [TAIL][XROW] remainder-block 1x1 weights
+  lds_u8* const Xt = wk + Cf::OFF_XT;                        // [PXB*32][XROW] depthwise output row (bf16)
+  lds_u8* const Ot = wk + Cf::OFF_OT;                        // [PX][CP] block output row (bf16)
+
+  const int per_xcd = (nblocks + 7) / 8;  // each XCD owns a contiguous band of strips (vertical halo hits its own L2)
+  const long lb = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (lb >= nblocks) return;
+  const int xg = (int)(lb % nxg);
+  long rr = lb / nxg;
+  const int yt = (H + SY - 1) / SY;
+  const int ys = (int)(rr % yt) * SY;
+  const int b = (int)(rr / yt);
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int x0 = xg * PX;
+  const int sy = min(SY, H - ys);
+  const int T = sy + 4;  // input rows ys-2 .. ys+sy+1
+  const int npx = min(PX, W - x0);
+
+  // ---- one-time staging (ordinary loads: they are all retired before the first DMA is issued)
+  {
+    constexpr int nvec = 26 * GC;
+#pragma unroll
+    for (int it = 0; it < (nvec + 255) / 256; ++it) {
+      const int i = tid + 256 * it;
+      if (i < nvec)
+        *(lds_f32x4*)(wsm + i * 4) =
+            *reinterpret_cast<const f32x4*>(i < 25 * GC ? dww + (long)i * 4 : dwb + (long)(i - 25 * GC) * 4);
+    }
+    if (tid < GC) *(lds_f32x4*)(pbs + tid * 4) = *reinterpret_cast<const f32x4*>(pwb + tid * 4);
+    constexpr int wslots = Cf::TAIL * (XROW / 16);
+    for (int i = tid; i < wslots; i += 256) {
+      const int n = i / (XROW / 16), sl = i - n * (XROW / 16);
+      u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+      if (sl < CP * 2 / 16) v = *reinterpret_cast<const u32x4_t*>(pw + (long)(32 * Cf::NBF + n) * ldpw + sl * 8);
+      *(lds_u32x4*)(Wt + n * XROW + sl * 16) = v;
+    }
+    for (int i = tid; i < PXB * 32 * XROW / 16; i += 256) *(lds_u32x4*)(Xt + i * 16) = u32x4_t{0u, 0u, 0u, 0u};
+  }
+  // weights of this wave's own 32-channel block stay in registers (A operand: row = channel, 8 consecutive k per lane)
+  u32x4_t wown[Cf::NBF ? KS : 1];
+  if constexpr (Cf::NBF > 0) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wown[ks] = *reinterpret_cast<const u32x4_t*>(pw + (long)(32 * wv + l31) * ldpw + ks * 16 + hh * 8);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)  // make the compiler retire these loads here, not inside the pipelined loop
+      asm volatile("" : "+v"(wown[ks]));
+  }
+
+  // ---- DMA descriptors: wave wv issues the 1 KiB pieces wv, wv+4, .. of every input row; lane -> 16-byte chunk
+  const char* zsrc = reinterpret_cast<const char*>(g_rb_zero_page);
+  const char* inb = reinterpret_cast<const char*>(in + ((long)b * H * W) * CP);
+  const int qoff0 = (wv * 64 + lane) * 16;  // piece q of this wave starts 4 KiB * q further
+  bool qok[KW];
+#pragma unroll
+  for (int q = 0; q < KW; ++q) {
+    const int chunk = (wv + 4 * q) * 64 + lane;
+    const int x = x0 - 2 + chunk / (CP / 8);
+    qok[q] = chunk * 16 < Cf::IN_ROWB && x >= 0 && x < W;
+  }
+  const int kw = (NDMA - wv + 3) / 4;  // pieces this wave really issues per row
+#define ROMA_RB_ISSUE_ROW(RROW, SLOT)                                                                  \
+  {                                                                                                    \
+    const int yy_ = ys - 2 + (RROW);                                                                   \
+    const bool rok_ = (RROW) < T && yy_ >= 0 && yy_ < H;                                               \
+    const char* rb_ = inb + ((long)(rok_ ? yy_ : 0) * W + x0 - 2) * (CP * 2);                          \
+    _Pragma("unroll") for (int q = 0; q < KW; ++q) {                                                   \
+      if (wv + 4 * q < NDMA)                                                                           \
+        rb_glds16((rok_ && qok[q]) ? rb_ + qoff0 + q * 4096 : zsrc, (lds_u8*)ring + (SLOT) * RSTRIDE + (wv + 4 * q) * 1024); \
+    }                                                                                                  \
+  }
+
+  ROMA_RB_BARRIER();  // staged tiles visible; nothing of ours in flight yet
+#pragma unroll
+  for (int r = 0; r < NR; ++r) ROMA_RB_ISSUE_ROW(r, r);
+  if (kw == KW) ROMA_RB_WAIT_VM((NR - 1) * KW); else ROMA_RB_WAIT_VM((NR - 1) * (KW - 1));
+  ROMA_RB_BARRIER();  // input row 0 landed
+
+  const int cg = tid % GC, xq = tid / GC;
+  const int xb = x0 + xq * 4;
+  const bool active = xq < XQ && xb < W;
+  const int c = cg * 4;
+  const f32x4 bx = *(lds_f32x4*)(wsm + 25 * CP + c);
+  const f32x2 bias0 = f32x2{bx[0], bx[1]}, bias1 = f32x2{bx[2], bx[3]};
+  f32x2 acc[5][4][2];
+#pragma unroll
+  for (int s5 = 0; s5 < 5; ++s5)
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      acc[s5][px][0] = bias0;
+      acc[s5][px][1] = bias1;
+    }
+  const unsigned ring_lds = (unsigned)(size_t)((lds_u8*)ring);
+  const unsigned rd0 = ring_lds + (unsigned)((xq * 4 * CP + c) * 2);
+  bf16_t* obase = out + ((long)b * H * W) * CP;
+
+  int slot = 0;
+#pragma nounroll
+  for (int t = 0; t < T; ++t) {
+    const int o = t - 4;  // output row (relative to ys) finished by input row t
+    if (active && !(dbg & 1)) {
+      unsigned long long cr[8];
+      const unsigned ra = rd0 + (unsigned)slot * RSTRIDE;
+      asm volatile(
+          "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:%9\n\tds_read_b64 %2, %8 offset:%10\n\t"
+          "ds_read_b64 %3, %8 offset:%11\n\tds_read_b64 %4, %8 offset:%12\n\tds_read_b64 %5, %8 offset:%13\n\t"
+          "ds_read_b64 %6, %8 offset:%14\n\tds_read_b64 %7, %8 offset:%15\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(cr[0]), "=&v"(cr[1]), "=&v"(cr[2]), "=&v"(cr[3]), "=&v"(cr[4]), "=&v"(cr[5]), "=&v"(cr[6]), "=&v"(cr[7])
+          : "v"(ra), "n"(CP * 2), "n"(CP * 4), "n"(CP * 6), "n"(CP * 8), "n"(CP * 10), "n"(CP * 12), "n"(CP * 14)
+          : "memory");
+      // Column-major tap order: for tap column kx only the 4-wide window v[kx..kx+3] of converted inputs is live
+      // (the other columns stay packed bf16), and the 5 weights of that column are read from LDS one column ahead.
+      // The scheduling fences stop the compiler from hoisting all 25 weight reads (100 VGPRs), which spilled.
+#define ROMA_RB_CVT(J)                                                                             \
+  {                                                                                                \
+    const uint32_t lo_ = (uint32_t)cr[J], hi_ = (uint32_t)(cr[J] >> 32);                           \
+    v[J][0] = f32x2{__uint_as_float(lo_ << 16), __uint_as_float(lo_ & 0xffff0000u)};               \
+    v[J][1] = f32x2{__uint_as_float(hi_ << 16), __uint_as_float(hi_ & 0xffff0000u)};               \
+  }
+      f32x2 v[8][2];
+      ROMA_RB_CVT(0) ROMA_RB_CVT(1) ROMA_RB_CVT(2)
+      f32x4 wq[2][5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) wq[0][k] = *(lds_f32x4*)(wsm + ((4 - k) * 5 + 0) * CP + c);
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        if (kx < 4) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k)
+            wq[(kx + 1) & 1][k] = *(lds_f32x4*)(wsm + ((4 - k) * 5 + kx + 1) * CP + c);
+        }
+        ROMA_RB_CVT(kx + 3)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {  // acc[k] holds output row t - 4 + k (tap row ky = 4 - k)
+          const f32x4 wx = wq[kx & 1][k];
+          const f32x2 w0 = f32x2{wx[0], wx[1]}, w1 = f32x2{wx[2], wx[3]};
+#pragma unroll
+          for (int px = 0; px < 4; ++px) {
+            acc[k][px][0] = v[px + kx][0] * w0 + acc[k][px][0];
+            acc[k][px][1] = v[px + kx][1] * w1 + acc[k][px][1];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef ROMA_RB_CVT
+      if (o >= 0) {
+        lds_u8* xrow = Xt + (xq * 4) * XROW + cg * 8;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          u32x2_t u;
+          u.x = pack_bf16x2(fmaxf(acc[0][px][0][0], 0.f), fmaxf(acc[0][px][0][1], 0.f));
+          u.y = pack_bf16x2(fmaxf(acc[0][px][1][0], 0.f), fmaxf(acc[0][px][1][1], 0.f));
+          *(lds_u32x2*)(xrow + px * XROW) = u;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          acc[k][px][0] = acc[k + 1][px][0];
+          acc[k][px][1] = acc[k + 1][px][1];
+        }
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        acc[4][px][0] = bias0;
+        acc[4][px][1] = bias1;
+      }
+    }
+    ROMA_RB_BARRIER();  // B2: Xt complete; every wave is done reading ring slot `slot`
+    if (!(dbg & 8)) ROMA_RB_ISSUE_ROW(t + NR, slot);  // refill it with input row t + NR (zero page beyond the strip: keeps vmcnt uniform)
+    if (o >= 0 && !(dbg & 2)) {
+      // ---------------- 1x1 convolution of output row o on MFMA, out of LDS
+      if constexpr (Cf::NBF > 0) {
+        f32x16 oa[PXB];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bq = *(lds_f32x4*)(pbs + 32 * wv + 8 * g + 4 * hh);
+#pragma unroll
+          for (int u = 0; u < PXB; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oa[u][4 * g + j] = bq[j];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int u = 0; u < PXB; ++u) {
+            const u32x4_t xf = *(lds_u32x4*)(Xt + (u * 32 + l31) * XROW + ks * 32 + hh * 16);
+            oa[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wown[ks]),
+                                                            __builtin_bit_cast(bf16x8_t, xf), oa[u], 0, 0, 0);
+          }
+#pragma unroll
+        for (int u = 0; u < PXB; ++u) {
+          const int pxl = u * 32 + l31;
+          if (pxl < PX) {
+            lds_u8* orow = Ot + pxl * (CP * 2) + (32 * wv + 4 * hh) * 2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              u32x2_t q;
+              q.x = pack_bf16x2(oa[u][4 * g + 0], oa[u][4 * g + 1]);
+              q.y = pack_bf16x2(oa[u][4 * g + 2], oa[u][4 * g + 3]);
+              *(lds_u32x2*)(orow + g * 16) = q;
+            }
+          }
+        }
+      }
+      // remainder block (channels 32*NBF ..): its pixel blocks rotate over the waves
+#pragma unroll
+      for (int pb = 0; pb < PXB; ++pb) {
+        if (((pb + o) & 3) != wv) continue;
+        int lanev = lane;  // opaque copy: keeps the (loop-invariant) LDS addresses below from being hoisted into
+        asm volatile("" : "+v"(lanev));  // long-lived registers - this kernel sits exactly at the 256-VGPR budget
+        const int l31v = lanev & 31, hhv = lanev >> 5;
+        const int wrow = l31v < Cf::TAIL ? l31v : l31v - Cf::TAIL;  // rows >= TAIL of the MFMA tile are never stored
+        f32x16 ta;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+          if (8 * g + 4 * hhv < Cf::TAIL) bq = *(lds_f32x4*)(pbs + 32 * Cf::NBF + 8 * g + 4 * hhv);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ta[4 * g + j] = bq[j];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const u32x4_t wf = *(lds_u32x4*)(Wt + wrow * XROW + ks * 32 + hhv * 16);
+          const u32x4_t xf = *(lds_u32x4*)(Xt + (pb * 32 + l31v) * XROW + ks * 32 + hhv * 16);
+          ta = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, xf),
+                                                       ta, 0, 0, 0);
+        }
+        const int pxl = pb * 32 + l31v;
+        if (pxl < PX) {
+          lds_u8* orow = Ot + pxl * (CP * 2) + (32 * Cf::NBF + 4 * hhv) * 2;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (8 * g + 4 * hhv < Cf::TAIL) {
+              u32x2_t q;
+              q.x = pack_bf16x2(ta[4 * g + 0], ta[4 * g + 1]);
+              q.y = pack_bf16x2(ta[4 * g + 2], ta[4 * g + 3]);
+              *(lds_u32x2*)(orow + g * 16) = q;
+            }
+          }
+        }
+      }
+    }
+    // input row t+1 must have landed: everything issued after its DMA may stay in flight.  That is the DMA of rows
+    // t+2 .. t+NR (kw pieces each) plus, in steady state, the 2 output stores of each of the last NR-1 iterations.
+    if (t >= NR + 3) {
+      if (kw == KW) ROMA_RB_WAIT_VM((NR - 1) * (KW + 2)); else ROMA_RB_WAIT_VM((NR - 1) * (KW + 1));
+    } else {
+      if (kw == KW) ROMA_RB_WAIT_VM((NR - 1) * KW); else ROMA_RB_WAIT_VM((NR - 1) * (KW - 1));
+    }
+    ROMA_RB_BARRIER();  // B3: Ot complete, input row t+1 visible to every wave
+    if (o >= 0 && !(dbg & 4)) {
+      // stream the row out: always exactly two 16-byte stores per lane (clamped duplicates keep the count uniform)
+      const int n16 = npx * (CP * 2 / 16);
+      bf16_t* orow = obase + ((long)(ys + o) * W + x0) * CP;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int j = min(tid + 256 * it, n16 - 1);
+        const u32x4_t q = *(lds_u32x4*)(Ot + j * 16);
+        *reinterpret_cast<u32x4_t*>(orow + j * 8) = q;
+      }
+    }
+    slot = slot + 1 == NR ? 0 : slot + 1;
+  }
+  ROMA_RB_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
+}
+#undef ROMA_RB_ISSUE_ROW
+
+bool refiner_block_supported(int Cp, int dt) { return dt == DT_BF16 && (Cp == 24 || Cp == 144); }
+
+template <int CP>
+static int launch_cp(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
+                     const float* pw_b, int B, int H, int W, hipStream_t s) {
+  typedef RBCfg<CP> Cf;
+  const int SY = H >= 256 ? 36 : 16;  // SY + 4 input rows are read per strip
+  const int nxg = (W + Cf::PX - 1) / Cf::PX;
+  const long nb = (long)B * ((H + SY - 1) / SY) * nxg;
+  ROMA_REQUIRE(nb < (1l << 30), "refiner_block: grid too large");
+  const int nblocks = (int)nb;
+  static const int dbg = getenv("ROMA_RB_DBG") ? atoi(getenv("ROMA_RB_DBG")) : 0;  // tuning ablations only
+  if (dbg & 16) {
+    int nb_cu = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_cu, refiner_block_kernel<CP>, 256, 0);
+    fprintf(stderr, "refiner_block<%d>: %d workgroups/CU, grid %d\n", CP, nb_cu, nblocks);
+  }
+  dim3 grid((unsigned)(((nblocks + 7) / 8) * 8));
+  hipLaunchKernelGGL(refiner_block_kernel<CP>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, dw_w, dw_b,
+                     (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks, dbg);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+int refiner_block_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
+                         const float* pw_b, int B, int H, int W, int Cp, int dt, hipStream_t s) {
+  ROMA_REQUIRE(refiner_block_supported(Cp, dt), "refiner_block: only bf16 with Cp = 24 or 144 is fused");
+  ROMA_REQUIRE(in != out, "refiner_block: in and out must not alias");
+  ROMA_REQUIRE(ldpw % 8 == 0, "refiner_block: 1x1 weight rows must be 16-byte aligned");
+  ProfScope ps(Cp == 24 ? "refiner_block_kernel<24>" : "refiner_block_kernel<144>", 2.0 * (double)B * H * W * Cp * 2.0,
+               "byte", s);
+  if (Cp == 24) return launch_cp<24>(in, out, dw_w, dw_b, pw, ldpw, pw_b, B, H, W, s);
+  return launch_cp<144>(in, out, dw_w, dw_b, pw, ldpw, pw_b, B, H, W, s);
+}
+
+}  // namespace roma

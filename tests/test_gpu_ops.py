@@ -259,6 +259,33 @@ def test_dwconv5x5(lib, dt):
     assert torch.allclose(out.cpu().double(), ref, atol=tol, rtol=tol)
 
 
+@pytest.mark.parametrize("Cp,B,H,W", [(24, 2, 13, 10), (24, 1, 75, 301), (24, 1, 290, 150), (144, 2, 13, 10), (144, 1, 41, 59),
+                                      (144, 1, 262, 31)])
+def test_refiner_block_fused(lib, Cp, B, H, W):
+    """Fused dw5x5+BN+ReLU+1x1 (refiner_block.hip) vs torch f64 on the same bf16-rounded operands: ragged strips,
+    x tiles and pixel blocks, both strip heights (H >= 256 selects 36-row strips)."""
+    x = rnd(B, Cp, H, W, seed=1).to(torch.bfloat16)
+    w, b = rnd(Cp, 1, 5, 5, seed=2, std=0.2), rnd(Cp, seed=3)
+    pw = rnd(Cp, Cp, seed=4, std=Cp ** -0.5).to(torch.bfloat16)
+    pb = rnd(Cp, seed=5)
+    mid = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=2, groups=Cp)).to(torch.bfloat16)
+    ref = (F.conv2d(mid.double(), pw.double()[:, :, None, None], pb.double())).permute(0, 2, 3, 1)
+    out = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=torch.bfloat16)
+    wp = w.reshape(Cp, 25).T.contiguous().cuda()
+    ok(lib, lib.roma_op_refiner_block(P(x.permute(0, 2, 3, 1).contiguous().cuda()), P(out), P(wp), P(b.cuda()), P(pw.cuda()),
+                                      P(pb.cuda()), B, H, W, Cp, BF16, None))
+    torch.cuda.synchronize()
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    # bf16 output rounding (2^-8 relative) + the occasional 1-ulp flip of the bf16 intermediate
+    err = (got - ref).abs()
+    assert (err <= 1e-2 * ref.abs() + 3e-2).all(), float(err.max())
+    assert float(err.mean()) < 6e-3
+    # unsupported configurations fail loudly instead of falling back
+    assert lib.roma_op_refiner_block(P(out), P(out), P(wp), P(b.cuda()), P(pw.cuda()), P(pb.cuda()), B, H, W, Cp, BF16, None) != 0
+    assert lib.roma_op_refiner_block(P(x.cuda()), P(out), P(wp), P(b.cuda()), P(pw.cuda()), P(pb.cuda()), B, H, W, Cp, F32, None) != 0
+
+
 def test_maxpool_and_first_conv(lib):
     B, H, W = 2, 16, 24
     img, w, b = rnd(B, 3, H, W, seed=1), rnd(64, 3, 3, 3, seed=2, std=0.3), rnd(64, seed=3)
