@@ -35,6 +35,7 @@ struct GemmArgs {
   void *q = nullptr, *k = nullptr, *vt = nullptr;
   int heads = 0, hd = 0, ntok = 0, npad = 0;
   float qscale = 1.f;
+  int qkv_pad = 0;  // set by gemm_launch: GEMM rows are (image, token) with npad tokens per image (rows >= ntok read zeros)
   // EPI_COSK:  exp((acc/(nx[m]*ny[n]+1e-6) - 1) * inv_t) (+ diag_add on m==n)
   const float *nx = nullptr, *ny = nullptr;
   long sNx = 0, sNy = 0;

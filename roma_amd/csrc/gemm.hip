@@ -36,6 +36,20 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
 
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// Same function for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the 2^-9 relative
+// rounding of the bf16 store) - one v_rcp, one v_exp and 8 FMAs instead of libm's ~45-instruction branchy erff,
+// which cost 27% of the fc1 GEMM (128 values per lane per tile).
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  const float erf_abs = fmaf(-p * t, e, 1.0f);
+  return 0.5f * x + 0.5f * fabsf(x) * erf_abs;  // x * erf(x/sqrt2) = |x| * erf(|x|/sqrt2)
+}
 
 template <typename TOUT> __device__ inline void store4(TOUT* p, f32x4 v, bool vec, int nvalid) {
   if (vec && nvalid >= 4) {
@@ -49,6 +63,212 @@ template <typename TOUT> __device__ inline void store4(TOUT* p, f32x4 v, bool ve
 __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Plain (EPI_STD) epilogues, specialised at compile time on the activation and on "tile completely inside M x N".
+// One generic epilogue with every mode / activation / tail case inlined 32x per tile was ~50k instructions: its
+// straight-line path no longer fitted the instruction cache and cost ~8 us per 256x256 tile (as much as the K loop
+// at K = 1024).  Each variant below is a few hundred instructions.
+template <int ACT, bool FULL, bool BF16_OUT>
+__device__ __forceinline__ f32x4 epi_vals(f32x4 v, const GemmArgs& a, int n) {
+  if (a.bias) {
+    if (FULL || n + 3 < a.N) {
+      v += *reinterpret_cast<const f32x4*>(a.bias + n);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j < a.N) v[j] += a.bias[n + j];
+    }
+  }
+  if (ACT == ACT_RELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+  } else if (ACT == ACT_GELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = BF16_OUT ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
+  }
+  if (a.scale) {
+    if (FULL || n + 3 < a.N) {
+      v *= *reinterpret_cast<const f32x4*>(a.scale + n);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j < a.N) v[j] *= a.scale[n + j];
+    }
+  }
+  return v;
+}
+
+// bf16 output: the MFMA layout gives each lane 4 consecutive n of ONE row, i.e. a wave store would scatter 8-byte
+// pieces over 32 rows (measured 0.56 TB/s).  Stage the wave's tile through its private LDS slice instead and write
+// whole rows: 16 B per lane, 128..384 contiguous bytes per row.  (One wave's LDS operations complete in order.)
+template <int TM, int TN, int ACT, bool FULL>
+__device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], const GemmArgs& a, bf16_t* Cb, char* ws,
+                                                long mw0, int nw0, int lane) {
+  constexpr int RB = TN * 64;    // staged row: TN*32 bf16
+  constexpr int CPR = TN * 4;    // 16-byte chunks per row
+  constexpr int SWM = ((CPR & (CPR - 1)) == 0) ? CPR - 1 : 0;  // XOR swizzle of the chunk index (power-of-two rows)
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int n = nw0 + tn * 32 + 8 * rg + 4 * h;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = a.alpha * acc[tn][tm][4 * rg + j];
+        v = epi_vals<ACT, FULL, true>(v, a, n);
+        uint2 pk;
+        pk.x = pack_bf16x2(v[0], v[1]);
+        pk.y = pack_bf16x2(v[2], v[3]);
+        const int ch = tn * 4 + rg;
+        *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ (l31 & SWM)) << 4) + 8 * h) = pk;
+      }
+    const long mw = mw0 + tm * 32;
+#pragma unroll
+    for (int c = lane; c < 32 * CPR; c += 64) {
+      const int row = c / CPR, ch = c - row * CPR;
+      const long m = mw + row;
+      const int n = nw0 + ch * 8;
+      const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ (row & SWM)) << 4));
+      if (a.dbg & 1) continue;
+      bf16_t* dst = Cb + m * a.ldc + n;
+      if (FULL) {
+        *reinterpret_cast<uint4*>(dst) = v;
+      } else {
+        if (m >= a.M || n >= a.N) continue;
+        if (n + 8 <= a.N) {
+          *reinterpret_cast<uint4*>(dst) = v;
+        } else {
+          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+          for (int j = 0; j < 8; ++j)
+            if (n + j < a.N) dst[j] = e[j];
+        }
+      }
+    }
+  }
+}
+
+// EPI_QKV with bf16 outputs.  The GEMM rows are padded to npad tokens per image (gemm_launch), so every 32-row MFMA
+// block lies inside one image at a 32-aligned token: q / k rows are written like the plain staged epilogue (one head
+// = 2*hd contiguous bytes per token), and V is staged TRANSPOSED ([d][token]) so that V^T leaves as 16-byte pieces of
+// 8 consecutive tokens instead of single bf16 elements.
+template <int TM, int TN>
+__device__ __forceinline__ void epi_staged_qkv(const f32x16 (&acc)[TN][TM], const GemmArgs& a, char* ws, long mw0, int nw0,
+                                               int lane) {
+  constexpr int RB = TN * 64;
+  constexpr int CPR = TN * 4;
+  constexpr int SWM = ((CPR & (CPR - 1)) == 0) ? CPR - 1 : 0;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int D = a.heads * a.hd;
+  const int which = nw0 / D;         // wave-uniform: D % (TN*32) == 0
+  const int nrel = nw0 - which * D;  // first column of this wave inside q / k / v
+  const float sc = which == 0 ? a.qscale : 1.0f;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const long mw = mw0 + tm * 32;
+    if (mw >= a.M) continue;
+    const int qb = (int)(mw / a.npad);
+    const int qt0 = (int)(mw - (long)qb * a.npad);
+    if (qt0 >= a.ntok) continue;  // block of padding rows only
+    if (which < 2) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int n = nw0 + tn * 32 + 8 * rg + 4 * h;
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][4 * rg + j];
+          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+          v *= sc;
+          uint2 pk;
+          pk.x = pack_bf16x2(v[0], v[1]);
+          pk.y = pack_bf16x2(v[2], v[3]);
+          const int ch = tn * 4 + rg;
+          *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ (l31 & SWM)) << 4) + 8 * h) = pk;
+        }
+      bf16_t* dstb = reinterpret_cast<bf16_t*>(which == 0 ? a.q : a.k);
+#pragma unroll
+      for (int c = lane; c < 32 * CPR; c += 64) {
+        const int row = c / CPR, ch = c - row * CPR;
+        const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ (row & SWM)) << 4));
+        const int nr = nrel + ch * 8;
+        const int head = nr / a.hd, d = nr - head * a.hd;
+        if (qt0 + row >= a.ntok || (a.dbg & 1)) continue;  // padding rows stay zero
+        *reinterpret_cast<uint4*>(dstb + (((long)qb * a.heads + head) * a.npad + qt0 + row) * a.hd + d) = v;
+      }
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int nl = tn * 32 + 8 * rg + 4 * h;
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][4 * rg + j];
+          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + nw0 + nl);
+          const uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
+          unsigned short* col = reinterpret_cast<unsigned short*>(ws + nl * 64 + l31 * 2);  // [d][token]
+          col[0] = (unsigned short)(p0 & 0xffffu);
+          col[32] = (unsigned short)(p0 >> 16);
+          col[64] = (unsigned short)(p1 & 0xffffu);
+          col[96] = (unsigned short)(p1 >> 16);
+        }
+      bf16_t* vt = reinterpret_cast<bf16_t*>(a.vt);
+#pragma unroll
+      for (int i = 0; i < TN * 2; ++i) {
+        const int u = lane + 64 * i;
+        const int dl = u >> 2, tg = u & 3;
+        const uint4 v = *reinterpret_cast<const uint4*>(ws + dl * 64 + tg * 16);
+        const int nr = nrel + dl;
+        const int head = nr / a.hd, d = nr - head * a.hd;
+        if (a.dbg & 1) continue;
+        *reinterpret_cast<uint4*>(vt + (((long)qb * a.heads + head) * a.hd + d) * a.npad + qt0 + tg * 8) = v;
+      }
+    }
+  }
+}
+
+// f32 output (+ optional f32 residual, which may alias C): same idea, one 32 x 32 MFMA block (4 KiB) at a time.
+// Direct stores from the MFMA layout touch 32 rows x 32 B per instruction; staged, a wave instruction covers
+// 8 rows x 128 contiguous bytes for both the residual read and the store.  Requires N % 4 == 0.
+template <int TM, int TN, int ACT, bool FULL>
+__device__ __forceinline__ void epi_staged_f32(const f32x16 (&acc)[TN][TM], const GemmArgs& a, float* Cb, const float* Rb,
+                                               char* ws, long mw0, int nw0, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int n = nw0 + tn * 32 + 8 * rg + 4 * h;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = a.alpha * acc[tn][tm][4 * rg + j];
+        v = epi_vals<ACT, FULL, false>(v, a, n);
+        *reinterpret_cast<f32x4*>(ws + l31 * 128 + (((2 * rg + h) ^ (l31 & 7)) << 4)) = v;
+      }
+      const long mw = mw0 + tm * 32;
+      const int nw = nw0 + tn * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        const int row = c >> 3, ch = c & 7;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ws + row * 128 + ((ch ^ (row & 7)) << 4));
+        const long m = mw + row;
+        const int n = nw + ch * 4;
+        if (!FULL && (m >= a.M || n >= a.N)) continue;
+        if (Rb) v += *reinterpret_cast<const f32x4*>(Rb + m * a.ldr + n);
+        if (a.dbg & 1) continue;
+        *reinterpret_cast<f32x4*>(Cb + m * a.ldc + n) = v;
+      }
+    }
+  }
 }
 
 template <typename TIN, typename TOUT, int WM, int WN, int TM, int TN, bool CONV>
@@ -111,6 +331,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
           a_y[j] = rem / a.conv_w;                                                                          \
           a_x[j] = rem - a_y[j] * a.conv_w;                                                                 \
           a_src[j] = reinterpret_cast<const char*>(Ab + gm * a.conv_c + chunk * CE);                        \
+        } else if (a.qkv_pad) { /* rows = (image, padded token); tokens >= ntok read the zero page */      \
+          const long qb_ = gm / a.npad;                                                                     \
+          const int qt_ = (int)(gm - qb_ * a.npad);                                                         \
+          a_y[j] = a_x[j] = 0;                                                                              \
+          a_src[j] = qt_ < a.ntok ? reinterpret_cast<const char*>(Ab + (qb_ * a.ntok + qt_) * a.lda + chunk * CE) : nullptr; \
         } else {                                                                                            \
           a_y[j] = a_x[j] = 0;                                                                              \
           a_src[j] = reinterpret_cast<const char*>(Ab + gm * a.lda + chunk * CE);                           \
@@ -163,6 +388,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
   for (int g = 0; g < 4; ++g) rd_off[g] = l31 * ROWB + (((2 * g + h) ^ sw) << 4);
 
   const int nk = (a.dbg & 2) ? 1 : (a.K + BKE - 1) / BKE;
+  if constexpr (NWAVES == 8) {
+    // Persistent equal-sized tiles keep every CU in lock-step: all epilogues hit HBM in one write burst while no
+    // MFMA runs, then HBM idles.  Start every other workgroup half a tile late so the two phases interleave chip-wide.
+    if ((a.dbg & 16) && ((blockIdx.x >> 3) & 1) && nblk > gridDim.x) {
+      const long t0 = __builtin_readcyclecounter();
+      const long wait = (long)nk * 1100;
+      while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+  }
   ROMA_TILE_SETUP((long)xcd * per_xcd + li);
   ROMA_ISSUE_SLAB(0, 0);
   int bsel = 0;  // LDS buffer holding slab 0 of the current tile
@@ -219,12 +453,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
     if constexpr (NWAVES == 8) {
       // large MFMA-bound tiles: DMA first, fragments per k-group from inline asm (see above)
       if (kt + 1 < nk) {
-        ROMA_ISSUE_SLAB(kt + 1, cur ^ 1);
+        if (!(a.dbg & 4)) ROMA_ISSUE_SLAB(kt + 1, cur ^ 1);
       } else if (has_next) {
         ROMA_TILE_SETUP((long)xcd * per_xcd + li_next);
         ROMA_ISSUE_SLAB(0, cur ^ 1);
       }
-      if (skip_tile) continue;
+      if (skip_tile || (a.dbg & 8)) continue;
       const unsigned sb = lds0 + cur * BUF;
       uint4 wvA[TN], avA[TM], wvB[TN], avB[TM];
       ROMA_READ_G(wvA, avA, 0);
@@ -284,69 +518,49 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
   const bool vecC = ((a.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
   const bool vecR = Rb && ((a.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(Rb) & 15) == 0);
 
-  if constexpr (sizeof(TOUT) == 2) {
-    // bf16 output, plain epilogue: the MFMA layout gives each lane 4 consecutive n of ONE row, i.e. a wave store
-    // would scatter 8-byte pieces over 32 rows (measured 0.56 TB/s).  Stage the wave's tile through its private
-    // LDS slice instead and write whole rows: 16 B per lane, 128..384 contiguous bytes per row.
-    constexpr int RB = TN * 64;    // staged row: TN*32 bf16
-    constexpr int CPR = TN * 4;    // 16-byte chunks per row
-    constexpr int SWM = ((CPR & (CPR - 1)) == 0) ? CPR - 1 : 0;  // XOR swizzle of the chunk index (power-of-two rows)
-    if (a.mode == EPI_STD && Rb == nullptr && (a.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0) {
-      // 8-wave (persistent) tiles stage in their own slice behind the operand buffers (the next tile's first slab is
-      // already being DMA'd into those); 4-wave tiles reuse the operand buffers after a barrier (keeps 2+ WGs per CU)
+  {
+    // staged plain epilogues (see epi_staged_*).  8-wave (persistent) tiles stage in their own slices behind the
+    // operand buffers (the next tile's first slab is already being DMA'd into those); 4-wave tiles reuse the
+    // operand buffers after a barrier (keeps 2+ workgroups per CU).
+    constexpr int SLICE = sizeof(TOUT) == 2 ? 32 * TN * 64 : 4096;
+    if constexpr (sizeof(TOUT) == 2) {
+      if (a.mode == EPI_QKV && a.qkv_pad && ((a.heads * a.hd) % (TN * 32)) == 0) {
+        if constexpr (NWAVES != 8) __builtin_amdgcn_s_barrier();
+        epi_staged_qkv<TM, TN>(acc, a, smem + (NWAVES == 8 ? 2 * BUF : 0) + wave * SLICE, m0 + (long)wm * TM * 32,
+                               n0 + wn * TN * 32, lane);
+        if (!has_next) break;
+        continue;  // next tile
+      }
+    }
+    bool staged = a.mode == EPI_STD && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0;
+    if constexpr (sizeof(TOUT) == 2) staged = staged && Rb == nullptr && (a.ldc & 7) == 0;
+    else staged = staged && vecC && (Rb == nullptr || vecR) && (a.N & 3) == 0 && a.act != ACT_GELU;
+    if (staged) {
       if constexpr (NWAVES != 8) __builtin_amdgcn_s_barrier();
-      char* ws = smem + (NWAVES == 8 ? 2 * BUF : 0) + wave * (32 * RB);  // wave-private: one wave's LDS ops complete in order
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const int n = n0 + wn * TN * 32 + tn * 32 + 8 * rg + 4 * h;
-            f32x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = a.alpha * acc[tn][tm][4 * rg + j];
-            if (a.bias && n + 3 < a.N) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-            else if (a.bias) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (n + j < a.N) v[j] += a.bias[n + j];
-            }
-            if (a.act == ACT_RELU) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-            } else if (a.act == ACT_GELU) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-            }
-            if (a.scale) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (n + j < a.N) v[j] *= a.scale[n + j];
-            }
-            uint2 pk;
-            pk.x = pack_bf16x2(v[0], v[1]);
-            pk.y = pack_bf16x2(v[2], v[3]);
-            const int ch = tn * 4 + rg;
-            *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ (l31 & SWM)) << 4) + 8 * h) = pk;
-          }
-        const long mw = m0 + (wm * TM + tm) * 32;
-        const int nw0 = n0 + wn * TN * 32;
-#pragma unroll
-        for (int c = lane; c < 32 * CPR; c += 64) {
-          const int row = c / CPR, ch = c - row * CPR;
-          const long m = mw + row;
-          const int n = nw0 + ch * 8;
-          const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ (row & SWM)) << 4));
-          if (m >= a.M || n >= a.N || (a.dbg & 1)) continue;
-          bf16_t* dst = reinterpret_cast<bf16_t*>(Cb) + m * a.ldc + n;
-          if (n + 8 <= a.N) {
-            *reinterpret_cast<uint4*>(dst) = v;
-          } else {
-            const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
-            for (int j = 0; j < 8; ++j)
-              if (n + j < a.N) dst[j] = e[j];
-          }
+      char* ws = smem + (NWAVES == 8 ? 2 * BUF : 0) + wave * SLICE;
+      const long mw0 = m0 + (long)wm * TM * 32;
+      const int nw0 = n0 + wn * TN * 32;
+      const bool full_tile = m0 + BM <= a.M && n0 + BN <= a.N;
+      if constexpr (sizeof(TOUT) == 2) {
+        bf16_t* Cbb = reinterpret_cast<bf16_t*>(Cb);
+        if (a.act == ACT_GELU) {
+          if (full_tile) epi_staged_bf16<TM, TN, ACT_GELU, true>(acc, a, Cbb, ws, mw0, nw0, lane);
+          else epi_staged_bf16<TM, TN, ACT_GELU, false>(acc, a, Cbb, ws, mw0, nw0, lane);
+        } else if (a.act == ACT_RELU) {
+          if (full_tile) epi_staged_bf16<TM, TN, ACT_RELU, true>(acc, a, Cbb, ws, mw0, nw0, lane);
+          else epi_staged_bf16<TM, TN, ACT_RELU, false>(acc, a, Cbb, ws, mw0, nw0, lane);
+        } else {
+          if (full_tile) epi_staged_bf16<TM, TN, ACT_NONE, true>(acc, a, Cbb, ws, mw0, nw0, lane);
+          else epi_staged_bf16<TM, TN, ACT_NONE, false>(acc, a, Cbb, ws, mw0, nw0, lane);
+        }
+      } else {
+        float* Cbf = reinterpret_cast<float*>(Cb);
+        if (a.act == ACT_RELU) {
+          if (full_tile) epi_staged_f32<TM, TN, ACT_RELU, true>(acc, a, Cbf, Rb, ws, mw0, nw0, lane);
+          else epi_staged_f32<TM, TN, ACT_RELU, false>(acc, a, Cbf, Rb, ws, mw0, nw0, lane);
+        } else {
+          if (full_tile) epi_staged_f32<TM, TN, ACT_NONE, true>(acc, a, Cbf, Rb, ws, mw0, nw0, lane);
+          else epi_staged_f32<TM, TN, ACT_NONE, false>(acc, a, Cbf, Rb, ws, mw0, nw0, lane);
         }
       }
       if (!has_next) break;
@@ -362,8 +576,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
     if (a.mode == EPI_COSK) nxm = a.nx[(long)bz * a.sNx + m];
     int qb = 0, qt = 0;
     if (a.mode == EPI_QKV) {
-      qb = (int)(m / a.ntok);
-      qt = (int)(m - (long)qb * a.ntok);
+      const int per = a.qkv_pad ? a.npad : a.ntok;
+      qb = (int)(m / per);
+      qt = (int)(m - (long)qb * per);
+      if (qt >= a.ntok) continue;
     }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -458,8 +674,8 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const long nblk = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   size_t lds = (size_t)2 * (BM + BN) * ROWB;
-  if (sizeof(TOUT) == 2) {  // bf16 epilogue staging slices (one per wave)
-    const size_t stg = (size_t)WM * WN * 32 * TN * 64;
+  {  // epilogue staging slices (one per wave): bf16 rows of the wave tile, or one 32 x 32 f32 block
+    const size_t stg = (size_t)WM * WN * (sizeof(TOUT) == 2 ? 32 * TN * 64 : 4096);
     lds = (WM * WN == 8) ? lds + stg : std::max(lds, stg);
   }
   // persistent grid: the co-resident workgroups (256 CUs x LDS-limited occupancy), a multiple of the 8 XCDs;
@@ -532,6 +748,14 @@ int gemm_launch(const GemmArgs& a0, hipStream_t stream) {
   }
   if (a.mode == EPI_QKV) {
     ROMA_REQUIRE(a.hd % 4 == 0 && a.N == 3 * a.heads * a.hd, "gemm(qkv): bad head geometry");
+    ROMA_REQUIRE(a.ntok > 0 && a.M % a.ntok == 0 && a.npad >= a.ntok, "gemm(qkv): rows must be images x tokens");
+    // bf16: run the GEMM over padded rows (npad tokens per image) so the epilogue can write V^T as 16-byte pieces
+    if (a.out_dt == DT_BF16 && a.npad % 32 == 0 && a.hd % 8 == 0 && a.batch == 1 &&
+        (reinterpret_cast<uintptr_t>(a.q) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.k) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(a.vt) & 15) == 0) {
+      a.qkv_pad = 1;
+      a.M = (a.M / a.ntok) * a.npad;
+    }
   }
 #define ROMA_GEMM_DISPATCH(TIN, TOUT)                                              \
   return conv ? launch_shape<TIN, TOUT, true>(a, stream) : launch_shape<TIN, TOUT, false>(a, stream)

@@ -1,0 +1,14 @@
+import os, subprocess, sys
+code = r'''
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.argv=["x"]
+import tools.bench_gemm as b
+for (M,N,K) in [(65536,1024,1024),(25616,4096,1024)]:
+    b.run(M,N,K,b.BF16,b.BF16)
+    b.run(M,N,K,b.BF16,b.F32)
+    b.run(M,N,K,b.BF16,b.BF16,bias=False)
+'''
+for d in (0, 1, 12, 13, 14, 15):
+    print("== ROMA_GEMM_DBG=%d" % d, flush=True)
+    env = dict(os.environ, ROMA_GEMM_DBG=str(d))
+    subprocess.run([sys.executable, "-c", code], env=env)
