@@ -354,11 +354,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
     }                                                                                                       \
   }
 
-#define ROMA_ISSUE_SLAB(KT, BUFI)                                                                           \
+#define ROMA_ISSUE_SLAB_A(KT, BUFI)                                                                         \
   {                                                                                                         \
     const int k0_ = (KT) * BKE;                                                                             \
     char* abuf_ = smem + (BUFI) * BUF;                                                                      \
-    char* wbuf_ = abuf_ + BM * ROWB;                                                                        \
     if (CONV) {                                                                                             \
       const int tap_ = k0_ / a.conv_c;                                                                      \
       const int c0_ = k0_ - tap_ * a.conv_c;                                                                \
@@ -375,11 +374,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
         glds16(ok_ ? a_src[j] + (long)k0_ * sizeof(TIN) : zero, abuf_ + (wave * NA + j) * 1024);            \
       }                                                                                                     \
     }                                                                                                       \
+  }
+#define ROMA_ISSUE_SLAB_W(KT, BUFI)                                                                         \
+  {                                                                                                         \
+    const int k0_ = (KT) * BKE;                                                                             \
+    char* wbuf_ = smem + (BUFI) * BUF + BM * ROWB;                                                          \
     _Pragma("unroll") for (int j = 0; j < NW; ++j) {                                                        \
       const bool ok_ = w_src[j] != nullptr && (k0_ + w_chunk[j] * CE < a.K);                                \
       glds16(ok_ ? w_src[j] + (long)k0_ * sizeof(TIN) : zero, wbuf_ + (wave * NW + j) * 1024);              \
     }                                                                                                       \
   }
+#define ROMA_ISSUE_SLAB(KT, BUFI) \
+  ROMA_ISSUE_SLAB_A(KT, BUFI)     \
+  ROMA_ISSUE_SLAB_W(KT, BUFI)
 
   // fragment read offsets: row = tile_row0 + l31 (tile_row0 % 32 == 0), slot = (2g + h) ^ ((l31 >> 1) & 7)
   const int sw = (l31 >> 1) & 7;
@@ -452,13 +459,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
     __builtin_amdgcn_s_barrier();
     if constexpr (NWAVES == 8) {
       // large MFMA-bound tiles: DMA first, fragments per k-group from inline asm (see above)
+      // the next slab's DMA is issued in two bursts (A rows now, W rows after the first MFMA group): both waves of
+      // a SIMD leave the barrier together, and a single 8-piece burst per wave kept the MFMA pipe idle behind the
+      // VMEM issue (~60-180 cycles per piece)
+      int ikt = -1;
       if (kt + 1 < nk) {
-        if (!(a.dbg & 4)) ROMA_ISSUE_SLAB(kt + 1, cur ^ 1);
+        if (!(a.dbg & 4)) ikt = kt + 1;
       } else if (has_next) {
         ROMA_TILE_SETUP((long)xcd * per_xcd + li_next);
-        ROMA_ISSUE_SLAB(0, cur ^ 1);
+        ikt = 0;
       }
-      if (skip_tile || (a.dbg & 8)) continue;
+      const bool split = !(a.dbg & 32);
+      if (ikt >= 0) {
+        ROMA_ISSUE_SLAB_A(ikt, cur ^ 1);
+        if (!split) ROMA_ISSUE_SLAB_W(ikt, cur ^ 1);
+      }
+      if (skip_tile || (a.dbg & 8)) {
+        if (ikt >= 0 && split) ROMA_ISSUE_SLAB_W(ikt, cur ^ 1);
+        continue;
+      }
       const unsigned sb = lds0 + cur * BUF;
       uint4 wvA[TN], avA[TM], wvB[TN], avB[TM];
       ROMA_READ_G(wvA, avA, 0);
@@ -466,6 +485,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
       ROMA_WAIT_LGKM(TN + TM);
       ROMA_MFMA_G(wvA, avA);
       __builtin_amdgcn_sched_barrier(0);
+      if (ikt >= 0 && split) ROMA_ISSUE_SLAB_W(ikt, cur ^ 1);
       ROMA_READ_G(wvA, avA, 2);
       ROMA_WAIT_LGKM(TN + TM);
       ROMA_MFMA_G(wvB, avB);
@@ -666,6 +686,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
   if (!has_next) break;
   }  // tile loop
 #undef ROMA_ISSUE_SLAB
+#undef ROMA_ISSUE_SLAB_A
+#undef ROMA_ISSUE_SLAB_W
 #undef ROMA_TILE_SETUP
 }
 
