@@ -2,6 +2,8 @@
 // Conventions: channels-last activations, 16-byte (or 8-byte for bf16 quads) vector accesses,
 // one wave64 per row for row reductions, f32 math everywhere.
 #include "elementwise.h"
+
+#include <stdlib.h>
 #include "gemm.h"  // DT_*
 
 namespace roma {
@@ -623,28 +625,6 @@ __global__ __launch_bounds__(256) void refiner_input_pix_kernel(const RefinerInp
   for (int c4 = 0; c4 < LDD / 4; ++c4) ElemIO<T>::st4(d + c4 * 4, f32x4{o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3]});
 }
 
-int refiner_input_launch(const RefinerInputArgs& a, hipStream_t s) {
-  const long npix = (long)a.B * a.H * a.W;
-  if (a.C == 9 && a.E == 6 && a.Kcorr == 0 && a.ldf == 16 && a.ldd == 24) {
-    dim3 grid((unsigned)((npix + 255) / 256));
-    ROMA_DT_SWITCH(a.dt, T, hipLaunchKernelGGL((refiner_input_pix_kernel<T, 9, 6>), grid, dim3(256), 0, s, a));
-    ROMA_LAUNCH_CHECK();
-    return 0;
-  }
-  if (a.C % 4 != 0 || a.C < 32) {
-    const long total = npix * a.ldd;
-    dim3 grid((unsigned)std::min<long>((total + 255) / 256, 1 << 20));
-    ROMA_DT_SWITCH(a.dt, T, hipLaunchKernelGGL(refiner_input_small_kernel<T>, grid, dim3(256), 0, s, a));
-    ROMA_LAUNCH_CHECK();
-    return 0;
-  }
-  ROMA_REQUIRE(a.ldf % 4 == 0 && a.ldd % 4 == 0, "refiner_input: strides must be multiples of 4");
-  dim3 grid((unsigned)((npix + 3) / 4));
-  ROMA_DT_SWITCH(a.dt, T, hipLaunchKernelGGL(refiner_input_kernel<T>, grid, dim3(256), 0, s, a));
-  ROMA_LAUNCH_CHECK();
-  return 0;
-}
-
 // ------------------------------------------------------------------ depthwise 5x5 + BN(folded) + ReLU
 // One thread = one 16-byte channel vector (4 f32 / 8 bf16) x 4 consecutive x positions of one row; the 5x8 input
 // window is walked row by row so each loaded vector feeds up to 4 outputs.  Workgroups are remapped so that each
@@ -677,6 +657,99 @@ template <> struct VecIO<bf16_t> {
     *reinterpret_cast<uint4*>(p) = u;
   }
 };
+
+// refiner input, vectorised: LPP lanes (a power of two) share one pixel, 64/LPP pixels per wave, 16 bytes per lane
+// per access.  The wave-per-pixel kernel above left 48 of 64 lanes idle at C = 64 (stride-2 refiner, 4.2 M pixels).
+template <typename T>
+__global__ __launch_bounds__(256) void refiner_input_vec_kernel(const RefinerInputArgs a, int lpp) {
+  constexpr int CV = VecIO<T>::CV;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (lpp - 1), pw = lane / lpp, ppw = 64 / lpp;
+  const long HW = (long)a.H * a.W;
+  const long pix = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ppw + pw;
+  if (pix >= (long)a.B * HW) return;
+  const int b = (int)(pix / HW);
+  const long p = pix - (long)b * HW;
+  const int y = (int)(p / a.W), x = (int)(p - (long)y * a.W);
+  const T* feat = reinterpret_cast<const T*>(a.feat);
+  const T* fq = feat + ((long)b * HW + p) * a.ldf;
+  const int simg = (b + a.shift) % a.nimg;
+  const T* fs = feat + (long)simg * HW * a.ldf;
+  T* d = reinterpret_cast<T*>(a.d) + pix * a.ldd;
+  const float wx = a.flow[pix * 2 + 0], wy = a.flow[pix * 2 + 1];
+  float ix = ((wx + 1.f) * a.W - 1.f) * 0.5f, iy = ((wy + 1.f) * a.H - 1.f) * 0.5f;
+  ix = fminf(fmaxf(ix, -1.0e6f), 1.0e6f);
+  iy = fminf(fmaxf(iy, -1.0e6f), 1.0e6f);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float tx = ix - fx0, ty = iy - fy0;
+  const float wgt[4] = {(1.f - tx) * (1.f - ty), tx * (1.f - ty), (1.f - tx) * ty, tx * ty};
+  bool ok[4];
+  long off[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
+    ok[t] = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;  // zeros padding: out-of-image taps are skipped
+    off[t] = ((long)yy * a.W + xx) * a.ldf;
+  }
+  for (int c = sub * CV; c < a.C; c += lpp * CV) {
+    *reinterpret_cast<uint4*>(d + c) = *reinterpret_cast<const uint4*>(fq + c);
+    float r[CV];
+#pragma unroll
+    for (int j = 0; j < CV; ++j) r[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (ok[t]) {
+        float tv[CV];
+        VecIO<T>::ld(fs + off[t] + c, tv);
+#pragma unroll
+        for (int j = 0; j < CV; ++j) r[j] += wgt[t] * tv[j];
+      }
+    VecIO<T>::st(d + a.C + c, r);
+  }
+  const float dx = a.disp_scale * (wx - pix_coord(x, a.W)), dy = a.disp_scale * (wy - pix_coord(y, a.H));
+  for (int e = sub; e < a.E; e += lpp) {
+    const float v = a.emb_w[e * 2 + 0] * dx + a.emb_w[e * 2 + 1] * dy + a.emb_b[e];
+    ElemIO<T>::st(d + 2 * a.C + e, v);
+  }
+  for (long c = 2 * a.C + a.E + a.Kcorr + sub; c < a.ldd; c += lpp) ElemIO<T>::st(d + c, 0.f);
+}
+
+int refiner_input_launch(const RefinerInputArgs& a, hipStream_t s) {
+  const long npix = (long)a.B * a.H * a.W;
+  if (a.C == 9 && a.E == 6 && a.Kcorr == 0 && a.ldf == 16 && a.ldd == 24) {
+    dim3 grid((unsigned)((npix + 255) / 256));
+    ROMA_DT_SWITCH(a.dt, T, hipLaunchKernelGGL((refiner_input_pix_kernel<T, 9, 6>), grid, dim3(256), 0, s, a));
+    ROMA_LAUNCH_CHECK();
+    return 0;
+  }
+  if (a.C % 4 != 0 || a.C < 32) {
+    const long total = npix * a.ldd;
+    dim3 grid((unsigned)std::min<long>((total + 255) / 256, 1 << 20));
+    ROMA_DT_SWITCH(a.dt, T, hipLaunchKernelGGL(refiner_input_small_kernel<T>, grid, dim3(256), 0, s, a));
+    ROMA_LAUNCH_CHECK();
+    return 0;
+  }
+  ROMA_REQUIRE(a.ldf % 4 == 0 && a.ldd % 4 == 0, "refiner_input: strides must be multiples of 4");
+  {
+    const int cv = a.dt == DT_F32 ? 4 : 8;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a.feat) | reinterpret_cast<uintptr_t>(a.d)) & 15) == 0;
+    static const bool vec_off = getenv("ROMA_RI_VEC") && atoi(getenv("ROMA_RI_VEC")) == 0;  // A/B debugging only
+    if (!vec_off && aligned && a.C % cv == 0 && a.ldf % cv == 0 && a.ldd % cv == 0) {
+      int lpp = 1;
+      while (lpp < 64 && lpp * cv < a.C) lpp *= 2;
+      const long per_wg = 4 * (64 / lpp);
+      dim3 vgrid((unsigned)((npix + per_wg - 1) / per_wg));
+      ROMA_DT_SWITCH(a.dt, T, hipLaunchKernelGGL(refiner_input_vec_kernel<T>, vgrid, dim3(256), 0, s, a, lpp));
+      ROMA_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  dim3 grid((unsigned)((npix + 3) / 4));
+  ROMA_DT_SWITCH(a.dt, T, hipLaunchKernelGGL(refiner_input_kernel<T>, grid, dim3(256), 0, s, a));
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
