@@ -364,6 +364,10 @@ __global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __r
 }
 #undef ROMA_RB_ISSUE_ROW
 
+// (A stand-alone depthwise kernel on the same LDS-DMA ring was measured for the wide scales, C = 576 / 1152 / 1408:
+//  0.541 vs 0.504 ms at 16x216x216x576, 0.299 vs 0.266 ms at 16x108x108x1152 - slower than the register-prefetch
+//  kernel in elementwise.hip.  The depthwise phase is bound by its 200 v_pk_fma_f32 + 25 LDS weight reads per row,
+//  not by load latency; the ring only pays off here, where it also frees the registers the 1x1 weights need.)
 bool refiner_block_supported(int Cp, int dt) { return dt == DT_BF16 && (Cp == 24 || Cp == 144); }
 
 template <int CP>

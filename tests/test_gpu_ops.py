@@ -245,13 +245,14 @@ def test_resize_bilinear(lib, hin, hout, nc):
     assert torch.allclose(out.cpu().permute(0, 3, 1, 2), ref, atol=2e-5), (out.cpu().permute(0, 3, 1, 2) - ref).abs().max()
 
 
-@pytest.mark.parametrize("dt", [F32, BF16])
-def test_dwconv5x5(lib, dt):
-    B, H, W, Cp = 2, 13, 10, 24
+@pytest.mark.parametrize("dt,B,H,W,Cp", [(F32, 2, 13, 10, 24), (BF16, 2, 13, 10, 24), (BF16, 1, 41, 59, 264), (BF16, 1, 262, 31, 152),
+                                         (BF16, 1, 20, 300, 576), (F32, 1, 20, 37, 264)])
+def test_dwconv5x5(lib, dt, B, H, W, Cp):
+    """Rolling-window depthwise kernel: ragged channel chunks (264 = 2 x 33 groups), x tiles, both strip heights."""
     tdt = torch.float32 if dt == F32 else torch.bfloat16
     x, w, b = rnd(B, Cp, H, W, seed=1).to(tdt), rnd(Cp, 1, 5, 5, seed=2, std=0.2), rnd(Cp, seed=3)
     ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=2, groups=Cp)).permute(0, 2, 3, 1)
-    out = torch.empty((B, H, W, Cp), device="cuda", dtype=tdt)
+    out = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=tdt)
     wp = w.reshape(Cp, 25).T.contiguous().cuda()
     ok(lib, lib.roma_op_dwconv5x5(P(x.permute(0, 2, 3, 1).contiguous().cuda()), P(out), P(wp), P(b.cuda()), B, H, W, Cp, dt, None))
     torch.cuda.synchronize()
