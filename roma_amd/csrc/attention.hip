@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a) {
 
 // bf16 inputs, f32 softmax/accumulate; v_mfma_f32_32x32x16_bf16.
 template <int HD, typename TOUT, bool EXP2>
-__global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_bf16_kernel(const AttnArgs a) {
   constexpr int KV = 64;
   constexpr int KS = HD + 8, VS = KV + 8;  // bf16 elements per LDS row
   constexpr int KT = KV / 32, DT = HD / 32, NS = HD / 16;
@@ -156,18 +156,42 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
+  // K / V tiles travel global -> registers -> LDS; the loads of tile t+1 are issued (all at once) right after tile t
+  // has been published, so their latency is covered by the MFMA / softmax work instead of serialising four dependent
+  // round trips per tile
+  constexpr int NKC = KV * (HD / 8) / 256, NVC = HD * (KV / 8) / 256;  // 16-byte pieces per thread
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;  // (HIP's struct uint4 arrays went to scratch here)
+  u32x4_t kreg[NKC], vreg[NVC];
+#define ROMA_ATTN_FETCH(KV0)                                                                           \
+  {                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < NKC; ++i) {                                                  \
+      const int idx = tid + 256 * i;                                                                   \
+      const int row = idx / (HD / 8), c8 = idx % (HD / 8);                                             \
+      kreg[i] = *reinterpret_cast<const u32x4_t*>(K + (long)((KV0) + row) * HD + c8 * 8);             \
+    }                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NVC; ++i) {                                                  \
+      const int idx = tid + 256 * i;                                                                   \
+      const int row = idx / (KV / 8), c8 = idx % (KV / 8);                                             \
+      vreg[i] = *reinterpret_cast<const u32x4_t*>(Vt + (long)row * a.npad + (KV0) + c8 * 8);          \
+    }                                                                                                  \
+  }
+  ROMA_ATTN_FETCH(0);
   for (int kv0 = 0; kv0 < a.N; kv0 += KV) {
-    for (int idx = tid; idx < KV * (HD / 8); idx += 256) {
+#pragma unroll
+    for (int i = 0; i < NKC; ++i) {
+      const int idx = tid + 256 * i;
       const int row = idx / (HD / 8), c8 = idx % (HD / 8);
-      *reinterpret_cast<uint4*>(&Ks[row * KS + c8 * 8]) =
-          *reinterpret_cast<const uint4*>(K + (long)(kv0 + row) * HD + c8 * 8);
+      *reinterpret_cast<u32x4_t*>(&Ks[row * KS + c8 * 8]) = kreg[i];
     }
-    for (int idx = tid; idx < HD * (KV / 8); idx += 256) {
+#pragma unroll
+    for (int i = 0; i < NVC; ++i) {
+      const int idx = tid + 256 * i;
       const int row = idx / (KV / 8), c8 = idx % (KV / 8);
-      *reinterpret_cast<uint4*>(&Vs[row * VS + c8 * 8]) =
-          *reinterpret_cast<const uint4*>(Vt + (long)row * a.npad + kv0 + c8 * 8);
+      *reinterpret_cast<u32x4_t*>(&Vs[row * VS + c8 * 8]) = vreg[i];
     }
     __syncthreads();
+    // unconditional (a conditional fetch made hipcc keep kreg / vreg in scratch); past the end it re-reads the last tile
+    ROMA_ATTN_FETCH(min(kv0 + KV, a.npad - KV));
     f32x16 s[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
@@ -248,6 +272,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
       }
   }
 }
+
+#undef ROMA_ATTN_FETCH
 
 int attention_launch(const AttnArgs& a, hipStream_t stream) {
   ROMA_REQUIRE(a.hd == 64 || a.hd == 128, "attention: head dim must be 64 or 128");
