@@ -350,34 +350,54 @@ int transpose_launch(const float* in, float* out, int n, long ld, int batch, hip
 // (A fully unrolled register/readlane variant was correct but ~70 KB of straight-line code: instruction-fetch bound.)
 __global__ __launch_bounds__(64) void chol_diag_kernel(float* A, long ld, long strideA, float* Linv, float* LinvT,
                                                        int k, int nblk) {
-  __shared__ float L[64][65];
-  __shared__ float X[64][65];
+  // 68-float rows: 16-byte aligned and conflict free for lane-per-row ds_read_b128 (bank = 4 * lane).  The inner loops
+  // move 4 columns per LDS operation (row piece of this lane + a broadcast piece of the transposed copy): the scalar
+  // version issued ~10k dependent single-dword LDS operations per call and took 123 us on the GP's critical path.
+  constexpr int S = 68;
+  __shared__ __attribute__((aligned(16))) float L[64 * S];   // L[i][c]   (lane i owns row i)
+  __shared__ __attribute__((aligned(16))) float LT[64 * S];  // LT[j][c] = L[c][j]   (broadcast source)
+  __shared__ __attribute__((aligned(16))) float XT[64 * S];  // XT[c][t] = X[t][c]   (lane c owns row c)
   float* Ab = A + (long)blockIdx.x * strideA + ((long)k * 64) * ld + (long)k * 64;
   const int i = threadIdx.x;
   for (int idx = i; idx < 64 * 16; idx += 64) {  // coalesced float4 loads
     const int row = idx >> 4, c4 = idx & 15;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(Ab + (long)row * ld + c4 * 4);
-    L[row][c4 * 4 + 0] = v[0]; L[row][c4 * 4 + 1] = v[1]; L[row][c4 * 4 + 2] = v[2]; L[row][c4 * 4 + 3] = v[3];
+    *reinterpret_cast<f32x4*>(&L[row * S + c4 * 4]) = *reinterpret_cast<const f32x4*>(Ab + (long)row * ld + c4 * 4);
   }
   for (int j = 0; j < 64; ++j) {
-    const float d = sqrtf(L[j][j]);
-    const float lij = (i == j) ? d : L[i][j] / d;
-    L[i][j] = lij;  // rows < j: harmless garbage in the strictly upper part
-    for (int c = j + 1; c < 64; ++c) L[i][c] -= lij * L[c][j];  // a_ic -= l_ij * l_cj  (L[c][j] is a broadcast read)
+    const float d = sqrtf(L[j * S + j]);
+    const float lij = (i == j) ? d : L[i * S + j] / d;
+    L[i * S + j] = lij;   // rows < j: harmless garbage in the strictly upper part
+    LT[j * S + i] = lij;  // column j of the factor, contiguous
+    // a_ic -= l_ij * l_cj for c > j.  All 16 column groups every time (selects, no trip-count dependent loop): the
+    // 48 LDS operations of a step are independent and pipeline, instead of ~150 cycles of latency per group.
+#pragma unroll
+    for (int c = 0; c < 64; c += 4) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(&L[i * S + c]);
+      const f32x4 lc = *reinterpret_cast<const f32x4*>(&LT[j * S + c]);  // same address in every lane: broadcast
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = (c + u > j) ? a[u] - lij * lc[u] : a[u];
+      *reinterpret_cast<f32x4*>(&L[i * S + c]) = a;
+    }
   }
-  // inverse: lane c solves L x = e_c by forward substitution, x kept in X[.][c]
+  // inverse: lane c solves L x = e_c by forward substitution; x lives in XT[c][.]
   const int c = i;
   for (int r = 0; r < 64; ++r) {
     float sacc = (r == c) ? 1.f : 0.f;
-    for (int t = 0; t < r; ++t) sacc -= L[r][t] * X[t][c];
-    X[r][c] = sacc / L[r][r];
+#pragma unroll
+    for (int t = 0; t < 64; t += 4) {
+      const f32x4 lr = *reinterpret_cast<const f32x4*>(&L[r * S + t]);   // broadcast
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(&XT[c * S + t]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sacc = (t + u < r) ? sacc - lr[u] * xv[u] : sacc;
+    }
+    XT[c * S + r] = sacc / L[r * S + r];
   }
   float* Li = Linv + ((long)blockIdx.x * nblk + k) * 4096;
   float* LiT = LinvT + ((long)blockIdx.x * nblk + k) * 4096;
   for (int idx = i; idx < 64 * 64; idx += 64) {
     const int row = idx >> 6, col = idx & 63;
-    Ab[(long)row * ld + col] = (col <= row) ? L[row][col] : 0.f;
-    const float xv = (col <= row) ? X[row][col] : 0.f;
+    Ab[(long)row * ld + col] = (col <= row) ? L[row * S + col] : 0.f;
+    const float xv = (col <= row) ? XT[col * S + row] : 0.f;  // X[row][col]
     Li[idx] = xv;                 // Linv[row][col]
     LiT[col * 64 + row] = xv;     // LinvT[col][row]
   }
