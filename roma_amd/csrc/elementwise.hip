@@ -779,7 +779,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // strip of rows top to bottom:
 //   * its 25 x 4 weights stay in registers for the whole strip (one load per thread, not per output),
 //   * each input row is loaded ONCE (8 vectors) and feeds the 5 output rows it touches (5 rolling accumulator
-//     slots, static indices by unrolling the row loop 5x), i.e. 200 packed-f32 FMAs (v_pk_fma_f32) per 8 loads,
+//     slots that are rotated after every row), i.e. 200 packed-f32 FMAs (v_pk_fma_f32) per 8 loads,
 //   * the next input row is prefetched while the current one is multiplied.
 // Workgroups are remapped so each XCD owns a contiguous band of strips (private L2 sees the 4-row halo once).
 template <typename T> struct RawVec;
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(256, 2) void dwconv5x5_kernel(const T* in, T* out, 
 int dwconv5x5_launch(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp,
                      int dt, hipStream_t s) {
   ROMA_REQUIRE(Cp % 4 == 0, "dwconv5x5: padded channel count must be a multiple of 4");
-  const int SY = H >= 256 ? 36 : 16;  // strip height (SY + 4 input rows per strip; SY + 4 divisible by the 5x unroll)
+  const int SY = H >= 256 ? 36 : 16;  // strip height (SY + 4 input rows are read per strip)
   const int CG = Cp / 4;
   const int nchunk = (CG + 63) / 64;
   const int GC = (CG + nchunk - 1) / nchunk;  // channel groups (of 4) per workgroup, <= 64
@@ -1004,9 +1004,91 @@ __global__ __launch_bounds__(256) void refiner_out_kernel(const T* d, long ldd, 
   }
 }
 
+// Vectorised form: LPR lanes (a power of two) share a row, 16 bytes per lane per access, and a wave walks ROWS_IT
+// groups of 64/LPR rows with its out_conv weights held in registers.  (The kernel above re-read 48 bytes of f32
+// weights from L1/L2 for every 8 bytes of activations and left 28 of 64 lanes idle at Cp = 144: 4x off the HBM bound.)
+template <typename T, int NK>
+__global__ __launch_bounds__(256) void refiner_out_vec_kernel(const T* d, long ldd, const float* w, const float* bb,
+                                                              float* flow, float* cert, long M, int Cp, float sx, float sy,
+                                                              int lpr, int rows_it) {
+  constexpr int CV = VecIO<T>::CV;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (lpr - 1), rw = lane / lpr, rpw = 64 / lpr;
+  float wr[NK][3][CV];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int c = (sub + k * lpr) * CV;
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+      for (int j = 0; j < CV; ++j) wr[k][o][j] = c < Cp ? w[(long)o * Cp + c + j] : 0.f;
+  }
+  const float b0 = bb[0], b1 = bb[1], b2 = bb[2];
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw * rows_it + rw;
+  for (int it = 0; it < rows_it; ++it) {
+    const long row = row0 + (long)it * rpw;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (row < M) {
+      float v[NK][CV];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int c = (sub + k * lpr) * CV;
+        if (c < Cp) {
+          VecIO<T>::ld(d + row * ldd + c, v[k]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < CV; ++j) v[k][j] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int j = 0; j < CV; ++j) {
+          a0 = fmaf(v[k][j], wr[k][0][j], a0);
+          a1 = fmaf(v[k][j], wr[k][1][j], a1);
+          a2 = fmaf(v[k][j], wr[k][2][j], a2);
+        }
+    }
+    for (int off = lpr >> 1; off >= 1; off >>= 1) {
+      a0 += __shfl_xor(a0, off);
+      a1 += __shfl_xor(a1, off);
+      a2 += __shfl_xor(a2, off);
+    }
+    if (row < M && sub == 0) {
+      flow[row * 2 + 0] += sx * (a0 + b0);
+      flow[row * 2 + 1] += sy * (a1 + b1);
+      cert[row] += a2 + b2;
+    }
+  }
+}
+
 int refiner_out_launch(const void* d, long ldd, int dt, const float* w, const float* b, float* flow, float* cert,
                        long M, int Cp, float sx, float sy, hipStream_t s) {
   ROMA_REQUIRE(Cp % 4 == 0 && ldd % 4 == 0, "refiner_out: channel padding must be a multiple of 4");
+  {
+    const int cv = dt == DT_F32 ? 4 : 8;
+    const int chunks = Cp / cv;
+    if (Cp % cv == 0 && ldd % cv == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 && chunks >= 1) {
+      int lpr = 1;
+      while (lpr < 64 && lpr * 2 <= chunks) lpr *= 2;       // largest power of two <= chunks (<= 64)
+      const int nk = (chunks + lpr - 1) / lpr;              // 16-byte pieces per lane per row
+      if (nk <= 6) {
+        const int rows_it = 8;
+        const long rows_per_block = 4l * (64 / lpr) * rows_it;
+        dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block));
+#define ROMA_ROV(NKV)                                                                                          \
+  ROMA_DT_SWITCH(dt, T, hipLaunchKernelGGL((refiner_out_vec_kernel<T, NKV>), grid, dim3(256), 0, s, (const T*)d, ldd, w, b, \
+                                           flow, cert, M, Cp, sx, sy, lpr, rows_it))
+        if (nk <= 1) { ROMA_ROV(1); }
+        else if (nk == 2) { ROMA_ROV(2); }
+        else if (nk == 3) { ROMA_ROV(3); }
+        else { ROMA_ROV(6); }
+#undef ROMA_ROV
+        ROMA_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+  }
   const int chunks = Cp / 4;
 #define ROMA_RO(G)                                                                                          \
   {                                                                                                         \

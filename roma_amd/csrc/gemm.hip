@@ -1,4 +1,5 @@
-// MFMA GEMM for gfx950 (see gemm.h).  One 256-thread workgroup = 4 wave64s.
+// MFMA GEMM for gfx950 (see gemm.h).  Workgroups of 4 wave64s (small / HBM-bound tiles, several per CU) or 8 wave64s
+// (256-row tiles: one persistent workgroup per CU that walks its XCD's band of tiles).
 //
 // Tile anatomy (CDNA4):
 //   * K is staged in slabs of 8 x 16-byte chunks per row (32 f32 / 64 bf16 = 128-byte LDS rows) with
@@ -9,8 +10,9 @@
 //     a ds_read_b128 lane group then touches 16 distinct 16-B slots of the 256-B bank row: conflict free.
 //   * out-of-range rows / K tail / 3x3-conv zero padding are DMA'd from a 256-byte zero page, so every
 //     tail is exact without predicated stores into LDS.
-//   * two LDS buffers, ONE raw `s_barrier` per slab: the DMA of slab t+1 is issued after slab t's fragments
-//     are in registers and runs under slab t's MFMAs.
+//   * two LDS buffers, ONE raw `s_barrier` per slab: the DMA of slab t+1 runs under slab t's MFMAs (8-wave tiles
+//     issue it first and read their fragments with inline asm, 4-wave tiles issue it after the fragment reads:
+//     hipcc drains the DMA queue before any LDS read it can see).
 //   * MFMA operand roles are SWAPPED: the weight tile feeds the A operand (rows = n) and the
 //     activation tile the B operand (cols = m).  D[n][m] then puts 4 CONSECUTIVE n of one output
 //     row m in each lane's register quad, so bias/scale/residual/output move as 16-byte vectors.
