@@ -379,27 +379,37 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(float* A, long ld, long s
       *reinterpret_cast<f32x4*>(&L[i * S + c]) = a;
     }
   }
-  // inverse: lane c solves L x = e_c by forward substitution; x lives in XT[c][.]
+  // inverse: lane c solves L x = e_c by forward substitution; x lives in XT[c][.].  Four interleaved partial sums
+  // (t mod 4) keep the dependent-FMA chain at 16 instead of 64 per row.
   const int c = i;
   for (int r = 0; r < 64; ++r) {
-    float sacc = (r == c) ? 1.f : 0.f;
+    f32x4 part = {(r == c) ? 1.f : 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 64; t += 4) {
       const f32x4 lr = *reinterpret_cast<const f32x4*>(&L[r * S + t]);   // broadcast
       const f32x4 xv = *reinterpret_cast<const f32x4*>(&XT[c * S + t]);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) sacc = (t + u < r) ? sacc - lr[u] * xv[u] : sacc;
+      for (int u = 0; u < 4; ++u) part[u] = (t + u < r) ? part[u] - lr[u] * xv[u] : part[u];
     }
-    XT[c * S + r] = sacc / L[r * S + r];
+    XT[c * S + r] = ((part[0] + part[1]) + (part[2] + part[3])) / L[r * S + r];
   }
   float* Li = Linv + ((long)blockIdx.x * nblk + k) * 4096;
   float* LiT = LinvT + ((long)blockIdx.x * nblk + k) * 4096;
-  for (int idx = i; idx < 64 * 64; idx += 64) {
-    const int row = idx >> 6, col = idx & 63;
-    Ab[(long)row * ld + col] = (col <= row) ? L[row * S + col] : 0.f;
-    const float xv = (col <= row) ? XT[col * S + row] : 0.f;  // X[row][col]
-    Li[idx] = xv;                 // Linv[row][col]
-    LiT[col * 64 + row] = xv;     // LinvT[col][row]
+  // write-back, 16 bytes per lane: the factor (upper part zeroed), Linv^T rows (= XT rows) and Linv (transposed read)
+  for (int idx = i; idx < 64 * 16; idx += 64) {
+    const int row = idx >> 4, c4 = (idx & 15) * 4;
+    f32x4 lv = *reinterpret_cast<const f32x4*>(&L[row * S + c4]);
+    f32x4 xt = *reinterpret_cast<const f32x4*>(&XT[row * S + c4]);  // XT[row][c4..] = X[c4..][row] = LinvT[row][c4..]
+    f32x4 xl;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (c4 + u > row) lv[u] = 0.f;
+      if (c4 + u < row) xt[u] = 0.f;               // X[t][c] is zero for t < c
+      xl[u] = (c4 + u <= row) ? XT[(c4 + u) * S + row] : 0.f;  // Linv[row][c4+u] = X[row][c4+u]
+    }
+    *reinterpret_cast<f32x4*>(Ab + (long)row * ld + c4) = lv;
+    *reinterpret_cast<f32x4*>(LiT + row * 64 + c4) = xt;
+    *reinterpret_cast<f32x4*>(Li + row * 64 + c4) = xl;
   }
 }
 
