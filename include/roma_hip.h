@@ -102,6 +102,10 @@ int roma_op_dwconv5x5(const void* in, void* out, const float* w, const float* bi
  * dw_w/dw_b.  bf16 only, Cp in {24, 144}; in/out [B,H,W,Cp] must not alias; pw bf16 [Cp][Cp], pw_b f32 [Cp]. */
 int roma_op_refiner_block(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw,
                           const float* pw_b, int B, int H, int W, int Cp, int dt, void* stream);
+/* Gaussian KDE of sampled matches (romatch/utils/kde.py:4-12; RegressionMatcher.sample, matcher.py:598-629):
+ * density[i] = sum_j exp(-|x_i - x_{j*down}|^2 / (2 std^2)), x: DEVICE [n,4] f32.  half_inputs != 0 rounds the
+ * coordinates to fp16 first (the reference's x.half()); accumulation is f32. */
+int roma_op_kde(const float* x, long n, int down, float std, int half_inputs, float* density, void* stream);
 int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream);
 int roma_op_conv3x3_c3(const float* img, const float* w, const float* bias, void* out, int B, int H, int W, int dt_out,
                        void* stream);

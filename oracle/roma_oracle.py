@@ -342,3 +342,37 @@ def match(im_A, im_B, sd, dsd, im_A_high_res=None, im_B_high_res=None, symmetric
     else:
         warp = torch.cat((grid, flow), dim=-1)
     return warp, certainty[:, 0]
+
+
+# --------------------------------------------------------------------------- sampling
+def kde(x, std=0.1, half=False, down=None):
+    """Gaussian kernel density of matches x [n,4] - romatch/utils/kde.py:4-12.
+
+    The reference computes `(-cdist(x, x[::down])**2 / (2 std^2)).exp().sum(-1)` (in fp16 when half=True).  Restated
+    with an explicit squared distance in f32/f64: cdist's sqrt followed by **2 is the identity up to rounding.  With
+    half=True only the INPUT rounding of the reference is reproduced (x.half()); the arithmetic stays f32."""
+    x = x.detach().to(torch.float32)
+    if half:
+        x = x.half().float()
+    y = x if down is None else x[::down]
+    d2 = ((x[:, None, :].double() - y[None, :, :].double()) ** 2).sum(-1)
+    return torch.exp(-d2 / (2.0 * std ** 2)).sum(-1).float()
+
+
+def sample(matches, certainty, num=10000, sample_mode="threshold_balanced", sample_thresh=0.05, generator=None):
+    """RegressionMatcher.sample - romatch/models/matcher.py:598-629 (stochastic: two multinomial draws)."""
+    if "threshold" in sample_mode:
+        certainty = certainty.clone()
+        certainty[certainty > sample_thresh] = 1
+    matches, certainty = matches.reshape(-1, 4), certainty.reshape(-1)
+    expansion_factor = 4 if "balanced" in sample_mode else 1
+    good = torch.multinomial(certainty, num_samples=min(expansion_factor * num, len(certainty)), replacement=False,
+                             generator=generator)
+    good_matches, good_certainty = matches[good], certainty[good]
+    if "balanced" not in sample_mode:
+        return good_matches, good_certainty
+    density = kde(good_matches, std=0.1)
+    p = 1 / (density + 1)
+    p[density < 10] = 1e-7
+    bal = torch.multinomial(p, num_samples=min(num, len(good_certainty)), replacement=False, generator=generator)
+    return good_matches[bal], good_certainty[bal]

@@ -11,6 +11,7 @@
 #include "local_corr.h"
 #include "model.h"
 #include "refiner_block.h"
+#include "kde.h"
 
 namespace roma {
 static thread_local std::string g_err;
@@ -234,6 +235,10 @@ int roma_op_dwconv5x5(const void* in, void* out, const float* w, const float* bi
 int roma_op_refiner_block(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw,
                           const float* pw_b, int B, int H, int W, int Cp, int dt, void* stream) {
   return refiner_block_launch(in, out, dw_w, dw_b, pw, Cp, pw_b, B, H, W, Cp, DT(dt), S(stream));
+}
+
+int roma_op_kde(const float* x, long n, int down, float std, int half_inputs, float* density, void* stream) {
+  return kde_launch(x, n, down, std, half_inputs, density, S(stream));
 }
 
 int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream) {

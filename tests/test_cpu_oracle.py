@@ -80,6 +80,43 @@ def test_oracle_integer_patch_identity():
     assert (out - ref).abs()[mask[:, None].expand_as(ref)].max() < 1e-4
 
 
+def test_oracle_kde_vs_reference_golden():
+    """oracle.kde (matcher.sample's density) against romatch.utils.kde.kde run on CPU
+    (tools/make_goldens.py kde).  f32 evaluation: 1e-4 relative.  The reference's default fp16 evaluation
+    (half=True) is itself up to ~13 % away from exact arithmetic on these points; the oracle reproduces only its
+    input rounding, so that comparison is loose by construction."""
+    from oracle import roma_oracle as O
+    g = np.load(os.path.join(GOLDEN, "kde_reference.npz"))
+    x = torch.from_numpy(g["x"])
+    for key, kw in (("density_f32", {}), ("density_f32_down3", {"down": 3}), ("density_f32_std025", {"std": 0.25})):
+        d, r = O.kde(x, **kw).numpy(), g[key]
+        assert np.all(np.abs(d - r) <= 1e-4 * np.abs(r) + 1e-6), key
+    d, r = O.kde(x, half=True).numpy(), g["density_half"]
+    assert np.all(np.abs(d - r) <= 0.15 * np.abs(r) + 0.15)
+    assert np.all(O.kde(x).numpy() >= 1.0 - 1e-6)  # every point is its own neighbour
+
+
+def test_oracle_sample_semantics():
+    """Control flow of RegressionMatcher.sample (matcher.py:598-629) in the oracle restatement."""
+    from oracle import roma_oracle as O
+    g = torch.Generator().manual_seed(3)
+    n = 4000
+    dense = torch.tensor([0.3, -0.2, 0.1, 0.4]) + 0.02 * torch.randn(3000, 4, generator=g)
+    loose = torch.tensor([-0.5, 0.5, -0.4, -0.3]) + 0.08 * torch.randn(1000, 4, generator=g)
+    matches = torch.cat([dense, loose])
+    cert = torch.full((n,), 0.5)
+    cert[:10] = 0.01
+    m, c = O.sample(matches, cert, num=500, sample_mode="threshold", sample_thresh=0.05, generator=g)
+    assert m.shape == (500, 4) and c.shape == (500,)
+    assert set(np.unique(c.numpy()).tolist()) <= {1.0, np.float32(0.01).item()}  # > thresh -> 1, else untouched
+    m, c = O.sample(matches, cert, num=500, sample_mode="threshold_balanced", sample_thresh=0.05, generator=g)
+    assert m.shape == (500, 4)
+    frac_loose = float((m[:, 0] < -0.1).float().mean())
+    assert frac_loose > 0.5, frac_loose  # 25 % of the points, but ~7x lower density -> favoured by 1/(density+1)
+    src = {tuple(np.round(r, 6)) for r in matches.numpy().tolist()}
+    assert all(tuple(np.round(r, 6)) in src for r in m.numpy().tolist())
+
+
 def test_library_exports_every_declared_symbol(built_lib):
     """include/roma_hip.h <-> libroma_hip.so <-> ctypes table: same symbol set; no compute without a GPU."""
     from roma_amd import _lib

@@ -300,3 +300,78 @@ def test_maxpool_and_first_conv(lib):
     assert torch.allclose(out.cpu().double(), ref, atol=1e-5, rtol=1e-5)
     refp = F.max_pool2d(ref.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
     assert torch.allclose(pooled.cpu().double(), refp, atol=1e-5)
+
+
+
+# ------------------------------------------------------------------ sampling: KDE + RegressionMatcher.sample
+def test_kde_vs_reference_golden_and_oracle():
+    import roma_amd
+    from oracle import roma_oracle as O
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "kde_reference.npz"))
+    x = torch.from_numpy(g["x"])
+    xd = x.cuda()
+    for key, kw in (("density_f32", {"half": False}), ("density_f32_down3", {"half": False, "down": 3}),
+                    ("density_f32_std025", {"half": False, "std": 0.25})):
+        d = roma_amd.kde(xd, **kw).cpu().numpy()
+        r = g[key]                                   # the reference itself (f32 evaluation)
+        assert np.all(np.abs(d - r) <= 1e-4 * np.abs(r) + 1e-6), key
+        o = O.kde(x, **{k: v for k, v in kw.items() if k != "half"}).numpy()
+        assert np.all(np.abs(d - o) <= 1e-5 * np.abs(o) + 1e-7), key  # f32 sum + v_exp_f32 vs the f64 oracle
+    d = roma_amd.kde(xd).cpu().numpy()              # default half=True: same input rounding as the oracle
+    o = O.kde(x, half=True).numpy()
+    assert np.all(np.abs(d - o) <= 1e-5 * np.abs(o) + 1e-7)
+    r = g["density_half"]
+    assert np.all(np.abs(d - r) <= 0.15 * np.abs(r) + 0.15)  # the reference's own fp16 arithmetic noise
+
+
+def test_kde_full_size_properties():
+    """n = 40 000 (4 x num, the size matcher.sample evaluates): spot rows against float64, density >= 1, and
+    invariance under a permutation of the points."""
+    import roma_amd
+    g = np.random.Generator(np.random.PCG64(5))
+    n = 40000
+    x = (g.random((n, 4), dtype=np.float32) * 2 - 1)
+    x[: n // 2] = x[:50][g.integers(0, 50, n // 2)] + 0.03 * g.standard_normal((n // 2, 4), dtype=np.float32)
+    xd = torch.from_numpy(x).cuda()
+    d = roma_amd.kde(xd, half=False).cpu().numpy()
+    assert d.shape == (n,) and np.all(d >= 1.0 - 1e-5)
+    rows = g.integers(0, n, 64)
+    ref = np.exp(-((x[rows, None, :].astype(np.float64) - x[None, :, :].astype(np.float64)) ** 2).sum(-1) / 0.02).sum(-1)
+    assert np.all(np.abs(d[rows] - ref) <= 2e-5 * ref)
+    perm = g.permutation(n)
+    dp = roma_amd.kde(torch.from_numpy(x[perm]).cuda(), half=False).cpu().numpy()
+    assert np.all(np.abs(dp - d[perm]) <= 1e-5 * d[perm])
+    with pytest.raises(Exception):
+        roma_amd.kde(torch.from_numpy(x))  # CPU tensor: no fallback
+
+
+def test_sample_distribution_matches_oracle():
+    """RegressionMatcher.sample on the device vs the oracle restatement: same control flow, distributional parity."""
+    from roma_amd.matcher import RegressionMatcher
+    from oracle import roma_oracle as O
+    gen = torch.Generator().manual_seed(3)
+    dense = torch.tensor([0.3, -0.2, 0.1, 0.4]) + 0.02 * torch.randn(3000, 4, generator=gen)
+    loose = torch.tensor([-0.5, 0.5, -0.4, -0.3]) + 0.08 * torch.randn(1000, 4, generator=gen)
+    matches = torch.cat([dense, loose])
+    cert = torch.full((4000,), 0.5)
+    cert[:10] = 0.01
+    m = RegressionMatcher.__new__(RegressionMatcher)  # sample() needs only the two sampling attributes
+    m.sample_mode, m.sample_thresh = "threshold_balanced", 0.05
+    torch.manual_seed(11)
+    fr = []
+    for _ in range(4):
+        gm, gc = m.sample(matches.cuda().reshape(40, 100, 4), cert.cuda().reshape(40, 100), num=500)
+        assert gm.shape == (500, 4) and gc.shape == (500,) and gm.is_cuda
+        fr.append(float((gm[:, 0] < -0.1).float().mean()))
+    fo = []
+    for _ in range(4):
+        om, _ = O.sample(matches, cert, num=500, generator=gen)
+        fo.append(float((om[:, 0] < -0.1).float().mean()))
+    assert abs(np.mean(fr) - np.mean(fo)) < 0.08, (fr, fo)
+    assert np.mean(fr) > 0.5
+    m.sample_mode = "threshold"
+    gm, gc = m.sample(matches.cuda(), cert.cuda(), num=500)
+    assert gm.shape == (500, 4)
+    vals = set(np.unique(gc.cpu().numpy()).tolist())
+    assert vals <= {1.0, np.float32(0.01).item()}

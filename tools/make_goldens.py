@@ -8,6 +8,7 @@ fixtures are what travels to the GPU box.  Usage:
     python tools/make_goldens.py tiny          # match() 112 -> 168, B=1 symmetric (+ stage tensors)
     python tools/make_goldens.py small         # match() 224 -> 336, B=2, non-symmetric and symmetric coarse-only
     python tools/make_goldens.py full          # match() 560 -> 864, B=1 symmetric (sub-sampled)
+    python tools/make_goldens.py kde           # romatch.utils.kde.kde on seeded match-like points
 """
 import json
 import os
@@ -170,6 +171,25 @@ def full():
     print(meta)
 
 
+def kde_golden():
+    """Reference romatch.utils.kde.kde on seeded match-like points: f32 (half=False), the reference's default fp16
+    evaluation (half=True) and the `down` sub-sampling."""
+    install_stubs()
+    from romatch.utils.kde import kde as ref_kde
+    g = torch.Generator().manual_seed(7)
+    n = 1500
+    # clustered + spread points in [-1,1]^4, like warp samples: dense blobs give densities well above 10
+    centers = torch.rand(12, 4, generator=g) * 1.6 - 0.8
+    x = centers[torch.randint(0, 12, (n,), generator=g)] + 0.05 * torch.randn(n, 4, generator=g)
+    x[: n // 5] = torch.rand(n // 5, 4, generator=g) * 2 - 1
+    out = dict(x=np32(x), density_f32=np32(ref_kde(x, std=0.1, half=False)),
+               density_half=np32(ref_kde(x, std=0.1, half=True).float()),
+               density_f32_down3=np32(ref_kde(x, std=0.1, half=False, down=3)),
+               density_f32_std025=np32(ref_kde(x, std=0.25, half=False)))
+    np.savez_compressed(os.path.join(GOLD, "kde_reference.npz"), **out)
+    print({k: (v.shape, float(v.min()), float(v.max())) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     for what in sys.argv[1:]:
-        {"contract": contract, "ops": ops, "tiny": tiny, "small": small, "full": full}[what]()
+        {"contract": contract, "ops": ops, "tiny": tiny, "small": small, "full": full, "kde": kde_golden}[what]()
