@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a) {
 template <int HD, typename TOUT, bool EXP2>
 __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_bf16_kernel(const AttnArgs a) {
   constexpr int KV = 64;
-  constexpr int KS = HD + 8, VS = KV + 8;  // bf16 elements per LDS row
+  // bf16 elements per LDS row.  K rows (+8: 144 B) are read as 16-byte fragments, conflict free; V^T rows are read as
+  // 8-byte pieces by 32 lanes at once: a 136-byte pitch (34 dwords) spreads them over all 64 banks, the 144-byte
+  // pitch was a 2-way conflict (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.33)
+  constexpr int KS = HD + 8, VS = KV + 4;
   constexpr int KT = KV / 32, DT = HD / 32, NS = HD / 16;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[KV * KS];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[HD * VS];
@@ -187,7 +190,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_bf16_kernel(const 
     for (int i = 0; i < NVC; ++i) {
       const int idx = tid + 256 * i;
       const int row = idx / (KV / 8), c8 = idx % (KV / 8);
-      *reinterpret_cast<u32x4_t*>(&Vs[row * VS + c8 * 8]) = vreg[i];
+      typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;  // rows are only 8-byte aligned now
+      *reinterpret_cast<u32x2_t*>(&Vs[row * VS + c8 * 8]) = u32x2_t{vreg[i].x, vreg[i].y};
+      *reinterpret_cast<u32x2_t*>(&Vs[row * VS + c8 * 8 + 4]) = u32x2_t{vreg[i].z, vreg[i].w};
     }
     __syncthreads();
     // unconditional (a conditional fetch made hipcc keep kreg / vreg in scratch); past the end it re-reads the last tile

@@ -72,6 +72,16 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
 // One generic epilogue with every mode / activation / tail case inlined 32x per tile was ~50k instructions: its
 // straight-line path no longer fitted the instruction cache and cost ~8 us per 256x256 tile (as much as the K loop
 // at K = 1024).  Each variant below is a few hundred instructions.
+// XOR swizzle of the 16-byte chunk index inside a staged row of CPR chunks.  Power-of-two rows: row & (CPR-1).
+// CPR = 12 (256x192 tiles, 192-byte rows = 48 dwords): 48*row mod 64 only takes 4 values, so the chunk is rotated
+// inside its group of 4 by (row >> 2) - rows r, r+4, r+8, r+12 then land in different banks (the unswizzled layout
+// measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.38 for this tile shape, 0.06 for 256x256).
+template <int CPR> __device__ __forceinline__ int epi_swz(int row) {
+  if constexpr ((CPR & (CPR - 1)) == 0) return row & (CPR - 1);
+  else if constexpr (CPR % 4 == 0) return (row >> 2) & 3;
+  else return 0;
+}
+
 template <int ACT, bool FULL, bool BF16_OUT>
 __device__ __forceinline__ f32x4 epi_vals(f32x4 v, const GemmArgs& a, int n) {
   if (a.bias) {
@@ -110,7 +120,6 @@ __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], con
                                                 long mw0, int nw0, int lane) {
   constexpr int RB = TN * 64;    // staged row: TN*32 bf16
   constexpr int CPR = TN * 4;    // 16-byte chunks per row
-  constexpr int SWM = ((CPR & (CPR - 1)) == 0) ? CPR - 1 : 0;  // XOR swizzle of the chunk index (power-of-two rows)
   const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
@@ -127,7 +136,7 @@ __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], con
         pk.x = pack_bf16x2(v[0], v[1]);
         pk.y = pack_bf16x2(v[2], v[3]);
         const int ch = tn * 4 + rg;
-        *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ (l31 & SWM)) << 4) + 8 * h) = pk;
+        *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ epi_swz<CPR>(l31)) << 4) + 8 * h) = pk;
       }
     const long mw = mw0 + tm * 32;
 #pragma unroll
@@ -135,7 +144,7 @@ __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], con
       const int row = c / CPR, ch = c - row * CPR;
       const long m = mw + row;
       const int n = nw0 + ch * 8;
-      const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ (row & SWM)) << 4));
+      const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ epi_swz<CPR>(row)) << 4));
       if (a.dbg & 1) continue;
       bf16_t* dst = Cb + m * a.ldc + n;
       if (FULL) {
@@ -163,7 +172,6 @@ __device__ __forceinline__ void epi_staged_qkv(const f32x16 (&acc)[TN][TM], cons
                                                int lane) {
   constexpr int RB = TN * 64;
   constexpr int CPR = TN * 4;
-  constexpr int SWM = ((CPR & (CPR - 1)) == 0) ? CPR - 1 : 0;
   const int l31 = lane & 31, h = lane >> 5;
   const int D = a.heads * a.hd;
   const int which = nw0 / D;         // wave-uniform: D % (TN*32) == 0
@@ -191,13 +199,13 @@ __device__ __forceinline__ void epi_staged_qkv(const f32x16 (&acc)[TN][TM], cons
           pk.x = pack_bf16x2(v[0], v[1]);
           pk.y = pack_bf16x2(v[2], v[3]);
           const int ch = tn * 4 + rg;
-          *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ (l31 & SWM)) << 4) + 8 * h) = pk;
+          *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ epi_swz<CPR>(l31)) << 4) + 8 * h) = pk;
         }
       bf16_t* dstb = reinterpret_cast<bf16_t*>(which == 0 ? a.q : a.k);
 #pragma unroll
       for (int c = lane; c < 32 * CPR; c += 64) {
         const int row = c / CPR, ch = c - row * CPR;
-        const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ (row & SWM)) << 4));
+        const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ epi_swz<CPR>(row)) << 4));
         const int nr = nrel + ch * 8;
         const int head = nr / a.hd, d = nr - head * a.hd;
         if (qt0 + row >= a.ntok || (a.dbg & 1)) continue;  // padding rows stay zero
