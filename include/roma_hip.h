@@ -106,6 +106,16 @@ int roma_op_refiner_block(const void* in, void* out, const float* dw_w, const fl
  * density[i] = sum_j exp(-|x_i - x_{j*down}|^2 / (2 std^2)), x: DEVICE [n,4] f32.  half_inputs != 0 rounds the
  * coordinates to fp16 first (the reference's x.half()); accumulation is f32. */
 int roma_op_kde(const float* x, long n, int down, float std, int half_inputs, float* density, void* stream);
+/* RegressionMatcher.match_keypoints (matcher.py:732-773), all pointers DEVICE:
+ * sample_warp_at: xa_to_b[i] = bilinear(warp[..., 2:4], xa[i]), cert_a[i] = bilinear(cert, xa[i])  (zeros padding,
+ *   align_corners=False); warp [H,W,4] f32, cert [H,W] f32, xa [n,2] normalised (x,y).
+ * mutual_nn: match_b[i] = j if b[j] is the nearest neighbour of a[i], a[i] is at the column-minimum distance of
+ *   b[j], cert_a[i] > cert_th (cert_a may be NULL) and |a[i]-b[j]| < max_dist; else -1.  Row ties resolve to the
+ *   lowest j (the reference returns every tied pair).  ws_a / ws_b: 8*na / 8*nb byte workspaces. */
+int roma_op_sample_warp_at(const float* warp, const float* cert, int H, int W, const float* xa, long n, float* xa_to_b,
+                           float* cert_a, void* stream);
+int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
+                      int* match_b, void* ws_a, void* ws_b, void* stream);
 int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream);
 int roma_op_conv3x3_c3(const float* img, const float* w, const float* bias, void* out, int B, int H, int W, int dt_out,
                        void* stream);

@@ -376,3 +376,13 @@ def sample(matches, certainty, num=10000, sample_mode="threshold_balanced", samp
     p[density < 10] = 1e-7
     bal = torch.multinomial(p, num_samples=min(num, len(good_certainty)), replacement=False, generator=generator)
     return good_matches[bal], good_certainty[bal]
+
+
+def match_keypoints(x_A, x_B, warp, certainty, max_dist=0.005, cert_th=0):
+    """RegressionMatcher.match_keypoints - romatch/models/matcher.py:732-773; returns (inds_A, inds_B)."""
+    x_A_to_B = F.grid_sample(warp[..., -2:].permute(2, 0, 1)[None], x_A[None, None], align_corners=False,
+                             mode="bilinear")[0, :, 0].mT
+    cert_A_to_B = F.grid_sample(certainty[None, None, ...], x_A[None, None], align_corners=False, mode="bilinear")[0, 0, 0]
+    D = torch.cdist(x_A_to_B, x_B)
+    return torch.nonzero((D == D.min(dim=-1, keepdim=True).values) * (D == D.min(dim=-2, keepdim=True).values)
+                         * (cert_A_to_B[:, None] > cert_th) * (D < max_dist), as_tuple=True)

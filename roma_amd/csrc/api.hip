@@ -12,6 +12,7 @@
 #include "model.h"
 #include "refiner_block.h"
 #include "kde.h"
+#include "keypoints.h"
 
 namespace roma {
 static thread_local std::string g_err;
@@ -239,6 +240,17 @@ int roma_op_refiner_block(const void* in, void* out, const float* dw_w, const fl
 
 int roma_op_kde(const float* x, long n, int down, float std, int half_inputs, float* density, void* stream) {
   return kde_launch(x, n, down, std, half_inputs, density, S(stream));
+}
+
+int roma_op_sample_warp_at(const float* warp, const float* cert, int H, int W, const float* xa, long n, float* xa_to_b,
+                           float* cert_a, void* stream) {
+  return sample_warp_at_launch(warp, cert, H, W, xa, n, xa_to_b, cert_a, S(stream));
+}
+
+int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
+                      int* match_b, void* ws_a, void* ws_b, void* stream) {
+  return mutual_nn_launch(a, na, b, nb, cert_a, cert_th, max_dist, match_b, static_cast<unsigned long long*>(ws_a),
+                          static_cast<unsigned long long*>(ws_b), S(stream));
 }
 
 int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream) {

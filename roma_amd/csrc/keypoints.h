@@ -1,0 +1,14 @@
+// RegressionMatcher.match_keypoints (romatch/models/matcher.py:732-773) on the device:
+//   1. sample_warp_at: x_A_to_B = grid_sample(warp[..., 2:4], x_A), cert_A = grid_sample(certainty, x_A)
+//      (bilinear, zeros padding, align_corners=False - the same tap rule as the refiner warp);
+//   2. mutual_nn: mutual nearest neighbours between x_A_to_B and x_B within max_dist, certainty above cert_th.
+#pragma once
+#include "common.h"
+
+namespace roma {
+int sample_warp_at_launch(const float* warp, const float* cert, int H, int W, const float* xa, long n, float* xa_to_b,
+                          float* cert_a, hipStream_t s);
+// match_b[i] = j (index into b) or -1.  ws_a / ws_b: 8-byte workspaces of na / nb entries.
+int mutual_nn_launch(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
+                     int* match_b, unsigned long long* ws_a, unsigned long long* ws_b, hipStream_t s);
+}  // namespace roma

@@ -1,0 +1,127 @@
+// Keypoint matching helpers (see keypoints.h).  All-pairs work of at most ~1e8 pairs: VALU bound, microseconds.
+#include "keypoints.h"
+
+namespace roma {
+
+// ------------------------------------------------------------------ bilinear sampling of (warp_B, certainty) at points
+__global__ __launch_bounds__(256) void sample_warp_at_kernel(const float* __restrict__ warp, const float* __restrict__ cert,
+                                                             int H, int W, const float* __restrict__ xa, long n,
+                                                             float* __restrict__ xa_to_b, float* __restrict__ cert_a) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gx = xa[i * 2 + 0], gy = xa[i * 2 + 1];
+  float ix = ((gx + 1.f) * W - 1.f) * 0.5f, iy = ((gy + 1.f) * H - 1.f) * 0.5f;  // align_corners=False
+  ix = fminf(fmaxf(ix, -1.0e6f), 1.0e6f);
+  iy = fminf(fmaxf(iy, -1.0e6f), 1.0e6f);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float tx = ix - fx0, ty = iy - fy0;
+  const float wgt[4] = {(1.f - tx) * (1.f - ty), tx * (1.f - ty), (1.f - tx) * ty, tx * ty};
+  float bx = 0.f, by = 0.f, c = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {  // zeros padding
+      const long p = (long)yy * W + xx;
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(warp + p * 4);
+      bx += wgt[t] * w4[2];
+      by += wgt[t] * w4[3];
+      c += wgt[t] * cert[p];
+    }
+  }
+  xa_to_b[i * 2 + 0] = bx;
+  xa_to_b[i * 2 + 1] = by;
+  cert_a[i] = c;
+}
+
+int sample_warp_at_launch(const float* warp, const float* cert, int H, int W, const float* xa, long n, float* xa_to_b,
+                          float* cert_a, hipStream_t s) {
+  if (n == 0) return 0;
+  ROMA_REQUIRE(warp && cert && xa && xa_to_b && cert_a && H > 0 && W > 0 && n > 0, "sample_warp_at: bad arguments");
+  ROMA_REQUIRE((reinterpret_cast<uintptr_t>(warp) & 15) == 0, "sample_warp_at: warp must be 16-byte aligned [H,W,4] f32");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sample_warp_at_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, warp, cert, H, W, xa, n,
+                     xa_to_b, cert_a);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ nearest neighbour of every p_i in q (squared distance)
+// best[i] = (float bits of min d2) << 32 | argmin j  (d2 >= 0, so the integer order is the numeric order and ties
+// resolve to the lowest j); slices of q are merged with a 64-bit atomicMin.
+__global__ __launch_bounds__(256) void nn_kernel(const float* __restrict__ p, long np, const float* __restrict__ q, long nq,
+                                                 unsigned long long* __restrict__ best, long q_per_slice) {
+  __shared__ float qs[1024 * 2];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  float px = 0.f, py = 0.f;
+  if (i < np) {
+    px = p[i * 2 + 0];
+    py = p[i * 2 + 1];
+  }
+  const long j_begin = (long)blockIdx.y * q_per_slice;
+  const long j_end = min(nq, j_begin + q_per_slice);
+  float bd = INFINITY;
+  unsigned bj = 0xffffffffu;
+  for (long j0 = j_begin; j0 < j_end; j0 += 1024) {
+    const int cnt = (int)min((long)1024, j_end - j0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt * 2; t += 256) qs[t] = q[j0 * 2 + t];
+    __syncthreads();
+    for (int t = 0; t < cnt; ++t) {
+      const float dx = px - qs[2 * t], dy = py - qs[2 * t + 1];
+      const float d2 = fmaf(dy, dy, dx * dx);
+      if (d2 < bd) {  // strict: the first (lowest) index wins ties
+        bd = d2;
+        bj = (unsigned)(j0 + t);
+      }
+    }
+  }
+  if (i < np && bj != 0xffffffffu)
+    atomicMin(best + i, ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)bj);
+}
+
+__global__ __launch_bounds__(256) void mutual_nn_finalize_kernel(const unsigned long long* __restrict__ best_a,
+                                                                 const unsigned long long* __restrict__ best_b, long na,
+                                                                 const float* __restrict__ cert_a, float cert_th,
+                                                                 float max_d2, int* __restrict__ match_b) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= na) return;
+  const unsigned long long ba = best_a[i];
+  const unsigned j = (unsigned)(ba & 0xffffffffull);
+  const unsigned d2bits = (unsigned)(ba >> 32);
+  int out = -1;
+  if (j != 0xffffffffu) {
+    // (D == row min) * (D == column min) * (certainty > th) * (D < max_dist)   (matcher.py:756-762)
+    const bool col_min = (unsigned)(best_b[j] >> 32) == d2bits;
+    const bool cert_ok = cert_a == nullptr || cert_a[i] > cert_th;
+    if (col_min && cert_ok && __uint_as_float(d2bits) < max_d2) out = (int)j;
+  }
+  match_b[i] = out;
+}
+
+int mutual_nn_launch(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
+                     int* match_b, unsigned long long* ws_a, unsigned long long* ws_b, hipStream_t s) {
+  if (na == 0) return 0;
+  ROMA_REQUIRE(a && match_b && ws_a && ws_b && na > 0 && nb >= 0 && (b || nb == 0), "mutual_nn: bad arguments");
+  ROMA_REQUIRE(na < (1l << 31) && nb < (1l << 31), "mutual_nn: too many points");
+  if (na == 0) return 0;
+  ROMA_CHECK_HIP(hipMemsetAsync(ws_a, 0xff, (size_t)na * 8, s));
+  if (nb > 0) ROMA_CHECK_HIP(hipMemsetAsync(ws_b, 0xff, (size_t)nb * 8, s));
+  auto run = [&](const float* p, long np, const float* q, long nq, unsigned long long* best) {
+    const long pblocks = (np + 255) / 256;
+    long slices = std::max<long>(1, std::min<long>((nq + 1023) / 1024, (1024 + pblocks - 1) / pblocks));
+    const long per = (((nq + slices - 1) / slices) + 1023) / 1024 * 1024;
+    slices = (nq + per - 1) / per;
+    hipLaunchKernelGGL(nn_kernel, dim3((unsigned)pblocks, (unsigned)slices), dim3(256), 0, s, p, np, q, nq, best, per);
+  };
+  if (nb > 0) {
+    run(a, na, b, nb, ws_a);
+    run(b, nb, a, na, ws_b);
+  }
+  hipLaunchKernelGGL(mutual_nn_finalize_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, s, ws_a, ws_b, na, cert_a,
+                     cert_th, max_dist * max_dist, match_b);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace roma

@@ -263,6 +263,48 @@ class RegressionMatcher:
         balanced_samples = torch.multinomial(p, num_samples=min(num, len(good_certainty)), replacement=False)
         return good_matches[balanced_samples], good_certainty[balanced_samples]
 
+    # ------------------------------------------------------------------ keypoint matching (matcher.py:732-773)
+    def match_keypoints(self, x_A, x_B, warp, certainty, return_tuple=True, return_inds=False, max_dist=0.005, cert_th=0):
+        """Mutual-nearest-neighbour matching of detector keypoints through the dense warp.
+
+        x_A [Na,2], x_B [Nb,2] normalised (x,y); warp [H,W,4] / certainty [H,W] of ONE pair (as returned by match() with
+        the batch dimension removed).  `roma_op_sample_warp_at` + `roma_op_mutual_nn` replace the reference's
+        grid_sample + Na x Nb cdist matrix; a keypoint of A tied between several nearest B keypoints yields one pair
+        (lowest index) where the reference yields all of them."""
+        for t in (x_A, x_B, warp, certainty):
+            if not t.is_cuda:
+                raise _lib.RomaHipError("match_keypoints: tensors must live on a HIP device; there is no CPU fallback")
+        lib = _lib.load()
+        H, W = int(warp.shape[0]), int(warp.shape[1])
+        if warp.dim() != 3 or warp.shape[2] != 4 or tuple(certainty.shape) != (H, W):
+            raise ValueError("match_keypoints: expected warp [H,W,4] and certainty [H,W]")
+        w = warp.detach().to(torch.float32).contiguous()
+        c = certainty.detach().to(torch.float32).contiguous()
+        xa = x_A.detach().to(torch.float32).contiguous()
+        xb = x_B.detach().to(torch.float32).contiguous()
+        na, nb = xa.shape[0], xb.shape[0]
+        dev = xa.device
+        xab = torch.empty((na, 2), device=dev, dtype=torch.float32)
+        ca = torch.empty((na,), device=dev, dtype=torch.float32)
+        match_b = torch.empty((na,), device=dev, dtype=torch.int32)
+        ws_a = torch.empty((max(na, 1),), device=dev, dtype=torch.int64)
+        ws_b = torch.empty((max(nb, 1),), device=dev, dtype=torch.int64)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(dev):
+            _lib.check(lib.roma_op_sample_warp_at(P(w), P(c), H, W, P(xa), na, P(xab), P(ca), stream))
+            _lib.check(lib.roma_op_mutual_nn(P(xab), na, P(xb), nb, P(ca), float(cert_th), float(max_dist), P(match_b),
+                                             P(ws_a), P(ws_b), stream))
+        inds_A = torch.nonzero(match_b >= 0, as_tuple=True)[0]
+        inds_B = match_b[inds_A].to(torch.int64)
+        if return_tuple:
+            if return_inds:
+                return inds_A, inds_B
+            return x_A[inds_A], x_B[inds_B]
+        if return_inds:
+            return torch.cat((inds_A, inds_B), dim=-1)
+        return torch.cat((x_A[inds_A], x_B[inds_B]), dim=-1)
+
     # ------------------------------------------------------------------ light post-processing helpers (torch)
     def to_pixel_coordinates(self, coords, H_A, W_A, H_B=None, W_B=None):
         """matcher.py:701-717."""

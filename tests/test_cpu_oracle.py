@@ -117,6 +117,16 @@ def test_oracle_sample_semantics():
     assert all(tuple(np.round(r, 6)) in src for r in m.numpy().tolist())
 
 
+def test_oracle_match_keypoints_vs_reference_golden():
+    """oracle.match_keypoints against RegressionMatcher.match_keypoints of the reference (index-exact)."""
+    from oracle import roma_oracle as O
+    g = np.load(os.path.join(GOLDEN, "keypoints_reference.npz"))
+    t = {k: torch.from_numpy(g[k]) for k in ("warp", "cert", "x_A", "x_B")}
+    for name, kw in (("default", {}), ("loose", dict(max_dist=0.02, cert_th=0.6))):
+        iA, iB = O.match_keypoints(t["x_A"], t["x_B"], t["warp"], t["cert"], **kw)
+        assert np.array_equal(iA.numpy(), g["inds_A_" + name]) and np.array_equal(iB.numpy(), g["inds_B_" + name]), name
+
+
 def test_library_exports_every_declared_symbol(built_lib):
     """include/roma_hip.h <-> libroma_hip.so <-> ctypes table: same symbol set; no compute without a GPU."""
     from roma_amd import _lib

@@ -375,3 +375,26 @@ def test_sample_distribution_matches_oracle():
     assert gm.shape == (500, 4)
     vals = set(np.unique(gc.cpu().numpy()).tolist())
     assert vals <= {1.0, np.float32(0.01).item()}
+
+
+def test_match_keypoints_vs_reference_golden():
+    """RegressionMatcher.match_keypoints through roma_op_sample_warp_at + roma_op_mutual_nn: index-exact against the
+    reference's own output (tests/golden/keypoints_reference.npz) for both parameter sets, plus the return variants."""
+    from roma_amd.matcher import RegressionMatcher
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "keypoints_reference.npz"))
+    t = {k: torch.from_numpy(g[k]).cuda() for k in ("warp", "cert", "x_A", "x_B")}
+    m = RegressionMatcher.__new__(RegressionMatcher)
+    for name, kw in (("default", {}), ("loose", dict(max_dist=0.02, cert_th=0.6))):
+        iA, iB = m.match_keypoints(t["x_A"], t["x_B"], t["warp"], t["cert"], return_inds=True, **kw)
+        assert np.array_equal(iA.cpu().numpy(), g["inds_A_" + name]), name
+        assert np.array_equal(iB.cpu().numpy(), g["inds_B_" + name]), name
+    kA, kB = m.match_keypoints(t["x_A"], t["x_B"], t["warp"], t["cert"])
+    assert torch.equal(kA, t["x_A"][iA0 := torch.from_numpy(g["inds_A_default"]).cuda()]) and kB.shape == (len(iA0), 2)
+    cat = m.match_keypoints(t["x_A"], t["x_B"], t["warp"], t["cert"], return_tuple=False)
+    assert cat.shape == (len(iA0), 4)
+    with pytest.raises(Exception):
+        m.match_keypoints(t["x_A"].cpu(), t["x_B"], t["warp"], t["cert"])
+    # empty keypoint sets do not launch anything
+    e = m.match_keypoints(t["x_A"][:0], t["x_B"], t["warp"], t["cert"], return_inds=True)
+    assert len(e[0]) == 0 and len(e[1]) == 0

@@ -9,6 +9,7 @@ fixtures are what travels to the GPU box.  Usage:
     python tools/make_goldens.py small         # match() 224 -> 336, B=2, non-symmetric and symmetric coarse-only
     python tools/make_goldens.py full          # match() 560 -> 864, B=1 symmetric (sub-sampled)
     python tools/make_goldens.py kde           # romatch.utils.kde.kde on seeded match-like points
+    python tools/make_goldens.py keypoints     # RegressionMatcher.match_keypoints on a seeded warp + keypoints
 """
 import json
 import os
@@ -190,6 +191,30 @@ def kde_golden():
     print({k: (v.shape, float(v.min()), float(v.max())) for k, v in out.items()})
 
 
+def keypoints_golden():
+    """Reference RegressionMatcher.match_keypoints on a seeded smooth warp and jittered keypoint sets."""
+    install_stubs()
+    from romatch.models.matcher import RegressionMatcher
+    g = torch.Generator().manual_seed(11)
+    H, W = 96, 128
+    ys, xs = torch.meshgrid(torch.linspace(-1 + 1 / H, 1 - 1 / H, H), torch.linspace(-1 + 1 / W, 1 - 1 / W, W), indexing="ij")
+    bx = 0.9 * xs + 0.08 * torch.sin(3.0 * ys) + 0.03
+    by = 0.85 * ys - 0.06 * torch.cos(2.0 * xs) - 0.02
+    warp = torch.stack([xs, ys, bx, by], dim=-1)
+    cert = torch.sigmoid(4.0 * (1.0 - (xs ** 2 + ys ** 2)))  # confident in the centre
+    na, nb = 700, 900
+    x_A = torch.rand(na, 2, generator=g) * 1.9 - 0.95
+    wA = torch.nn.functional.grid_sample(warp[..., 2:].permute(2, 0, 1)[None], x_A[None, None], align_corners=False)[0, :, 0].mT
+    x_B = torch.cat([wA[:500] + 0.002 * torch.randn(500, 2, generator=g), torch.rand(nb - 500, 2, generator=g) * 2 - 1])
+    x_B = x_B[torch.randperm(nb, generator=g)]
+    out = dict(warp=np32(warp), cert=np32(cert), x_A=np32(x_A), x_B=np32(x_B))
+    for name, kw in (("default", {}), ("loose", dict(max_dist=0.02, cert_th=0.6))):
+        iA, iB = RegressionMatcher.match_keypoints(None, x_A, x_B, warp, cert, return_tuple=True, return_inds=True, **kw)
+        out["inds_A_" + name], out["inds_B_" + name] = iA.numpy().astype(np.int64), iB.numpy().astype(np.int64)
+        print(name, len(iA))
+    np.savez_compressed(os.path.join(GOLD, "keypoints_reference.npz"), **out)
+
+
 if __name__ == "__main__":
     for what in sys.argv[1:]:
-        {"contract": contract, "ops": ops, "tiny": tiny, "small": small, "full": full, "kde": kde_golden}[what]()
+        {"contract": contract, "ops": ops, "tiny": tiny, "small": small, "full": full, "kde": kde_golden, "keypoints": keypoints_golden}[what]()
