@@ -116,6 +116,11 @@ int roma_op_sample_warp_at(const float* warp, const float* cert, int H, int W, c
                            float* cert_a, void* stream);
 int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
                       int* match_b, void* ws_a, void* ws_b, void* stream);
+/* conf_from_fb_consistency (matcher.py:672-699): out[b,y,x] = 1 if the backward flow sampled (bilinear, zeros padding,
+ * align_corners=False) at the forward flow's target returns to within th_n of pixel (x,y)'s own normalised
+ * coordinate, else 0.  flows DEVICE [B,H,W,2] f32, out [B,H,W] f32; th_n = 2*th / max(H,W). */
+int roma_op_fb_consistency(const float* flow_fwd, const float* flow_bwd, int B, int H, int W, float th_n, float* out,
+                           void* stream);
 int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream);
 int roma_op_conv3x3_c3(const float* img, const float* w, const float* bias, void* out, int B, int H, int W, int dt_out,
                        void* stream);

@@ -386,3 +386,13 @@ def match_keypoints(x_A, x_B, warp, certainty, max_dist=0.005, cert_th=0):
     D = torch.cdist(x_A_to_B, x_B)
     return torch.nonzero((D == D.min(dim=-1, keepdim=True).values) * (D == D.min(dim=-2, keepdim=True).values)
                          * (cert_A_to_B[:, None] > cert_th) * (D < max_dist), as_tuple=True)
+
+
+def conf_from_fb_consistency(flow_forward, flow_backward, th=2):
+    """RegressionMatcher.conf_from_fb_consistency - romatch/models/matcher.py:672-699 (batched [B,H,W,2] flows)."""
+    H, W = flow_forward.shape[-3:-1]
+    th_n = 2 * th / max(H, W)
+    coords = torch.stack(torch.meshgrid(torch.linspace(-1 + 1 / W, 1 - 1 / W, W), torch.linspace(-1 + 1 / H, 1 - 1 / H, H),
+                                        indexing="xy"), dim=-1)
+    coords_fb = F.grid_sample(flow_backward.permute(0, 3, 1, 2), flow_forward, align_corners=False, mode="bilinear").permute(0, 2, 3, 1)
+    return ((coords - coords_fb).norm(dim=-1) < th_n).float()

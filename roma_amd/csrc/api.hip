@@ -253,6 +253,11 @@ int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const fl
                           static_cast<unsigned long long*>(ws_b), S(stream));
 }
 
+int roma_op_fb_consistency(const float* flow_fwd, const float* flow_bwd, int B, int H, int W, float th_n, float* out,
+                           void* stream) {
+  return fb_consistency_launch(flow_fwd, flow_bwd, B, H, W, th_n, out, S(stream));
+}
+
 int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream) {
   return maxpool2x2_launch(in, out, B, H, W, C, DT(dt), S(stream));
 }

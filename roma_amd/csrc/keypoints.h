@@ -11,4 +11,7 @@ int sample_warp_at_launch(const float* warp, const float* cert, int H, int W, co
 // match_b[i] = j (index into b) or -1.  ws_a / ws_b: 8-byte workspaces of na / nb entries.
 int mutual_nn_launch(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
                      int* match_b, unsigned long long* ws_a, unsigned long long* ws_b, hipStream_t s);
+// conf_from_fb_consistency (matcher.py:672-699): flows [B,H,W,2] f32 -> in_th [B,H,W] f32 (0 / 1)
+int fb_consistency_launch(const float* flow_fwd, const float* flow_bwd, int B, int H, int W, float th_n, float* out,
+                          hipStream_t s);
 }  // namespace roma

@@ -124,4 +124,48 @@ int mutual_nn_launch(const float* a, long na, const float* b, long nb, const flo
   return 0;
 }
 
+// ------------------------------------------------------------------ forward-backward consistency (matcher.py:672-699)
+// in_th[b,y,x] = || grid(x,y) - bilinear_zeropad(flow_backward[b], flow_forward[b,y,x]) || < th_n
+__global__ __launch_bounds__(256) void fb_consistency_kernel(const float* __restrict__ ff, const float* __restrict__ fb,
+                                                             int B, int H, int W, float th_n, float* __restrict__ out) {
+  const long total = (long)B * H * W;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  const long r = idx / W;
+  const int y = (int)(r % H);
+  const long b = r / H;
+  const float gx = ff[idx * 2 + 0], gy = ff[idx * 2 + 1];
+  float ix = ((gx + 1.f) * W - 1.f) * 0.5f, iy = ((gy + 1.f) * H - 1.f) * 0.5f;
+  ix = fminf(fmaxf(ix, -1.0e6f), 1.0e6f);
+  iy = fminf(fmaxf(iy, -1.0e6f), 1.0e6f);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float tx = ix - fx0, ty = iy - fy0;
+  const float wgt[4] = {(1.f - tx) * (1.f - ty), tx * (1.f - ty), (1.f - tx) * ty, tx * ty};
+  float cx = 0.f, cy = 0.f;
+  const float* fbb = fb + b * (long)H * W * 2;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      const long p = ((long)yy * W + xx) * 2;
+      cx += wgt[t] * fbb[p];
+      cy += wgt[t] * fbb[p + 1];
+    }
+  }
+  const float dx = (-1.f + (2.f * x + 1.f) / W) - cx, dy = (-1.f + (2.f * y + 1.f) / H) - cy;
+  out[idx] = sqrtf(dx * dx + dy * dy) < th_n ? 1.f : 0.f;
+}
+
+int fb_consistency_launch(const float* flow_fwd, const float* flow_bwd, int B, int H, int W, float th_n, float* out,
+                          hipStream_t s) {
+  ROMA_REQUIRE(flow_fwd && flow_bwd && out && B > 0 && H > 0 && W > 0, "fb_consistency: bad arguments");
+  const long total = (long)B * H * W;
+  hipLaunchKernelGGL(fb_consistency_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, flow_fwd, flow_bwd, B, H, W,
+                     th_n, out);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace roma

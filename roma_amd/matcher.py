@@ -305,6 +305,22 @@ class RegressionMatcher:
             return torch.cat((inds_A, inds_B), dim=-1)
         return torch.cat((x_A[inds_A], x_B[inds_B]), dim=-1)
 
+    def conf_from_fb_consistency(self, flow_forward, flow_backward, th=2):
+        """matcher.py:672-699: 1 where the backward flow maps the forward target back to within `th` pixels."""
+        for t in (flow_forward, flow_backward):
+            if not t.is_cuda:
+                raise _lib.RomaHipError("conf_from_fb_consistency: tensors must live on a HIP device; there is no CPU fallback")
+        has_batch = flow_forward.dim() != 3
+        ff = (flow_forward if has_batch else flow_forward[None]).detach().to(torch.float32).contiguous()
+        fb = (flow_backward if has_batch else flow_backward[None]).detach().to(torch.float32).contiguous()
+        B, H, W = int(ff.shape[0]), int(ff.shape[-3]), int(ff.shape[-2])
+        out = torch.empty((B, H, W), device=ff.device, dtype=torch.float32)
+        with torch.cuda.device(ff.device):
+            _lib.check(_lib.load().roma_op_fb_consistency(C.c_void_p(ff.data_ptr()), C.c_void_p(fb.data_ptr()), B, H, W,
+                                                          float(2 * th / max(H, W)), C.c_void_p(out.data_ptr()),
+                                                          C.c_void_p(torch.cuda.current_stream(ff.device).cuda_stream)))
+        return out if has_batch else out[0]
+
     # ------------------------------------------------------------------ light post-processing helpers (torch)
     def to_pixel_coordinates(self, coords, H_A, W_A, H_B=None, W_B=None):
         """matcher.py:701-717."""

@@ -398,3 +398,25 @@ def test_match_keypoints_vs_reference_golden():
     # empty keypoint sets do not launch anything
     e = m.match_keypoints(t["x_A"][:0], t["x_B"], t["warp"], t["cert"], return_inds=True)
     assert len(e[0]) == 0 and len(e[1]) == 0
+
+
+def test_fb_consistency_vs_oracle():
+    """conf_from_fb_consistency on the device vs the oracle restatement (matcher.py:672-699).  The output is a hard
+    threshold: pixels whose round-trip error is within 1e-5 of the threshold are excluded from the comparison."""
+    from roma_amd.matcher import RegressionMatcher
+    from oracle import roma_oracle as O
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 48, 64
+    ys, xs = torch.meshgrid(torch.linspace(-1 + 1 / H, 1 - 1 / H, H), torch.linspace(-1 + 1 / W, 1 - 1 / W, W), indexing="ij")
+    grid = torch.stack([xs, ys], dim=-1)[None].repeat(B, 1, 1, 1)
+    fwd = grid + 0.05 * torch.sin(3 * grid.flip(-1)) + 0.02 * torch.randn(B, H, W, 2, generator=g)
+    bwd = grid - 0.05 * torch.sin(3 * grid.flip(-1)) + 0.02 * torch.randn(B, H, W, 2, generator=g)
+    ref = O.conf_from_fb_consistency(fwd, bwd, th=2)
+    coords_fb = F.grid_sample(bwd.permute(0, 3, 1, 2), fwd, align_corners=False).permute(0, 2, 3, 1)
+    margin = ((grid - coords_fb).norm(dim=-1) - 2 * 2 / max(H, W)).abs()
+    m = RegressionMatcher.__new__(RegressionMatcher)
+    got = m.conf_from_fb_consistency(fwd.cuda(), bwd.cuda(), th=2).cpu()
+    assert got.shape == (B, H, W) and 0.2 < float(ref.mean()) < 0.98
+    assert torch.equal(got[margin > 1e-5], ref[margin > 1e-5])
+    one = m.conf_from_fb_consistency(fwd[0].cuda(), bwd[0].cuda(), th=2).cpu()
+    assert one.shape == (H, W) and torch.equal(one, got[0])
