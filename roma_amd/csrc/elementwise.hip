@@ -1055,7 +1055,8 @@ __global__ __launch_bounds__(256) void refiner_out_vec_kernel(const T* d, long l
   }
   const float b0 = bb[0], b1 = bb[1], b2 = bb[2];
   const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw * rows_it + rw;
-  for (int it = 0; it < rows_it; ++it) {
+#pragma unroll 4
+  for (int it = 0; it < rows_it; ++it) {  // unrolled: the loads of 4 row groups are in flight together
     const long row = row0 + (long)it * rpw;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     if (row < M) {
