@@ -27,259 +27,11 @@
 
 namespace roma {
 
-constexpr int ROWB = 128;  // bytes per LDS row = 8 chunks of 16 B
+}  // namespace roma
 
-template <typename T> struct InTraits;
-template <> struct InTraits<float> { static constexpr int CE = 4; };
-template <> struct InTraits<bf16_t> { static constexpr int CE = 8; };
+#include "gemm_device.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-
-__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
-
-__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-// Same function for bf16 outputs: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the 2^-9 relative
-// rounding of the bf16 store) - one v_rcp, one v_exp and 8 FMAs instead of libm's ~45-instruction branchy erff,
-// which cost 27% of the fc1 GEMM (128 values per lane per tile).
-__device__ __forceinline__ float gelu_erf_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-  const float erf_abs = fmaf(-p * t, e, 1.0f);
-  return 0.5f * x + 0.5f * fabsf(x) * erf_abs;  // x * erf(x/sqrt2) = |x| * erf(|x|/sqrt2)
-}
-
-template <typename TOUT> __device__ inline void store4(TOUT* p, f32x4 v, bool vec, int nvalid) {
-  if (vec && nvalid >= 4) {
-    ElemIO<TOUT>::st4(p, v);
-  } else {
-    for (int j = 0; j < 4; ++j)
-      if (j < nvalid) ElemIO<TOUT>::st(p + j, v[j]);
-  }
-}
-
-__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Plain (EPI_STD) epilogues, specialised at compile time on the activation and on "tile completely inside M x N".
-// One generic epilogue with every mode / activation / tail case inlined 32x per tile was ~50k instructions: its
-// straight-line path no longer fitted the instruction cache and cost ~8 us per 256x256 tile (as much as the K loop
-// at K = 1024).  Each variant below is a few hundred instructions.
-// XOR swizzle of the 16-byte chunk index inside a staged row of CPR chunks.  Power-of-two rows: row & (CPR-1).
-// CPR = 12 (256x192 tiles, 192-byte rows = 48 dwords): 48*row mod 64 only takes 4 values, so the chunk is rotated
-// inside its group of 4 by (row >> 2) - rows r, r+4, r+8, r+12 then land in different banks (the unswizzled layout
-// measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.38 for this tile shape, 0.06 for 256x256).
-template <int CPR> __device__ __forceinline__ int epi_swz(int row) {
-  if constexpr ((CPR & (CPR - 1)) == 0) return row & (CPR - 1);
-  else if constexpr (CPR % 4 == 0) return (row >> 2) & 3;
-  else return 0;
-}
-
-template <int ACT, bool FULL, bool BF16_OUT>
-__device__ __forceinline__ f32x4 epi_vals(f32x4 v, const GemmArgs& a, int n) {
-  if (a.bias) {
-    if (FULL || n + 3 < a.N) {
-      v += *reinterpret_cast<const f32x4*>(a.bias + n);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (n + j < a.N) v[j] += a.bias[n + j];
-    }
-  }
-  if (ACT == ACT_RELU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-  } else if (ACT == ACT_GELU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = BF16_OUT ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
-  }
-  if (a.scale) {
-    if (FULL || n + 3 < a.N) {
-      v *= *reinterpret_cast<const f32x4*>(a.scale + n);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (n + j < a.N) v[j] *= a.scale[n + j];
-    }
-  }
-  return v;
-}
-
-// bf16 output: the MFMA layout gives each lane 4 consecutive n of ONE row, i.e. a wave store would scatter 8-byte
-// pieces over 32 rows (measured 0.56 TB/s).  Stage the wave's tile through its private LDS slice instead and write
-// whole rows: 16 B per lane, 128..384 contiguous bytes per row.  (One wave's LDS operations complete in order.)
-template <int TM, int TN, int ACT, bool FULL>
-__device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], const GemmArgs& a, bf16_t* Cb, char* ws,
-                                                long mw0, int nw0, int lane) {
-  constexpr int RB = TN * 64;    // staged row: TN*32 bf16
-  constexpr int CPR = TN * 4;    // 16-byte chunks per row
-  const int l31 = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int n = nw0 + tn * 32 + 8 * rg + 4 * h;
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = a.alpha * acc[tn][tm][4 * rg + j];
-        v = epi_vals<ACT, FULL, true>(v, a, n);
-        uint2 pk;
-        pk.x = pack_bf16x2(v[0], v[1]);
-        pk.y = pack_bf16x2(v[2], v[3]);
-        const int ch = tn * 4 + rg;
-        *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ epi_swz<CPR>(l31)) << 4) + 8 * h) = pk;
-      }
-    const long mw = mw0 + tm * 32;
-#pragma unroll
-    for (int c = lane; c < 32 * CPR; c += 64) {
-      const int row = c / CPR, ch = c - row * CPR;
-      const long m = mw + row;
-      const int n = nw0 + ch * 8;
-      const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ epi_swz<CPR>(row)) << 4));
-      if (a.dbg & 1) continue;
-      bf16_t* dst = Cb + m * a.ldc + n;
-      if (FULL) {
-        *reinterpret_cast<uint4*>(dst) = v;
-      } else {
-        if (m >= a.M || n >= a.N) continue;
-        if (n + 8 <= a.N) {
-          *reinterpret_cast<uint4*>(dst) = v;
-        } else {
-          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
-          for (int j = 0; j < 8; ++j)
-            if (n + j < a.N) dst[j] = e[j];
-        }
-      }
-    }
-  }
-}
-
-// EPI_QKV with bf16 outputs.  The GEMM rows are padded to npad tokens per image (gemm_launch), so every 32-row MFMA
-// block lies inside one image at a 32-aligned token: q / k rows are written like the plain staged epilogue (one head
-// = 2*hd contiguous bytes per token), and V is staged TRANSPOSED ([d][token]) so that V^T leaves as 16-byte pieces of
-// 8 consecutive tokens instead of single bf16 elements.
-template <int TM, int TN>
-__device__ __forceinline__ void epi_staged_qkv(const f32x16 (&acc)[TN][TM], const GemmArgs& a, char* ws, long mw0, int nw0,
-                                               int lane) {
-  constexpr int RB = TN * 64;
-  constexpr int CPR = TN * 4;
-  const int l31 = lane & 31, h = lane >> 5;
-  const int D = a.heads * a.hd;
-  const int which = nw0 / D;         // wave-uniform: D % (TN*32) == 0
-  const int nrel = nw0 - which * D;  // first column of this wave inside q / k / v
-  const float sc = which == 0 ? a.qscale : 1.0f;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const long mw = mw0 + tm * 32;
-    if (mw >= a.M) continue;
-    const int qb = (int)(mw / a.npad);
-    const int qt0 = (int)(mw - (long)qb * a.npad);
-    if (qt0 >= a.ntok) continue;  // block of padding rows only
-    if (which < 2) {
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int n = nw0 + tn * 32 + 8 * rg + 4 * h;
-          f32x4 v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][4 * rg + j];
-          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-          v *= sc;
-          uint2 pk;
-          pk.x = pack_bf16x2(v[0], v[1]);
-          pk.y = pack_bf16x2(v[2], v[3]);
-          const int ch = tn * 4 + rg;
-          *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ epi_swz<CPR>(l31)) << 4) + 8 * h) = pk;
-        }
-      bf16_t* dstb = reinterpret_cast<bf16_t*>(which == 0 ? a.q : a.k);
-#pragma unroll
-      for (int c = lane; c < 32 * CPR; c += 64) {
-        const int row = c / CPR, ch = c - row * CPR;
-        const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ epi_swz<CPR>(row)) << 4));
-        const int nr = nrel + ch * 8;
-        const int head = nr / a.hd, d = nr - head * a.hd;
-        if (qt0 + row >= a.ntok || (a.dbg & 1)) continue;  // padding rows stay zero
-        *reinterpret_cast<uint4*>(dstb + (((long)qb * a.heads + head) * a.npad + qt0 + row) * a.hd + d) = v;
-      }
-    } else {
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int nl = tn * 32 + 8 * rg + 4 * h;
-          f32x4 v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][4 * rg + j];
-          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + nw0 + nl);
-          const uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
-          unsigned short* col = reinterpret_cast<unsigned short*>(ws + nl * 64 + l31 * 2);  // [d][token]
-          col[0] = (unsigned short)(p0 & 0xffffu);
-          col[32] = (unsigned short)(p0 >> 16);
-          col[64] = (unsigned short)(p1 & 0xffffu);
-          col[96] = (unsigned short)(p1 >> 16);
-        }
-      bf16_t* vt = reinterpret_cast<bf16_t*>(a.vt);
-#pragma unroll
-      for (int i = 0; i < TN * 2; ++i) {
-        const int u = lane + 64 * i;
-        const int dl = u >> 2, tg = u & 3;
-        const uint4 v = *reinterpret_cast<const uint4*>(ws + dl * 64 + tg * 16);
-        const int nr = nrel + dl;
-        const int head = nr / a.hd, d = nr - head * a.hd;
-        if (a.dbg & 1) continue;
-        *reinterpret_cast<uint4*>(vt + (((long)qb * a.heads + head) * a.hd + d) * a.npad + qt0 + tg * 8) = v;
-      }
-    }
-  }
-}
-
-// f32 output (+ optional f32 residual, which may alias C): same idea, one 32 x 32 MFMA block (4 KiB) at a time.
-// Direct stores from the MFMA layout touch 32 rows x 32 B per instruction; staged, a wave instruction covers
-// 8 rows x 128 contiguous bytes for both the residual read and the store.  Requires N % 4 == 0.
-template <int TM, int TN, int ACT, bool FULL>
-__device__ __forceinline__ void epi_staged_f32(const f32x16 (&acc)[TN][TM], const GemmArgs& a, float* Cb, const float* Rb,
-                                               char* ws, long mw0, int nw0, int lane) {
-  const int l31 = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int n = nw0 + tn * 32 + 8 * rg + 4 * h;
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = a.alpha * acc[tn][tm][4 * rg + j];
-        v = epi_vals<ACT, FULL, false>(v, a, n);
-        *reinterpret_cast<f32x4*>(ws + l31 * 128 + (((2 * rg + h) ^ (l31 & 7)) << 4)) = v;
-      }
-      const long mw = mw0 + tm * 32;
-      const int nw = nw0 + tn * 32;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = lane + 64 * i;
-        const int row = c >> 3, ch = c & 7;
-        f32x4 v = *reinterpret_cast<const f32x4*>(ws + row * 128 + ((ch ^ (row & 7)) << 4));
-        const long m = mw + row;
-        const int n = nw + ch * 4;
-        if (!FULL && (m >= a.M || n >= a.N)) continue;
-        if (Rb) v += *reinterpret_cast<const f32x4*>(Rb + m * a.ldr + n);
-        if (a.dbg & 1) continue;
-        *reinterpret_cast<f32x4*>(Cb + m * a.ldc + n) = v;
-      }
-    }
-  }
-}
+namespace roma {
 
 template <typename TIN, typename TOUT, int WM, int WN, int TM, int TN, bool CONV>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a) {
@@ -463,11 +215,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
   __builtin_amdgcn_sched_barrier(0);
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
   const unsigned aoff = (wm * TM) * 32 * ROWB, woff = BM * ROWB + (wn * TN) * 32 * ROWB;
+  // 8-wave tiles: the LAST k-group of a slab is multiplied only after the next slab's barrier (its fragments are
+  // carried in wvB / avB, zero for the first slab of a tile): those 8 MFMAs per wave are queued the moment the
+  // barrier opens and cover the DMA issue and the first fragment reads of the new slab, during which both waves of
+  // a SIMD used to leave the MFMA pipe idle (SQ counters: 39 % of the wave cycles parked).
+  // (bf16 only: the exact-f32 parity kernels keep the in-place order - with the carry they produced wrong sums, most
+  //  likely asynchronous asm-read fragments passing through a compiler-made copy; not worth chasing for that mode)
+  constexpr bool CARRY = sizeof(TIN) == 2;
+  uint4 wvA[TN], avA[TM], wvB[TN], avB[TM];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) wvB[tn] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) avB[tm] = make_uint4(0, 0, 0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = (bsel + kt) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (NWAVES == 8) {
+      if constexpr (CARRY) {
+        ROMA_MFMA_G(wvB, avB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // large MFMA-bound tiles: DMA first, fragments per k-group from inline asm (see above)
       // the next slab's DMA is issued in two bursts (A rows now, W rows after the first MFMA group): both waves of
       // a SIMD leave the barrier together, and a single 8-piece burst per wave kept the MFMA pipe idle behind the
@@ -489,7 +257,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
         continue;
       }
       const unsigned sb = lds0 + cur * BUF;
-      uint4 wvA[TN], avA[TM], wvB[TN], avB[TM];
       ROMA_READ_G(wvA, avA, 0);
       ROMA_READ_G(wvB, avB, 1);
       ROMA_WAIT_LGKM(TN + TM);
@@ -504,7 +271,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
       ROMA_WAIT_LGKM(TN + TM);
       ROMA_MFMA_G(wvA, avA);
       ROMA_WAIT_LGKM(0);
-      ROMA_MFMA_G(wvB, avB);
+      if constexpr (!CARRY) { ROMA_MFMA_G(wvB, avB); }
       __builtin_amdgcn_sched_barrier(0);
     } else {
       // small / HBM-bound tiles (4 waves, several workgroups per CU): compiler-scheduled reads of the whole slab,
@@ -531,6 +298,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
 #pragma unroll
       for (int g = 0; g < 4; ++g) ROMA_MFMA_G(wv[g], av[g]);
     }
+  }
+  if constexpr (NWAVES == 8 && CARRY) {
+    ROMA_MFMA_G(wvB, avB);  // the carried last k-group of the tile
   }
 #undef ROMA_WAIT_LGKM
 #undef ROMA_MFMA_G

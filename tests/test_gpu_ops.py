@@ -101,6 +101,34 @@ def test_gemm_bf16(lib, M, N, K):
     assert torch.allclose(outb.cpu().double(), ref, atol=0.02 * math.sqrt(K), rtol=1e-2)
 
 
+# ------------------------------------------------------------------ ping-pong GEMM (gemm_pp.hip): big-M bf16 shapes
+@pytest.mark.parametrize("M,N,K", [(8192 + 37, 640, 192), (8448, 512, 64), (70000, 1024, 128), (9000, 768, 1024), (25616, 1024, 4096)])
+def test_gemm_pingpong_bf16(lib, M, N, K):
+    """Shapes that gemm_dispatch routes to the staggered-wave-row kernel: ragged last m-tile, partial n-tile (640),
+    a single K slab, several tiles per persistent workgroup (70000 x 1024), long K.  Run twice: the second launch
+    re-uses a warm instruction cache / different timing (race screen)."""
+    A, W, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, std=K ** -0.5).bfloat16(), rnd(N, seed=3)
+    ref = A.double() @ W.double().T + b.double()
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    for _ in range(2):
+        out = gemm(lib, Ad, Wd, bias=bd, dt_in=BF16, dt_out=BF16)
+        assert torch.allclose(out.cpu().double(), ref, atol=0.03, rtol=1e-2)
+    outg = gemm(lib, Ad, Wd, bias=bd, act=2, dt_in=BF16, dt_out=BF16)
+    assert torch.allclose(outg.cpu().double(), F.gelu(ref), atol=0.03, rtol=1e-2)
+    # f32 output with LayerScale and an in-place f32 residual (the ViT proj / fc2 form)
+    s, r = rnd(N, seed=4), rnd(M, N, seed=5)
+    x = r.clone().cuda()
+    gemm(lib, Ad, Wd, bias=bd, scale=s.cuda(), res=x, out=x, dt_in=BF16, dt_out=F32, ldr=N)
+    ref2 = ref * s.double() + r.double()
+    assert torch.allclose(x.cpu().double(), ref2, atol=2e-3, rtol=1e-4)
+
+
+def test_qkv_scatter_pingpong_bf16(lib):
+    """QKV epilogue on the ping-pong kernel (rows padded to Npad per image): B*N >= 8192 rows."""
+    _attention_case(lib, 6, 4, 64, 1601, BF16)
+    _attention_case(lib, 5, 2, 128, 1700, BF16)
+
+
 @pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 11, 64, 128), (1, 16, 16, 128, 64), (3, 56, 60, 64, 64), (3, 56, 60, 64, 128), (2, 72, 70, 64, 256)])
 def test_conv3x3_implicit_gemm(lib, dt, B, H, W, Cin, Cout):
