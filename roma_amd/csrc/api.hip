@@ -8,7 +8,6 @@
 #include "attention.h"
 #include "elementwise.h"
 #include "gemm.h"
-#include "gemm_pp.h"
 #include "local_corr.h"
 #include "model.h"
 #include "refiner_block.h"
@@ -181,7 +180,7 @@ int roma_op_gemm(const void* A, long lda, const void* W, long ldw, void* C, long
   g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.batch = batch;
   g.sA = sA; g.sW = sW; g.sC = sC; g.bias = bias; g.scale = scale; g.res = res; g.ldr = ldr; g.sR = sC; g.act = act;
   g.alpha = alpha; g.in_dt = DT(dt_in); g.out_dt = DT(dt_out);
-  return gemm_dispatch(g, S(stream));
+  return gemm_launch(g, S(stream));
 }
 
 int roma_op_conv3x3(const void* in, const void* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
@@ -190,7 +189,7 @@ int roma_op_conv3x3(const void* in, const void* w, const float* bias, void* out,
   g.A = in; g.W = w; g.ldw = 9 * Cin; g.C = out; g.ldc = Cout; g.M = B * H * W; g.N = Cout; g.K = 9 * Cin;
   g.in_dt = DT(dt); g.out_dt = DT(dt); g.bias = bias; g.act = relu ? ACT_RELU : ACT_NONE;
   g.conv_h = H; g.conv_w = W; g.conv_c = Cin;
-  return gemm_dispatch(g, S(stream));
+  return gemm_launch(g, S(stream));
 }
 
 int roma_op_attention(const void* q, const void* k, const void* vt, void* out, int B, int heads, int N, int npad, int hd,
@@ -207,7 +206,7 @@ int roma_op_qkv_scatter_gemm(const void* A, const void* W, const float* bias, vo
   g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = B * N; g.N = 3 * heads * hd; g.K = K; g.in_dt = DT(dt_in);
   g.out_dt = DT(dt_out); g.bias = bias; g.mode = EPI_QKV; g.q = q; g.k = k; g.vt = vt; g.heads = heads; g.hd = hd;
   g.ntok = N; g.npad = npad; g.qscale = 1.0f / sqrtf((float)hd);
-  return gemm_dispatch(g, S(stream));
+  return gemm_launch(g, S(stream));
 }
 
 int roma_op_layernorm(const float* x, const float* w, const float* b, void* out, long M, int D, float eps, int dt_out,

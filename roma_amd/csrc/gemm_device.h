@@ -1,4 +1,4 @@
-// Device-side pieces shared by the GEMM kernels (gemm.hip, gemm_pp.hip): LDS row geometry, the LDS-DMA helper, the
+// Device-side pieces of the GEMM kernel (gemm.hip): LDS row geometry, the LDS-DMA helper, the
 // zero page and the compile-time specialised staged epilogues.
 #pragma once
 #include "gemm.h"

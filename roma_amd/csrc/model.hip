@@ -10,7 +10,6 @@
 #include "attention.h"
 #include "elementwise.h"
 #include "gemm.h"
-#include "gemm_pp.h"
 #include "local_corr.h"
 #include "refiner_block.h"
 
@@ -453,7 +452,7 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
     g.W = Linv + (long)k * 4096; g.ldw = 64; g.sW = sL;
     g.C = const_cast<float*>(static_cast<const float*>(g.A)); g.ldc = n; g.sC = sA;
     g.M = mrem; g.N = 64; g.K = 64; g.batch = batch;
-    if (int rc = gemm_dispatch(g, st)) return rc;
+    if (int rc = gemm_launch(g, st)) return rc;
     GemmArgs t;
     t.A = g.A; t.lda = n; t.sA = sA;
     t.W = g.A; t.ldw = n; t.sW = sA;
@@ -462,7 +461,7 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
     t.res = Ct; t.ldr = n; t.sR = sA;
     t.alpha = -1.f; t.lower_only = 1;
     t.M = mrem; t.N = mrem; t.K = 64; t.batch = batch;
-    if (int rc = gemm_dispatch(t, st)) return rc;
+    if (int rc = gemm_launch(t, st)) return rc;
   }
   if (int rc = transpose_launch(A, LT, n, n, batch, st)) return rc;
   for (int k = 0; k < nblk; ++k) {  // forward
@@ -471,7 +470,7 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
     g.W = Linv + (long)k * 4096; g.ldw = 64; g.sW = sL;
     g.C = Rt + k * 64; g.ldc = n; g.sC = sR;
     g.M = d; g.N = 64; g.K = 64; g.batch = batch;
-    if (int rc = gemm_dispatch(g, st)) return rc;
+    if (int rc = gemm_launch(g, st)) return rc;
     const int mrem = n - (k + 1) * 64;
     if (mrem <= 0) break;
     GemmArgs u;
@@ -481,7 +480,7 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
     u.res = Rt + (k + 1) * 64; u.ldr = n; u.sR = sR;
     u.alpha = -1.f;
     u.M = d; u.N = mrem; u.K = 64; u.batch = batch;
-    if (int rc = gemm_dispatch(u, st)) return rc;
+    if (int rc = gemm_launch(u, st)) return rc;
   }
   for (int k = nblk - 1; k >= 0; --k) {  // backward
     GemmArgs g;
@@ -489,7 +488,7 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
     g.W = LinvT + (long)k * 4096; g.ldw = 64; g.sW = sL;
     g.C = Rt + k * 64; g.ldc = n; g.sC = sR;
     g.M = d; g.N = 64; g.K = 64; g.batch = batch;
-    if (int rc = gemm_dispatch(g, st)) return rc;
+    if (int rc = gemm_launch(g, st)) return rc;
     if (k == 0) break;
     GemmArgs u;
     u.A = Rt + k * 64; u.lda = n; u.sA = sR;
@@ -498,7 +497,7 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
     u.res = Rt; u.ldr = n; u.sR = sR;
     u.alpha = -1.f;
     u.M = d; u.N = k * 64; u.K = 64; u.batch = batch;
-    if (int rc = gemm_dispatch(u, st)) return rc;
+    if (int rc = gemm_launch(u, st)) return rc;
   }
   return 0;
 }
@@ -555,7 +554,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       g.q = qbuf; g.k = kbuf; g.vt = vtbuf; g.heads = heads; g.hd = hd; g.ntok = N; g.npad = npad;
       // bf16 mode: fold log2(e) into the query scale so the softmax is a bare v_exp_f32 (2^x) per element
       g.qscale = (act_dt == DT_BF16 ? 1.4426950408889634f : 1.0f) / sqrtf((float)hd);
-      RUN(gemm_dispatch(g, st));
+      RUN(gemm_launch(g, st));
     }
     {
       AttnArgs a;
@@ -567,20 +566,20 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       GemmArgs g;
       g.A = ao; g.lda = 1024; g.W = w.proj.w; g.ldw = w.proj.ldw; g.C = x; g.ldc = 1024; g.M = (int)rows; g.N = 1024; g.K = 1024;
       g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = w.proj.b; g.scale = w.ls1; g.res = x; g.ldr = 1024;
-      RUN(gemm_dispatch(g, st));
+      RUN(gemm_launch(g, st));
     }
     RUN(layernorm_launch(x, w.ln2w, w.ln2b, ln, rows, 1024, eps, act_dt, st));
     {
       GemmArgs g;
       g.A = ln; g.lda = 1024; g.W = w.fc1.w; g.ldw = w.fc1.ldw; g.C = hid; g.ldc = 4096; g.M = (int)rows; g.N = 4096; g.K = 1024;
       g.in_dt = act_dt; g.out_dt = act_dt; g.bias = w.fc1.b; g.act = ACT_GELU;
-      RUN(gemm_dispatch(g, st));
+      RUN(gemm_launch(g, st));
     }
     {
       GemmArgs g;
       g.A = hid; g.lda = 4096; g.W = w.fc2.w; g.ldw = w.fc2.ldw; g.C = x; g.ldc = 1024; g.M = (int)rows; g.N = 1024; g.K = 4096;
       g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = w.fc2.b; g.scale = w.ls2; g.res = x; g.ldr = 1024;
-      RUN(gemm_dispatch(g, st));
+      RUN(gemm_launch(g, st));
     }
     return 0;
   };
@@ -607,7 +606,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         GemmArgs g;
         g.A = col1; g.lda = 32; g.W = vgg[0].w; g.ldw = vgg[0].ldw; g.C = t0; g.ldc = 64;
         g.M = nimg * H * W; g.N = 64; g.K = 32; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = vgg[0].b; g.act = ACT_RELU;
-        RUN(gemm_dispatch(g, st));
+        RUN(gemm_launch(g, st));
       }
       auto conv = [&](int li, const void* in, void* out, int h, int w) -> int {
         GemmArgs g;
@@ -615,7 +614,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         g.M = nimg * h * w; g.N = vgg_cout[li]; g.K = 9 * vgg_cin[li];
         g.in_dt = act_dt; g.out_dt = act_dt; g.bias = vgg[li].b; g.act = ACT_RELU;
         g.conv_h = h; g.conv_w = w; g.conv_c = vgg_cin[li];
-        RUN(gemm_dispatch(g, st));
+        RUN(gemm_launch(g, st));
         return 0;
       };
       if (int rc = conv(1, t0, feat[0], H, W)) return rc;
@@ -660,7 +659,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         GemmArgs g;
         g.A = col; g.lda = patch.ldw; g.W = patch.w; g.ldw = patch.ldw; g.C = pt; g.ldc = 1024;
         g.M = nimg * T; g.N = 1024; g.K = patch.ldw; g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = patch.b;
-        RUN(gemm_dispatch(g, st));
+        RUN(gemm_launch(g, st));
       }
       RUN(assemble_tokens_launch(pt, cls_tok, pos_emb, x, nimg, T, 1024, st));
       for (int i = 0; i < 24; ++i)
@@ -700,7 +699,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         GemmArgs g;
         g.A = feat[lvl]; g.lda = PROJ_CIN[si]; g.W = proj[si].w; g.ldw = proj[si].ldw; g.C = pf; g.ldc = ldf;
         g.M = (int)(nimg * hw); g.N = r.Cf; g.K = PROJ_CIN[si]; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = proj[si].b;
-        RUN(gemm_dispatch(g, st));
+        RUN(gemm_launch(g, st));
       }
       if (ins == 16) {
         if (debug && !dry)
@@ -728,7 +727,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           g.C = Kyy + (long)j0 * npad * npad; g.ldc = npad; g.sC = (long)npad * npad;
           g.M = n; g.N = n; g.K = 512; g.batch = nj; g.in_dt = act_dt; g.out_dt = DT_F32; g.mode = EPI_COSK;
           g.nx = norms + (long)j0 * n; g.ny = g.nx; g.sNx = n; g.sNy = n; g.inv_t = 1.0f / 0.2f; g.diag_add = 0.1f;
-          RUN(gemm_dispatch(g, st));
+          RUN(gemm_launch(g, st));
         }
         RUN(pad_identity_launch(Kyy + (long)j0 * npad * npad, npad, (long)npad * npad, n, npad, nj, st));
         if (!dry) ROMA_CHECK_HIP(hipMemsetAsync(Kxy, 0, (size_t)ndp * n * npad * 4, st));
@@ -740,7 +739,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           g.C = Kxy + (long)i0 * n * npad; g.ldc = npad; g.sC = (long)n * npad;
           g.M = n; g.N = n; g.K = 512; g.batch = B; g.in_dt = act_dt; g.out_dt = DT_F32; g.mode = EPI_COSK;
           g.nx = norms + (long)i0 * n; g.ny = norms + (long)s0 * n; g.sNx = n; g.sNy = n; g.inv_t = 1.0f / 0.2f;
-          RUN(gemm_dispatch(g, st));
+          RUN(gemm_launch(g, st));
         }
         RUN(gp_basis_launch(gp_w, gp_b, Ft, 512, th, tw, npad, st));
         for (int j = j0; j < j0 + nj; ++j)
@@ -754,7 +753,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           g.W = Rt + (long)s0 * 512 * npad; g.ldw = npad; g.sW = (long)512 * npad;
           g.C = tokens + (long)i0 * n * 1024; g.ldc = 1024; g.sC = (long)n * 1024;
           g.M = n; g.N = 512; g.K = npad; g.batch = B;
-          RUN(gemm_dispatch(g, st));
+          RUN(gemm_launch(g, st));
         }
         arena.release(gmark2);
         RUN(copy2d_launch(pf, ldf, act_dt, tokens + 512, 1024, DT_F32, rows_t, 512, st));
@@ -774,7 +773,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           GemmArgs g;
           g.A = zin; g.lda = 1024; g.W = to_out.w; g.ldw = to_out.ldw; g.C = logits; g.ldc = ldl;
           g.M = (int)rows_t; g.N = 4097; g.K = 1024; g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = to_out.b;
-          RUN(gemm_dispatch(g, st));
+          RUN(gemm_launch(g, st));
         }
         if (debug && !dry)
           if (int rc = dbg_save("logits16", logits, (size_t)rows_t * ldl * 4, st)) return rc;
@@ -822,7 +821,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           GemmArgs g;
           g.A = dalt; g.lda = r.Cp; g.W = r.pw[b].w; g.ldw = r.pw[b].ldw; g.C = dcur; g.ldc = r.Cp;
           g.M = (int)M; g.N = r.Cp; g.K = r.Cp; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = r.pw[b].b;
-          RUN(gemm_dispatch(g, st));
+          RUN(gemm_launch(g, st));
         }
         const float sx = (float)ins / (4.0f * (float)W), sy = (float)ins / (4.0f * (float)H);
         RUN(refiner_out_launch(dcur, r.Cp, act_dt, r.out_w, r.out_b, flow, cert, M, r.Cp, sx, sy, st));

@@ -101,12 +101,11 @@ def test_gemm_bf16(lib, M, N, K):
     assert torch.allclose(outb.cpu().double(), ref, atol=0.02 * math.sqrt(K), rtol=1e-2)
 
 
-# ------------------------------------------------------------------ ping-pong GEMM (gemm_pp.hip): big-M bf16 shapes
+# ------------------------------------------------------------------ big-M bf16 shapes (persistent 8-wave 256 x 256 tiles)
 @pytest.mark.parametrize("M,N,K", [(8192 + 37, 640, 192), (8448, 512, 64), (70000, 1024, 128), (9000, 768, 1024), (25616, 1024, 4096)])
-def test_gemm_pingpong_bf16(lib, M, N, K):
-    """Shapes that gemm_dispatch routes to the staggered-wave-row kernel: ragged last m-tile, partial n-tile (640),
-    a single K slab, several tiles per persistent workgroup (70000 x 1024), long K.  Run twice: the second launch
-    re-uses a warm instruction cache / different timing (race screen)."""
+def test_gemm_big_m_bf16(lib, M, N, K):
+    """The persistent 8-wave kernel with the carried last k-group: ragged last m-tile, partial n-tile (640), a single
+    K slab, several tiles per persistent workgroup (70000 x 1024), long K.  Run twice (timing-dependent races)."""
     A, W, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, std=K ** -0.5).bfloat16(), rnd(N, seed=3)
     ref = A.double() @ W.double().T + b.double()
     Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
@@ -123,8 +122,8 @@ def test_gemm_pingpong_bf16(lib, M, N, K):
     assert torch.allclose(x.cpu().double(), ref2, atol=2e-3, rtol=1e-4)
 
 
-def test_qkv_scatter_pingpong_bf16(lib):
-    """QKV epilogue on the ping-pong kernel (rows padded to Npad per image): B*N >= 8192 rows."""
+def test_qkv_scatter_big_m_bf16(lib):
+    """QKV epilogue on the persistent 8-wave kernel (rows padded to Npad per image): B*N >= 8192 rows."""
     _attention_case(lib, 6, 4, 64, 1601, BF16)
     _attention_case(lib, 5, 2, 128, 1700, BF16)
 
