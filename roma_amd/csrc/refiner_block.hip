@@ -52,11 +52,13 @@ template <int CP> struct RBCfg {
   static constexpr int KW = (NDMA + 3) / 4;                // max DMA instructions per wave per row (2 ; 3)
   static constexpr int OROW = PX * CP * 2;                 // bytes of one output row segment (6912 ; 8064)
   static constexpr int ROW16 = OROW / 16;
+  static constexpr int OPIX = CP * 2 + (CP >= 128 ? 16 : 0);  // LDS bytes per staged output pixel: 288 -> 304 keeps the 8-byte
+                                                                // MFMA-layout writes of 16 pixels on distinct banks (48 is already fine)
   static constexpr int OFF_PWB = 26 * CP * 4;
   static constexpr int OFF_WT = OFF_PWB + CP * 4;
   static constexpr int OFF_XT = OFF_WT + TAIL * XROW;
   static constexpr int OFF_OT = OFF_XT + PXB * 32 * XROW;
-  static constexpr int WORK_BYTES = OFF_OT + OROW;
+  static constexpr int WORK_BYTES = OFF_OT + PX * OPIX;
   static constexpr int RING_BYTES = NR * RSTRIDE;
   static_assert(NBF == 0 || NBF == 4, "one wave per full channel block");
   static_assert(GC * XQ <= 256 && OROW % 16 == 0 && TAIL % 8 == 0 && ROW16 <= 512, "layout");
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __r
         for (int u = 0; u < PXB; ++u) {
           const int pxl = u * 32 + l31;
           if (pxl < PX) {
-            lds_u8* orow = Ot + pxl * (CP * 2) + (32 * wv + 4 * hh) * 2;
+            lds_u8* orow = Ot + pxl * Cf::OPIX + (32 * wv + 4 * hh) * 2;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               u32x2_t q;
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __r
         }
         const int pxl = pb * 32 + l31v;
         if (pxl < PX) {
-          lds_u8* orow = Ot + pxl * (CP * 2) + (32 * Cf::NBF + 4 * hhv) * 2;
+          lds_u8* orow = Ot + pxl * Cf::OPIX + (32 * Cf::NBF + 4 * hhv) * 2;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             if (8 * g + 4 * hhv < Cf::TAIL) {
@@ -354,7 +356,8 @@ __global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __r
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int j = min(tid + 256 * it, n16 - 1);
-        const u32x4_t q = *(lds_u32x4*)(Ot + j * 16);
+        const int jp = j / (CP * 2 / 16), jc = j - jp * (CP * 2 / 16);  // piece -> (pixel, 16-byte column): un-pad
+        const u32x4_t q = *(lds_u32x4*)(Ot + jp * Cf::OPIX + jc * 16);
         *reinterpret_cast<u32x4_t*>(orow + j * 8) = q;
       }
     }
