@@ -9,8 +9,9 @@ to /root/reference/).  It is the *checker* for the HIP path; only `tests/`,
 Parity pinning: the reference's own tests hold no golden vectors for this path (SURVEY.md
 section 8c).  The oracle is pinned against OUTPUTS OF THE REFERENCE ITSELF, run in the build
 container by `tools/make_goldens.py` (stub-import of /root/reference, seeded synthetic
-weights) and committed under `tests/golden/`; `tests/test_oracle_golden.py` checks the oracle
-against them (per-stage tensors and final warp/certainty).  Third-party arithmetic that is
+weights) and committed under `tests/golden/`; `tests/test_cpu_oracle.py` checks the oracle
+against them (per-stage tensors and final warp/certainty; also `kde`, `sample`, `match_keypoints`, the
+post-processing steps restated at the end of this file).  Third-party arithmetic that is
 absent from /root/reference: `fused-local-corr` 0.2.2 (CUDA wheel, uv.lock:541-554) - its
 semantics are taken from the in-repo torch fallback (romatch/utils/local_correlation.py:39-74),
 the reference holds no test comparing the two, so parity at that operator boundary is pinned
