@@ -6,6 +6,8 @@
 //     fills the 256 CUs (157 query blocks alone would leave 40 % of them idle).
 #include "kde.h"
 
+#include <algorithm>
+
 namespace roma {
 
 __device__ __forceinline__ float round_to_half(float v) { return (float)(_Float16)v; }

@@ -1,6 +1,8 @@
 // Keypoint matching helpers (see keypoints.h).  All-pairs work of at most ~1e8 pairs: VALU bound, microseconds.
 #include "keypoints.h"
 
+#include <algorithm>
+
 namespace roma {
 
 // ------------------------------------------------------------------ bilinear sampling of (warp_B, certainty) at points
