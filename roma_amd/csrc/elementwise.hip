@@ -1059,6 +1059,14 @@ __global__ __launch_bounds__(256) void refiner_out_vec_kernel(const T* d, long l
   for (int it = 0; it < rows_it; ++it) {  // unrolled: the loads of 4 row groups are in flight together
     const long row = row0 + (long)it * rpw;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    // the running flow / certainty are fetched with the activations, not after the reduction (a dependent
+    // load -> add -> store tail per row group otherwise)
+    float f0 = 0.f, f1 = 0.f, c0 = 0.f;
+    if (row < M && sub == 0) {
+      f0 = flow[row * 2 + 0];
+      f1 = flow[row * 2 + 1];
+      c0 = cert[row];
+    }
     if (row < M) {
       float v[NK][CV];
 #pragma unroll
@@ -1086,9 +1094,9 @@ __global__ __launch_bounds__(256) void refiner_out_vec_kernel(const T* d, long l
       a2 += __shfl_xor(a2, off);
     }
     if (row < M && sub == 0) {
-      flow[row * 2 + 0] += sx * (a0 + b0);
-      flow[row * 2 + 1] += sy * (a1 + b1);
-      cert[row] += a2 + b2;
+      flow[row * 2 + 0] = f0 + sx * (a0 + b0);
+      flow[row * 2 + 1] = f1 + sy * (a1 + b1);
+      cert[row] = c0 + (a2 + b2);
     }
   }
 }
