@@ -48,7 +48,9 @@ int roma_set_tensor(roma_handle_t h, const char* name, int ndim, const int64_t* 
 /* strict key/shape check (as load_state_dict strict=True), BN folding, repacking, upload. */
 int roma_finalize(roma_handle_t h);
 /* mutable attributes of RegressionMatcher (README.md:82-90): "symmetric", "upsample_preds", "attenuate_cert", "debug";
- * tuning: "fuse_refiner_blocks" (default 1; 0 = separate dwconv + GEMM kernels at every scale) */
+ * tuning: "fuse_refiner_blocks" (default 1; 0 = separate dwconv + GEMM kernels at every scale),
+ *         "vit_bf16_residual" (bf16 mode only, default 1: DINOv2 residual stream in bf16 like the reference's bf16
+ *         backbone, encoders.py; 0 = keep it in f32) */
 int roma_set_option(roma_handle_t h, const char* key, int value);
 /* im_*: [B,3,H,W] float32 normalised images (already on the device). *_hr may be NULL when
  * upsample_preds == 0.  warp_out: [B,Ho,2*Wo,4] (symmetric) or [B,Ho,Wo,4]; cert_out: [B,Ho,2*Wo] / [B,Ho,Wo]. */
@@ -89,6 +91,14 @@ int roma_op_qkv_scatter_gemm(const void* A, const void* W, const float* bias, vo
                              int npad, int heads, int hd, int K, int dt_in, int dt_out, void* stream);
 int roma_op_layernorm(const float* x, const float* w, const float* b, void* out, long M, int D, float eps, int dt_out,
                       void* stream);
+/* LayerNorm with a typed input (dt_in 0 = f32, 1 = bf16; bf16 input implies bf16 output) - the bf16 residual stream of
+ * the DINOv2 blocks in bf16 mode (reference: encoders.py casts the backbone and its input to amp_dtype). */
+int roma_op_layernorm_dt(const void* x, int dt_in, const float* w, const float* b, void* out, long M, int D, float eps,
+                         int dt_out, void* stream);
+/* bf16 GEMM with a bf16 residual: C = bf16( res + scale * (A W^T + bias) ), C may alias res (the in-place residual
+ * update x += ls * linear(y) of a transformer block, dinov2.py NestedTensorBlock).  N, ldc, ldr multiples of 8. */
+int roma_op_gemm_res_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
+                          const float* bias, const float* scale, const void* res, long ldr, void* stream);
 /* Batched SPD solve  (A + 0 ) X = F  via blocked Cholesky: A [batch,n,n] f32 (destroyed), Ft [batch, d, n] = F^T,
  * overwritten by X^T.  Workspaces: LT [batch,n,n], Linv/LinvT [batch, n/64, 64, 64].  n multiple of 64. */
 int roma_op_cholesky_solve_t(float* A, float* Ft, float* LT, float* Linv, float* LinvT, int n, int d, int batch,

@@ -87,6 +87,7 @@ int roma_set_option(roma_handle_t h, const char* key, int value) {
   } else if (k == "attenuate_cert") h->m.cfg.attenuate_cert = value ? 1 : 0;
   else if (k == "debug") h->m.debug = value != 0;
   else if (k == "fuse_refiner_blocks") h->m.fuse_refiner_blocks = value != 0;
+  else if (k == "vit_bf16_residual") h->m.vit_bf16_residual = value != 0;
   else {
     set_error("roma_set_option: unknown key " + k);
     return ROMA_ERR_ARG;
@@ -212,6 +213,19 @@ int roma_op_qkv_scatter_gemm(const void* A, const void* W, const float* bias, vo
 int roma_op_layernorm(const float* x, const float* w, const float* b, void* out, long M, int D, float eps, int dt_out,
                       void* stream) {
   return layernorm_launch(x, w, b, out, M, D, eps, DT(dt_out), S(stream));
+}
+
+int roma_op_layernorm_dt(const void* x, int dt_in, const float* w, const float* b, void* out, long M, int D, float eps,
+                         int dt_out, void* stream) {
+  return layernorm_launch_dt(x, DT(dt_in), w, b, out, M, D, eps, DT(dt_out), S(stream));
+}
+
+int roma_op_gemm_res_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
+                          const float* bias, const float* scale, const void* res, long ldr, void* stream) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.bias = bias; g.scale = scale; g.res_bf16 = res; g.ldr = ldr; g.in_dt = DT_BF16; g.out_dt = DT_BF16;
+  return gemm_launch(g, S(stream));
 }
 
 int roma_op_cholesky_solve_t(float* A, float* Ft, float* LT, float* Linv, float* LinvT, int n, int d, int batch,

@@ -5,9 +5,12 @@
 
 namespace roma {
 
-// LayerNorm over the last dim (D multiple of 256, <= 2048): x f32 [M,D] -> out [M,D] (dt_out)
+// LayerNorm over the last dim (D multiple of 512, <= 2048): x f32 [M,D] -> out [M,D] (dt_out)
 int layernorm_launch(const float* x, const float* w, const float* b, void* out, long M, int D, float eps,
                      int dt_out, hipStream_t s);
+// same with a typed input: dt_in DT_F32, or DT_BF16 (bf16 residual stream; dt_out must then be DT_BF16)
+int layernorm_launch_dt(const void* x, int dt_in, const float* w, const float* b, void* out, long M, int D, float eps,
+                        int dt_out, hipStream_t s);
 
 // First VGG layer: NCHW f32 image -> conv3x3(3->64, pad 1) + folded BN + ReLU -> NHWC (dt_out)
 // w: [27][64] (tap-major: (ci*9+ky*3+kx), cout fastest), bias [64]

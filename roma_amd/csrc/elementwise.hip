@@ -26,23 +26,33 @@ __device__ inline float pix_coord(int i, int n) {
 }
 
 // ------------------------------------------------------------------ LayerNorm
-template <typename TOUT>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* w, const float* b, TOUT* out,
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const float* w, const float* b, TOUT* out,
                                                         long M, int D, float eps) {
   // one wave per row; a lane owns 8 consecutive elements of every 512-element chunk (two 16-byte loads, one 16-byte
   // bf16 store): the previous 4-element mapping wrote 8-byte pieces and ran at 2.9 TB/s
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const float* xr = x + row * D;
+  const TIN* xr = x + row * D;
   f32x4 v[4][2];
   const int nv = D / 512;
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     if (i < nv) {
-      v[i][0] = *reinterpret_cast<const f32x4*>(xr + i * 512 + lane * 8);
-      v[i][1] = *reinterpret_cast<const f32x4*>(xr + i * 512 + lane * 8 + 4);
+      if constexpr (sizeof(TIN) == 2) {  // bf16 residual stream: one 16-byte load, widened exactly
+        const uint4 r = *reinterpret_cast<const uint4*>(xr + i * 512 + lane * 8);
+        const unsigned rp[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[i][j >> 1][2 * (j & 1)] = __uint_as_float(rp[j] << 16);
+          v[i][j >> 1][2 * (j & 1) + 1] = __uint_as_float(rp[j] & 0xffff0000u);
+        }
+      } else {
+        v[i][0] = *reinterpret_cast<const f32x4*>(xr + i * 512 + lane * 8);
+        v[i][1] = *reinterpret_cast<const f32x4*>(xr + i * 512 + lane * 8 + 4);
+      }
     }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -87,13 +97,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     }
 }
 
-int layernorm_launch(const float* x, const float* w, const float* b, void* out, long M, int D, float eps,
-                     int dt_out, hipStream_t s) {
+int layernorm_launch_dt(const void* x, int dt_in, const float* w, const float* b, void* out, long M, int D, float eps,
+                        int dt_out, hipStream_t s) {
   ROMA_REQUIRE(D % 512 == 0 && D <= 2048, "layernorm: D must be a multiple of 512 and <= 2048");
+  ROMA_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+               "layernorm: x / out not 16-byte aligned");
   dim3 grid((unsigned)((M + 3) / 4));
-  ROMA_DT_SWITCH(dt_out, T, hipLaunchKernelGGL(layernorm_kernel<T>, grid, dim3(256), 0, s, x, w, b, (T*)out, M, D, eps));
+  if (dt_in == DT_BF16) {
+    ROMA_REQUIRE(dt_out == DT_BF16, "layernorm: bf16 input implies bf16 output");
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, w, b, (bf16_t*)out, M, D, eps);
+  } else {
+    ROMA_DT_SWITCH(dt_out, T, hipLaunchKernelGGL((layernorm_kernel<float, T>), grid, dim3(256), 0, s, (const float*)x, w, b,
+                                                 (T*)out, M, D, eps));
+  }
   ROMA_LAUNCH_CHECK();
   return 0;
+}
+
+int layernorm_launch(const float* x, const float* w, const float* b, void* out, long M, int D, float eps,
+                     int dt_out, hipStream_t s) {
+  return layernorm_launch_dt(x, DT_F32, w, b, out, M, D, eps, dt_out, s);
 }
 
 // ------------------------------------------------------------------ conv3x3, Cin = 3 (first VGG layer)

@@ -26,6 +26,9 @@ struct GemmArgs {
   const float* scale = nullptr;  // [N]
   const float* res = nullptr;    // f32 [M,N] (ldr), may alias C when C is f32
   long ldr = 0, sR = 0;
+  // bf16 residual stream (DINOv2 in throughput mode): bf16 [M,N] with the same ldr / sR, may alias C.  Requires bf16
+  // output, EPI_STD and 16-byte aligned rows (the staged row-writer adds it while it streams the tile out).
+  const void* res_bf16 = nullptr;
   int act = ACT_NONE;
   int mode = EPI_STD;
   int lower_only = 0;  // skip tiles strictly above the diagonal (square problems)

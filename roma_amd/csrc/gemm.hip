@@ -333,7 +333,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
       }
     }
     bool staged = a.mode == EPI_STD && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0;
-    if constexpr (sizeof(TOUT) == 2) staged = staged && Rb == nullptr && (a.ldc & 7) == 0;
+    if constexpr (sizeof(TOUT) == 2) staged = staged && Rb == nullptr && (a.ldc & 7) == 0;  // res_bf16: see gemm_launch
     else staged = staged && vecC && (Rb == nullptr || vecR) && (a.N & 3) == 0 && a.act != ACT_GELU;
     if (staged) {
       if constexpr (NWAVES != 8) __builtin_amdgcn_s_barrier();
@@ -349,6 +349,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
         } else if (a.act == ACT_RELU) {
           if (full_tile) epi_staged_bf16<TM, TN, ACT_RELU, true>(acc, a, Cbb, ws, mw0, nw0, lane);
           else epi_staged_bf16<TM, TN, ACT_RELU, false>(acc, a, Cbb, ws, mw0, nw0, lane);
+        } else if (a.res_bf16) {
+          const bf16_t* Rbb = reinterpret_cast<const bf16_t*>(a.res_bf16) + (long)bz * a.sR;
+          if (full_tile) epi_staged_bf16<TM, TN, ACT_NONE, true, true>(acc, a, Cbb, ws, mw0, nw0, lane, Rbb);
+          else epi_staged_bf16<TM, TN, ACT_NONE, false, true>(acc, a, Cbb, ws, mw0, nw0, lane, Rbb);
         } else {
           if (full_tile) epi_staged_bf16<TM, TN, ACT_NONE, true>(acc, a, Cbb, ws, mw0, nw0, lane);
           else epi_staged_bf16<TM, TN, ACT_NONE, false>(acc, a, Cbb, ws, mw0, nw0, lane);
@@ -541,6 +545,13 @@ int gemm_launch(const GemmArgs& a0, hipStream_t stream) {
   ROMA_REQUIRE(a.sA % ce == 0 && a.sW % ce == 0, "gemm: batch strides must keep 16-byte alignment");
   if (a.bias) ROMA_REQUIRE((reinterpret_cast<uintptr_t>(a.bias) & 15) == 0, "gemm: bias not 16-byte aligned");
   if (a.scale) ROMA_REQUIRE((reinterpret_cast<uintptr_t>(a.scale) & 15) == 0, "gemm: scale not 16-byte aligned");
+  if (a.res_bf16) {  // only the staged bf16 row-writer knows this residual: refuse anything that would bypass it
+    ROMA_REQUIRE(a.out_dt == DT_BF16 && a.mode == EPI_STD && a.act == ACT_NONE && a.res == nullptr,
+                 "gemm: res_bf16 needs bf16 output, EPI_STD, no activation and no f32 residual");
+    ROMA_REQUIRE(a.N % 8 == 0 && a.ldc % 8 == 0 && a.ldr % 8 == 0 && a.sC % 8 == 0 && a.sR % 8 == 0 &&
+                 (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.res_bf16) & 15) == 0,
+                 "gemm: res_bf16 needs 16-byte aligned rows (N, ldc, ldr multiples of 8)");
+  }
   const bool conv = a.conv_c > 0;
   if (conv) {
     ROMA_REQUIRE(a.conv_c % (8 * ce) == 0, "gemm(conv3x3): Cin must be a multiple of the K slab");

@@ -93,9 +93,11 @@ __device__ __forceinline__ f32x4 epi_vals(f32x4 v, const GemmArgs& a, int n) {
 // bf16 output: the MFMA layout gives each lane 4 consecutive n of ONE row, i.e. a wave store would scatter 8-byte
 // pieces over 32 rows (measured 0.56 TB/s).  Stage the wave's tile through its private LDS slice instead and write
 // whole rows: 16 B per lane, 128..384 contiguous bytes per row.  (One wave's LDS operations complete in order.)
-template <int TM, int TN, int ACT, bool FULL>
+// RES: add a bf16 residual (a.res_bf16, may alias C) to the rows as they leave LDS - the same lane reads and then
+// writes each 16-byte piece, so the in-place update is race free.
+template <int TM, int TN, int ACT, bool FULL, bool RES = false>
 __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], const GemmArgs& a, bf16_t* Cb, char* ws,
-                                                long mw0, int nw0, int lane) {
+                                                long mw0, int nw0, int lane, const bf16_t* Rb = nullptr) {
   constexpr int RB = TN * 64;    // staged row: TN*32 bf16
   constexpr int CPR = TN * 4;    // 16-byte chunks per row
   const int l31 = lane & 31, h = lane >> 5;
@@ -122,9 +124,22 @@ __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], con
       const int row = c / CPR, ch = c - row * CPR;
       const long m = mw + row;
       const int n = nw0 + ch * 8;
-      const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ epi_swz<CPR>(row)) << 4));
+      uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ epi_swz<CPR>(row)) << 4));
       if (a.dbg & 1) continue;
       bf16_t* dst = Cb + m * a.ldc + n;
+      if constexpr (RES) {
+        if (FULL || (m < a.M && n + 8 <= a.N)) {
+          const uint4 r = *reinterpret_cast<const uint4*>(Rb + m * a.ldr + n);
+          const unsigned* vp = reinterpret_cast<const unsigned*>(&v);
+          const unsigned* rp = reinterpret_cast<const unsigned*>(&r);
+          unsigned o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = pack_bf16x2(__uint_as_float(vp[j] << 16) + __uint_as_float(rp[j] << 16),
+                               __uint_as_float(vp[j] & 0xffff0000u) + __uint_as_float(rp[j] & 0xffff0000u));
+          v = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
       if (FULL) {
         *reinterpret_cast<uint4*>(dst) = v;
       } else {

@@ -65,6 +65,10 @@ class Model {
   bool finalized = false;
   bool debug = false;
   bool fuse_refiner_blocks = true;  // bf16 mode: fused dw5x5+1x1 kernel at the narrow scales (option "fuse_refiner_blocks")
+  // bf16 mode: DINOv2's residual stream in bf16, like the reference's bf16 backbone (encoders.py: dinov2 weights and
+  // input are cast to amp_dtype); the decoder transformer keeps f32 (autocast leaves its residual f32).  Option
+  // "vit_bf16_residual"; env ROMA_VIT_RES_F32=1 forces the f32 stream for A/B runs.
+  bool vit_bf16_residual = true;
   std::map<std::string, HostTensor> host;
 
   // packed weights (device)

@@ -2,6 +2,7 @@
 #include "model.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -543,10 +544,17 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
     cert_fin = (float*)AL((size_t)ndp * Hfin * Wfin, 4);
   }
 
-  // shared ViT block (DINOv2 and the coordinate decoder): x f32 residual stream, in place
-  auto vit_block = [&](const VitBlockW& w, float* x, long rows, int Bn, int N, int npad, int heads, int hd, float eps,
+  // shared ViT block (DINOv2 and the coordinate decoder): residual stream x updated in place; x_dt = DT_F32, or
+  // DT_BF16 for DINOv2 in bf16 mode (the proj / fc2 GEMMs then add the bf16 residual in their row-writer)
+  auto vit_block = [&](const VitBlockW& w, void* x, int x_dt, long rows, int Bn, int N, int npad, int heads, int hd, float eps,
                        void* ln, void* ao, void* hid) -> int {
-    RUN(layernorm_launch(x, w.ln1w, w.ln1b, ln, rows, 1024, eps, act_dt, st));
+    auto residual_gemm = [&](GemmArgs& g) -> int {
+      g.C = x; g.ldc = 1024; g.ldr = 1024;
+      if (x_dt == DT_BF16) { g.out_dt = DT_BF16; g.res_bf16 = x; }
+      else { g.out_dt = DT_F32; g.res = (const float*)x; }
+      return gemm_launch(g, st);
+    };
+    RUN(layernorm_launch_dt(x, x_dt, w.ln1w, w.ln1b, ln, rows, 1024, eps, act_dt, st));
     {
       GemmArgs g;
       g.A = ln; g.lda = 1024; g.W = w.qkv.w; g.ldw = w.qkv.ldw; g.M = (int)rows; g.N = 3072; g.K = 1024;
@@ -564,11 +572,11 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
     }
     {
       GemmArgs g;
-      g.A = ao; g.lda = 1024; g.W = w.proj.w; g.ldw = w.proj.ldw; g.C = x; g.ldc = 1024; g.M = (int)rows; g.N = 1024; g.K = 1024;
-      g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = w.proj.b; g.scale = w.ls1; g.res = x; g.ldr = 1024;
-      RUN(gemm_launch(g, st));
+      g.A = ao; g.lda = 1024; g.W = w.proj.w; g.ldw = w.proj.ldw; g.M = (int)rows; g.N = 1024; g.K = 1024;
+      g.in_dt = act_dt; g.bias = w.proj.b; g.scale = w.ls1;
+      RUN(residual_gemm(g));
     }
-    RUN(layernorm_launch(x, w.ln2w, w.ln2b, ln, rows, 1024, eps, act_dt, st));
+    RUN(layernorm_launch_dt(x, x_dt, w.ln2w, w.ln2b, ln, rows, 1024, eps, act_dt, st));
     {
       GemmArgs g;
       g.A = ln; g.lda = 1024; g.W = w.fc1.w; g.ldw = w.fc1.ldw; g.C = hid; g.ldc = 4096; g.M = (int)rows; g.N = 4096; g.K = 1024;
@@ -577,9 +585,9 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
     }
     {
       GemmArgs g;
-      g.A = hid; g.lda = 4096; g.W = w.fc2.w; g.ldw = w.fc2.ldw; g.C = x; g.ldc = 1024; g.M = (int)rows; g.N = 1024; g.K = 4096;
-      g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = w.fc2.b; g.scale = w.ls2; g.res = x; g.ldr = 1024;
-      RUN(gemm_launch(g, st));
+      g.A = hid; g.lda = 4096; g.W = w.fc2.w; g.ldw = w.fc2.ldw; g.M = (int)rows; g.N = 1024; g.K = 4096;
+      g.in_dt = act_dt; g.bias = w.fc2.b; g.scale = w.ls2;
+      RUN(residual_gemm(g));
     }
     return 0;
   };
@@ -662,9 +670,17 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         RUN(gemm_launch(g, st));
       }
       RUN(assemble_tokens_launch(pt, cls_tok, pos_emb, x, nimg, T, 1024, st));
+      static const bool res_f32_env = getenv("ROMA_VIT_RES_F32") && atoi(getenv("ROMA_VIT_RES_F32")) != 0;
+      void* xs = x;
+      int x_dt = DT_F32;
+      if (act_dt == DT_BF16 && (dry || (vit_bf16_residual && !res_f32_env))) {  // bf16 residual stream (model.h);
+        xs = AL((size_t)rows_d * 1024, 2);                                         // always planned, the option may flip later
+        x_dt = DT_BF16;
+        RUN(copy2d_launch(x, 1024, DT_F32, xs, 1024, DT_BF16, rows_d, 1024, st));
+      }
       for (int i = 0; i < 24; ++i)
-        if (int rc = vit_block(dino[i], x, rows_d, nimg, Nd, Npd, 16, 64, 1e-6f, ln, ao, hid)) return rc;
-      RUN(layernorm_launch(x, dino_nw, dino_nb, ln, rows_d, 1024, 1e-6f, act_dt, st));
+        if (int rc = vit_block(dino[i], xs, x_dt, rows_d, nimg, Nd, Npd, 16, 64, 1e-6f, ln, ao, hid)) return rc;
+      RUN(layernorm_launch_dt(xs, x_dt, dino_nw, dino_nb, ln, rows_d, 1024, 1e-6f, act_dt, st));
       for (int i = 0; i < nimg; ++i)  // drop the cls token: x_norm_patchtokens
         RUN(copy2d_launch(off(ln, ((long)i * Nd + 1) * 1024), 1024, act_dt, off(feat[4], (long)i * T * 1024), 1024, act_dt, T, 1024, st));
       arena.release(dmark);
@@ -761,7 +777,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           if (int rc = dbg_save("tokens16", tokens, (size_t)rows_t * 1024 * 4, st)) return rc;
         // ================= coordinate decoder (transformer/__init__.py:30-46)
         for (int i = 0; i < 5; ++i)
-          if (int rc = vit_block(tdec[i], tokens, rows_t, ndp, T, Npt, 8, 128, 1e-5f, ln, ao, hid)) return rc;
+          if (int rc = vit_block(tdec[i], tokens, DT_F32, rows_t, ndp, T, Npt, 8, 128, 1e-5f, ln, ao, hid)) return rc;
         const int ldl = 4104;
         float* logits = (float*)AL((size_t)rows_t * ldl, 4);
         const void* zin = tokens;

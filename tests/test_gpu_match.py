@@ -203,14 +203,17 @@ def test_bf16_mode_statistical(built_lib, weights0):
     d = _to_dev(inp)
     m = roma_model((112, 112), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=torch.bfloat16,
                    symmetric=True, upsample_res=(168, 168), max_batch=1)
-    warp, cert = m.match(d["im_A"], d["im_B"], im_A_high_res=d["im_A_high_res"], im_B_high_res=d["im_B_high_res"])
     w_ref, c_ref = O.match(inp["im_A"], inp["im_B"], sd, dsd, inp["im_A_high_res"], inp["im_B_high_res"])
-    ew = (warp.cpu() - w_ref).abs()
-    ec = (cert.cpu() - c_ref).abs()
-    print(f"bf16: median|dwarp|={ew.median():.3e} p99={ew.flatten().kthvalue(int(0.99 * ew.numel())).values:.3e} "
-          f"median|dcert|={ec.median():.3e} max={ec.max():.3e}")
-    assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
-    assert ew.median() < 5e-3 and ec.median() < 5e-2
+    for res16 in (True, False):  # DINOv2 residual stream in bf16 (default, = the reference's bf16 backbone) / in f32
+        m.vit_bf16_residual = res16
+        warp, cert = m.match(d["im_A"], d["im_B"], im_A_high_res=d["im_A_high_res"], im_B_high_res=d["im_B_high_res"])
+        ew = (warp.cpu() - w_ref).abs()
+        ec = (cert.cpu() - c_ref).abs()
+        print(f"bf16 (vit_bf16_residual={res16}): median|dwarp|={ew.median():.3e} "
+              f"p99={ew.flatten().kthvalue(int(0.99 * ew.numel())).values:.3e} "
+              f"median|dcert|={ec.median():.3e} max={ec.max():.3e}")
+        assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
+        assert ew.median() < 5e-3 and ec.median() < 5e-2
 
 
 def test_non_square_and_pil_inputs(built_lib, weights0, tmp_path):

@@ -122,6 +122,40 @@ def test_gemm_big_m_bf16(lib, M, N, K):
     assert torch.allclose(x.cpu().double(), ref2, atol=2e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 64, 72), (1000, 1024, 512), (25616, 1024, 1024), (9000, 1024, 4096)])
+def test_gemm_bf16_residual_in_place(lib, M, N, K):
+    """x = bf16(x + ls * (A W^T + b)) with x bf16, updated in place - the residual update of the DINOv2 blocks in bf16
+    mode (small 4-wave tiles, ragged last m-tile, the persistent 8-wave kernel).  The branch is rounded to bf16 before
+    the add (like the reference's bf16 backbone), so the bound is one rounding of the branch plus one of the sum."""
+    A, W, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, std=K ** -0.5).bfloat16(), rnd(N, seed=3)
+    s, r = rnd(N, seed=4), (3.0 * rnd(M, N, seed=5)).bfloat16()
+    branch = (A.double() @ W.double().T + b.double()) * s.double()
+    ref = branch + r.double()
+    Ad, Wd, bd, sd = A.cuda(), W.cuda(), b.cuda(), s.cuda()
+    for _ in range(2):
+        x = r.clone().cuda()
+        ok(lib, lib.roma_op_gemm_res_bf16(P(Ad), K, P(Wd), K, P(x), N, M, N, K, P(bd), P(sd), P(x), N, None))
+        torch.cuda.synchronize()
+        err = (x.cpu().double() - ref).abs()
+        bound = 2.0 ** -8 * (ref.abs() + branch.abs()) + 1e-3
+        assert bool((err <= bound).all()), float((err - bound).max())
+    # misuse is refused, not silently mis-computed: N not a multiple of 8
+    x = r.clone().cuda()
+    assert lib.roma_op_gemm_res_bf16(P(Ad), K, P(Wd), K, P(x), N, M, N - 4, K, P(bd), P(sd), P(x), N, None) != 0
+
+
+def test_layernorm_bf16_input(lib):
+    x, w, b = (rnd(1603, 1024, seed=1, std=3.0) + 0.5).bfloat16(), rnd(1024, seed=2), rnd(1024, seed=3)
+    out = torch.empty((1603, 1024), device="cuda", dtype=torch.bfloat16)
+    ok(lib, lib.roma_op_layernorm_dt(P(x.cuda()), BF16, P(w.cuda()), P(b.cuda()), P(out), 1603, 1024, 1e-6, BF16, None))
+    torch.cuda.synchronize()
+    ref = F.layer_norm(x.double(), (1024,), w.double(), b.double(), 1e-6)
+    assert torch.allclose(out.cpu().double(), ref, atol=1e-3, rtol=2.0 ** -8)
+    # bf16 input with f32 output is not a supported combination: refused
+    o32 = torch.empty((1603, 1024), device="cuda")
+    assert lib.roma_op_layernorm_dt(P(x.cuda()), BF16, P(w.cuda()), P(b.cuda()), P(o32), 1603, 1024, 1e-6, F32, None) != 0
+
+
 def test_qkv_scatter_big_m_bf16(lib):
     """QKV epilogue on the persistent 8-wave kernel (rows padded to Npad per image): B*N >= 8192 rows."""
     _attention_case(lib, 6, 4, 64, 1601, BF16)
