@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--coarse", type=int, default=560)
     ap.add_argument("--upsample", type=int, default=864)
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="sub-batch HIP streams per GPU (2 = experimental stream split, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -77,6 +79,7 @@ def main():
     amp = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = roma_outdoor(device=dev, weights=sd, dinov2_weights=dsd, coarse_res=args.coarse, upsample_res=args.upsample,
                          amp_dtype=amp, symmetric=True, upsample_preds=True, max_batch=args.batch)
+    model.dual_stream = args.streams == 2
     inp = {k: v.to(dev) for k, v in synthetic.make_inputs(args.batch, args.coarse, args.upsample, seed=1 + rank).items()}
     n_pairs = args.batch * world
 
@@ -115,18 +118,22 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"roma_outdoor match() {args.coarse}->{args.upsample}, symmetric, upsample_preds, "
                                f"{args.batch} pairs/GPU/step, seeded synthetic weights + N(0,1) images",
-                   "global_batch": n_pairs, "parallelism": f"pairs sharded x{world}, RCCL gather of results" if world > 1 else "single GPU",
+                   "global_batch": n_pairs, "streams_per_gpu": int(os.environ.get("ROMA_STREAMS", args.streams)), "parallelism": f"pairs sharded x{world}, RCCL gather of results" if world > 1 else "single GPU",
                    "outputs_finite": finite},
     }
 
     if rank == 0 and world == 1 and not args.no_roofline:
         # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream (separate instrumented pass)
+        # every kernel is timed owning the chip on the full-batch launch: with --streams 2 the split is switched off for
+        # this pass only
         lib = _lib.load()
+        model.dual_stream = False
         lib.roma_profile_enable(1)
         nprof = max(1, min(3, args.steps))
         for _ in range(nprof):
             step()
         torch.cuda.synchronize()
+        model.dual_stream = args.streams == 2
         n = lib.roma_profile_report(None, 0)
         buf = C.create_string_buffer(int(n))
         lib.roma_profile_report(buf, n)
@@ -144,6 +151,9 @@ def main():
             roof = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}
         roof.update({"traffic": pmc_traffic(name), "launches_per_step": v["calls"] / nprof, "avg_launch_ms": v["total_ms"] / v["calls"],
                      "share_of_instrumented_time": v["total_ms"] / tot_ms})
+        if args.streams == 2:
+            roof["mode"] = ("instrumented pass with the sub-batch stream split off: full-batch launches, one kernel on the "
+                            "chip at a time; the timed region overlaps two half-batch streams")
         result["roofline"] = roof
         result["kernels"] = {k: {"ms_per_step": x["total_ms"] / nprof, "calls_per_step": x["calls"] / nprof,
                                  ("TFLOP/s" if x["unit"] == "flop" else "GB/s"):

@@ -87,6 +87,19 @@ class Model {
 
   Arena arena;        // per-call scratch
   Arena persist;      // zero-initialised, never aliased (attention q/k/v^T pads, GP basis)
+  // Sub-batches on several HIP streams (option "streams" 1..4, "dual_stream" = 2 / 1; env ROMA_STREAMS overrides):
+  // pairs are independent, so sub-batch i > 0 runs the same schedule out of its own arenas on side stream i and the
+  // partially filled last rounds of one sub-batch's kernels (e.g. 404 GEMM tiles on 256 CUs) are filled by the
+  // others' work: +5 % at batch 8 with 2 streams (profiles/r01_v20_stream_split_ab.log).  OFF by default: in bf16
+  // mode the sub-batch on the caller's stream is not bit-reproducible under the overlap (1-5 % of runs differ by
+  // ~1 bf16 ulp in a 1 x 16 pixel patch of the finest refiner input; f32 mode 0 / 558) - see DESIGN.md.
+  // Side arenas / streams are created on first use from the sizes planned at roma_finalize.
+  static constexpr int MAX_STREAMS = 4;
+  int n_streams = 1, streams_ready = 1;
+  size_t side_arena_bytes = 0, side_persist_bytes = 0;
+  Arena side_arena[MAX_STREAMS - 1], side_persist[MAX_STREAMS - 1];
+  hipStream_t side[MAX_STREAMS - 1] = {nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[MAX_STREAMS - 1] = {nullptr};
   std::vector<void*> owned;  // device allocations to free
   std::map<std::string, std::pair<void*, size_t>> dbg;
 
@@ -97,10 +110,11 @@ class Model {
             float* cert, hipStream_t st);
 
  private:
+  int ensure_side_streams(int n);
   int check_contract();
   int pack_weights();
   int match_impl(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
-                 float* cert, hipStream_t st, bool dry);
+                 float* cert, hipStream_t st, bool dry, Arena& arena, Arena& persist);
   int dbg_save(const char* name, const void* p, size_t bytes, hipStream_t st);
   template <typename F> int upload_f32(const std::vector<float>& v, F** out);
   int upload_act(const std::vector<float>& v, void** out);

@@ -26,6 +26,11 @@ static const int REF_EMB[5] = {128, 64, 32, 16, 6};
 static const int REF_RAD[5] = {7, 3, 2, 0, 0};
 
 Model::~Model() {
+  for (int i = 0; i < MAX_STREAMS - 1; ++i) {
+    if (side[i]) (void)hipStreamDestroy(side[i]);
+    if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+  }
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
   for (void* p : owned) (void)hipFree(p);
   for (auto& kv : dbg) (void)hipFree(kv.second.first);
 }
@@ -389,10 +394,16 @@ int Model::finalize() {
   const int keep_sym = cfg.symmetric, keep_up = cfg.upsample_preds;
   cfg.symmetric = 1;
   cfg.upsample_preds = cfg.upsample_h > 0 ? 1 : 0;
-  int rc = match_impl(cfg.max_batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+  int rc = match_impl(cfg.max_batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, arena, persist);
+  // side streams (model.h): every side sub-batch is at most floor(max_batch / 2) pairs; only the sizes are planned here
+  Arena plan, plan_p;
+  if (!rc && cfg.max_batch >= 2)
+    rc = match_impl(cfg.max_batch / 2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, plan, plan_p);
   cfg.symmetric = keep_sym;
   cfg.upsample_preds = keep_up;
   if (rc) return rc;
+  side_arena_bytes = plan.peak + 4096;
+  side_persist_bytes = plan_p.peak + 4096;
   arena.cap = arena.peak + 4096;
   persist.cap = persist.peak + 4096;
   ROMA_CHECK_HIP(hipMalloc((void**)&arena.base, arena.cap));
@@ -403,6 +414,28 @@ int Model::finalize() {
   ROMA_CHECK_HIP(hipMemset(arena.base, 0, arena.cap));
   arena.dry = persist.dry = false;
   finalized = true;
+  return 0;
+}
+
+// Side arenas, streams and events for `n` sub-batch streams, created on first use (a few GB of hipMalloc: first call only).
+int Model::ensure_side_streams(int n) {
+  for (int i = streams_ready - 1; i + 1 < n; ++i) {
+    Arena &a = side_arena[i], &p = side_persist[i];
+    a.cap = side_arena_bytes;
+    p.cap = side_persist_bytes;
+    ROMA_CHECK_HIP(hipMalloc((void**)&a.base, a.cap));
+    owned.push_back(a.base);
+    ROMA_CHECK_HIP(hipMalloc((void**)&p.base, p.cap));
+    owned.push_back(p.base);
+    ROMA_CHECK_HIP(hipMemset(p.base, 0, p.cap));
+    ROMA_CHECK_HIP(hipMemset(a.base, 0, a.cap));
+    ROMA_CHECK_HIP(hipDeviceSynchronize());
+    a.dry = p.dry = false;
+    ROMA_CHECK_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+    ROMA_CHECK_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+    if (!ev_fork) ROMA_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    streams_ready = i + 2;
+  }
   return 0;
 }
 
@@ -430,7 +463,32 @@ int Model::match(int B, const float* ima, const float* imb, const float* ima_hr,
     ROMA_REQUIRE(ima_hr && imb_hr, "roma_match: upsample_preds requires im_A_high_res and im_B_high_res");
   }
   ROMA_CHECK_HIP(hipSetDevice(cfg.device));
-  return match_impl(B, ima, imb, ima_hr, imb_hr, warp, cert, st, false);
+  static const int env_streams = getenv("ROMA_STREAMS") ? atoi(getenv("ROMA_STREAMS")) : 0;
+  const int ns = debug ? 1 : std::min(std::min(env_streams > 0 ? env_streams : n_streams, (int)MAX_STREAMS), B);
+  if (ns <= 1) return match_impl(B, ima, imb, ima_hr, imb_hr, warp, cert, st, false, arena, persist);
+  if (int rc = ensure_side_streams(ns)) return rc;
+  // fork: the side streams start after everything already queued on the caller's stream (inputs); join at the end
+  const size_t im_lo = (size_t)3 * cfg.coarse_h * cfg.coarse_w, im_hi = (size_t)3 * cfg.upsample_h * cfg.upsample_w;
+  const int Ho = cfg.upsample_preds ? cfg.upsample_h : cfg.coarse_h, Wo = cfg.upsample_preds ? cfg.upsample_w : cfg.coarse_w;
+  const size_t px = (size_t)Ho * Wo * (cfg.symmetric ? 2 : 1);
+  ROMA_CHECK_HIP(hipEventRecord(ev_fork, st));
+  int rc = 0, b0 = 0;
+  for (int i = 0; i < ns; ++i) {  // balanced contiguous split; part 0 (the largest) stays on the caller's stream
+    const int bi = B / ns + (i < B % ns ? 1 : 0);
+    hipStream_t si = i == 0 ? st : side[i - 1];
+    if (i > 0) ROMA_CHECK_HIP(hipStreamWaitEvent(si, ev_fork, 0));
+    if (!rc)
+      rc = match_impl(bi, ima + b0 * im_lo, imb + b0 * im_lo, ima_hr ? ima_hr + b0 * im_hi : nullptr,
+                      imb_hr ? imb_hr + b0 * im_hi : nullptr, warp + b0 * px * 4, cert + b0 * px, si, false,
+                      i == 0 ? arena : side_arena[i - 1], i == 0 ? persist : side_persist[i - 1]);
+    b0 += bi;
+  }
+  // always join, also on error: the caller's stream must not run ahead of work already queued on a side stream
+  for (int i = 1; i < ns; ++i) {
+    (void)hipEventRecord(ev_join[i - 1], side[i - 1]);
+    (void)hipStreamWaitEvent(st, ev_join[i - 1], 0);
+  }
+  return rc;
 }
 
 // ---------------------------------------------------------------- blocked Cholesky solve (transposed RHS)
@@ -513,7 +571,7 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
   } while (0)
 
 int Model::match_impl(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr,
-                      float* warp_out, float* cert_out, hipStream_t st, bool dry) {
+                      float* warp_out, float* cert_out, hipStream_t st, bool dry, Arena& arena, Arena& persist) {
   const size_t esz = act_dt == DT_F32 ? 4 : 2;
   const int nimg = 2 * B;
   const int ndp = cfg.symmetric ? 2 * B : B;

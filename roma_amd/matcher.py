@@ -94,6 +94,9 @@ class RegressionMatcher:
         # bf16 mode only: DINOv2's residual stream in bf16 like the reference's bf16 backbone (encoders.py casts the
         # backbone weights and input to amp_dtype); False keeps it in f32 (slower, slightly closer to the fp32 result)
         self.vit_bf16_residual = True
+        # opt-in: batches of >= 2 pairs as two half-batches on two HIP streams (+5 % at batch 8).  Off by default: in
+        # bf16 mode the overlapped sub-batch is not bit-reproducible yet (~1 bf16 ulp in a small patch in 1-5 % of runs)
+        self.dual_stream = False
         self._weights = weights
         self._dinov2_weights = dinov2_weights
         self._handle = None
@@ -211,7 +214,7 @@ class RegressionMatcher:
             raise ValueError(f"Invalid upsample_preds and high_res inputs with {im_A_high_res=} and {im_B_high_res=}")
         self._ensure_handle()
         lib = _lib.load()
-        for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug", "vit_bf16_residual"):
+        for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug", "vit_bf16_residual", "dual_stream"):
             _lib.check(lib.roma_set_option(self._handle, k.encode(), int(bool(getattr(self, k)))))
         B = a.shape[0]
         Ho, Wo = self.get_output_resolution() if self.upsample_preds else (a.shape[-2], a.shape[-1])

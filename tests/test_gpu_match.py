@@ -216,6 +216,37 @@ def test_bf16_mode_statistical(built_lib, weights0):
         assert ew.median() < 5e-3 and ec.median() < 5e-2
 
 
+@pytest.mark.parametrize("amp", [torch.float32, torch.bfloat16])
+def test_stream_split_matches_single_stream(built_lib, weights0, amp):
+    """Opt-in: batches of >= 2 pairs as sub-batches on two HIP streams (model.h `streams`).  Pairs are independent
+    everywhere in match(), so the split (here 3 pairs -> 2 + 1, own arenas, fork / join events) must reproduce the
+    single-stream result, also from a caller stream that is not the default one.  f32 was bit-identical in 558 / 558
+    stress runs; in bf16 mode 1-5 % of the runs differ by ~1 bf16 ulp inside a small patch (open issue, DESIGN.md:
+    the reason the split is off by default), so the assertion is a tolerance and the bitwise outcome is printed."""
+    from roma_amd import roma_model, synthetic
+    sd, dsd = weights0
+    inp = synthetic.make_inputs(3, 112, 168, seed=7)
+    d = _to_dev(inp)
+    m = roma_model((112, 112), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=amp,
+                   symmetric=True, upsample_res=(168, 168), max_batch=3)
+    kw = dict(im_A_high_res=d["im_A_high_res"], im_B_high_res=d["im_B_high_res"])
+    assert m.dual_stream is False
+    w1, c1 = m.match(d["im_A"], d["im_B"], **kw)
+    m.dual_stream = True
+    s = torch.cuda.Stream()
+    exact = 0
+    for it in range(4):
+        if it < 3:
+            w2, c2 = m.match(d["im_A"], d["im_B"], **kw)
+        else:  # a caller stream other than the default one
+            with torch.cuda.stream(s):
+                w2, c2 = m.match(d["im_A"], d["im_B"], **kw)
+            s.synchronize()
+        exact += int(torch.equal(w1, w2) and torch.equal(c1, c2))
+        assert torch.allclose(w1, w2, atol=1e-4, rtol=0) and torch.allclose(c1, c2, atol=1e-2, rtol=0)
+    print(f"stream split ({amp}): {exact}/4 runs bit-identical to the single-stream result")
+
+
 def test_non_square_and_pil_inputs(built_lib, weights0, tmp_path):
     """Non-square resolutions (different token grid h != w) and the path / PIL input route (matcher.py:806-816, 853-868)."""
     from PIL import Image

@@ -6,6 +6,7 @@ OUT=$PWD/gpurun_out
 REPO=$PWD
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export ROMA_STREAMS=1   # per-launch traffic of the full-batch launches, like bench.py's instrumented roofline pass
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o pmc -- python "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > "$OUT/pmc_$C.log" 2>&1
