@@ -50,7 +50,10 @@ int roma_finalize(roma_handle_t h);
 /* mutable attributes of RegressionMatcher (README.md:82-90): "symmetric", "upsample_preds", "attenuate_cert", "debug";
  * tuning: "fuse_refiner_blocks" (default 1; 0 = separate dwconv + GEMM kernels at every scale),
  *         "vit_bf16_residual" (bf16 mode only, default 1: DINOv2 residual stream in bf16 like the reference's bf16
- *         backbone, encoders.py; 0 = keep it in f32) */
+ *         backbone, encoders.py; 0 = keep it in f32),
+ *         "streams" (1..4, default 1) / "dual_stream" (1 = 2 streams): run a batch as sub-batches on several HIP streams
+ *         (+5 % at batch 8 with 2; side workspaces are allocated on first use; bf16 results are then reproducible only
+ *         to ~1 bf16 ulp, f32 results exactly - DESIGN.md) */
 int roma_set_option(roma_handle_t h, const char* key, int value);
 /* im_*: [B,3,H,W] float32 normalised images (already on the device). *_hr may be NULL when
  * upsample_preds == 0.  warp_out: [B,Ho,2*Wo,4] (symmetric) or [B,Ho,Wo,4]; cert_out: [B,Ho,2*Wo] / [B,Ho,Wo]. */
