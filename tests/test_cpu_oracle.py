@@ -186,9 +186,30 @@ def test_gloo_world2_gather(tmp_path):
         "warp = idx[:, None, None, None].expand(c, 4, 6, 4).contiguous()\n"
         "cert = idx[:, None, None].expand(c, 4, 6).contiguous() * 2\n"
         "W, Cc = gather_results(warp, cert, n)\n"
+        "ok = True\n"
         "if r == 0:\n"
         "    assert W.shape == (5, 4, 6, 4) and Cc.shape == (5, 4, 6)\n"
         "    assert torch.equal(W[:, 0, 0, 0], torch.arange(5.)) and torch.equal(Cc[:, 0, 0], 2 * torch.arange(5.))\n"
+        "else:\n"
+        "    assert W is None and Cc is None\n"
+        "# equal shards (received straight into the result) and the pipelined form bench.py uses: the gather of step i\n"
+        "# is waited for only after step i + 1 has been produced\n"
+        "n = 6\n"
+        "s, c = shard_pairs(n, r, w)\n"
+        "pend = None\n"
+        "for step in range(3):\n"
+        "    idx = torch.arange(s, s + c, dtype=torch.float32) + 10 * step\n"
+        "    warp = idx[:, None, None, None].expand(c, 4, 6, 4).contiguous()\n"
+        "    cert = idx[:, None, None].expand(c, 4, 6).contiguous() * 2\n"
+        "    if pend is not None:\n"
+        "        W, Cc = pend.wait()\n"
+        "        if r == 0:\n"
+        "            assert torch.equal(W[:, 1, 2, 3], torch.arange(6.) + 10 * (step - 1)) and W.shape == (6, 4, 6, 4)\n"
+        "            assert torch.equal(Cc[:, 3, 5], 2 * (torch.arange(6.) + 10 * (step - 1)))\n"
+        "    pend = gather_results(warp, cert, n, async_op=True)\n"
+        "W, Cc = pend.wait()\n"
+        "if r == 0:\n"
+        "    assert torch.equal(W[:, 0, 0, 0], torch.arange(6.) + 20)\n"
         "    print('GATHER_OK')\n"
         "dist.destroy_process_group()\n")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
