@@ -464,6 +464,7 @@ int Model::match(int B, const float* ima, const float* imb, const float* ima_hr,
   }
   ROMA_CHECK_HIP(hipSetDevice(cfg.device));
   static const int env_streams = getenv("ROMA_STREAMS") ? atoi(getenv("ROMA_STREAMS")) : 0;
+  static const bool serial_env = getenv("ROMA_STREAMS_SERIAL") && atoi(getenv("ROMA_STREAMS_SERIAL")) != 0;
   const int ns = debug ? 1 : std::min(std::min(env_streams > 0 ? env_streams : n_streams, (int)MAX_STREAMS), B);
   if (ns <= 1) return match_impl(B, ima, imb, ima_hr, imb_hr, warp, cert, st, false, arena, persist);
   if (int rc = ensure_side_streams(ns)) return rc;
@@ -477,6 +478,11 @@ int Model::match(int B, const float* ima, const float* imb, const float* ima_hr,
     const int bi = B / ns + (i < B % ns ? 1 : 0);
     hipStream_t si = i == 0 ? st : side[i - 1];
     if (i > 0) ROMA_CHECK_HIP(hipStreamWaitEvent(si, ev_fork, 0));
+    if (i > 0 && serial_env) {  // diagnostic: same streams and arenas, but no overlap - sub-batch i starts after i - 1 ended
+      hipStream_t sp = i == 1 ? st : side[i - 2];
+      ROMA_CHECK_HIP(hipEventRecord(ev_join[i - 1], sp));
+      ROMA_CHECK_HIP(hipStreamWaitEvent(si, ev_join[i - 1], 0));
+    }
     if (!rc)
       rc = match_impl(bi, ima + b0 * im_lo, imb + b0 * im_lo, ima_hr ? ima_hr + b0 * im_hi : nullptr,
                       imb_hr ? imb_hr + b0 * im_hi : nullptr, warp + b0 * px * 4, cert + b0 * px, si, false,
