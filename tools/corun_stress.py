@@ -46,7 +46,8 @@ def make_gemm(M, N, K, ldc, act=0):
     A, W, b = rnd(M, K, dtype=torch.bfloat16), rnd(N, K, std=K ** -0.5, dtype=torch.bfloat16), rnd(N)
 
     def run(stream):
-        out = torch.zeros(M, ldc, device=dev, dtype=torch.bfloat16)
+        with torch.cuda.stream(stream):  # zero-fill ordered before the GEMM (pad columns stay zero)
+            out = torch.zeros(M, ldc, device=dev, dtype=torch.bfloat16)
         ok(lib.roma_op_gemm(P(A), K, P(W), K, P(out), ldc, M, N, K, 1, 0, 0, 0, P(b), None, None, 0, act, 1.0, BF16, BF16, S(stream)))
         return out
     return run
@@ -103,7 +104,34 @@ def make_conv_c3(B, H, W):
     return run
 
 
+def make_chain(B, H, W, Cp, fused):
+    """The refiner's nine blocks as one dependent chain (ping-pong between two buffers, exactly the product schedule):
+    covers producer -> consumer hand-over between kernels of ONE stream while another stream runs (cache write-back /
+    invalidate at kernel boundaries, workgroup -> XCD placement), which single-kernel victims with static inputs cannot."""
+    x0 = rnd(B, H, W, Cp, dtype=torch.bfloat16)
+    ws = [(rnd(25, Cp, std=0.1), rnd(Cp, std=0.1), rnd(Cp, Cp, std=Cp ** -0.5, dtype=torch.bfloat16), rnd(Cp)) for _ in range(9)]
+    M = B * H * W
+
+    def run(stream):
+        with torch.cuda.stream(stream):
+            a, b = x0.clone(), torch.empty_like(x0)  # produced on the victim's stream like the refiner input
+        for (w, bb, pw, pb) in ws:
+            if fused:
+                ok(lib.roma_op_refiner_block(P(a), P(b), P(w), P(bb), P(pw), P(pb), B, H, W, Cp, BF16, S(stream)))
+                a, b = b, a
+            else:
+                ok(lib.roma_op_dwconv5x5(P(a), P(b), P(w), P(bb), B, H, W, Cp, BF16, S(stream)))
+                ok(lib.roma_op_gemm(P(b), Cp, P(pw), Cp, P(a), Cp, M, Cp, Cp, 1, 0, 0, 0, P(pb), None, None, 0, 0, 1.0, BF16, BF16, S(stream)))
+        _KEEP.append((a, b))
+        return a
+    return run
+
+
+_KEEP = []
+
 VICTIMS = {
+    "chain 9 x (dwconv + gemm) 4x168x168x24": make_chain(NDP, HF, HF, 24, False),
+    "chain 9 x refiner_block  4x168x168x24": make_chain(NDP, HF, HF, 24, True),
     "gemm proj  M=112896 N=9  K=64 (ldc 24)": make_gemm(MF, 9, 64, 24),
     "gemm pw    M=112896 N=24 K=24": make_gemm(MF, 24, 24, 24),
     "gemm pw144 M=28224  N=144 K=144": make_gemm(NDP * 84 * 84, 144, 144, 144),
@@ -139,6 +167,7 @@ def main():
                             aggr(s2)
                     outs.append(victim(s1))
                 torch.cuda.synchronize()
+                del _KEEP[:]
                 for o in outs:
                     total += 1
                     if not torch.equal(o, ref):
