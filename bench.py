@@ -4,17 +4,29 @@ Workload (BASELINE.json metric / configs[2]; reference timing script
 tests/test_roma_upsample_inference_time.py:7-47): roma_outdoor, coarse 560 -> upsample 864,
 batch = 8 pairs per GPU, symmetric, bf16 compute, synthetic N(0,1) images and seeded synthetic
 weights (no pretrained weights / datasets offline).  A "step" = one match() over one batch,
-inputs already resident in HBM.  N > 1: one process per GPU (torch.distributed.run), pairs
-sharded 8 per GPU (weak scaling), the only collective is the RCCL gather of the results.
+inputs already resident in HBM.  N > 1: one process per GPU, pairs sharded 8 per GPU (weak
+scaling), the only collective is the RCCL gather of the results.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3            # re-executes itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+    python bench.py --config coarse --batch 1                 # BASELINE config 2 (coarse-only 560, B = 1)
+    python bench.py --gpus 2 --dry                            # CPU / gloo: launch + shard + gather logic only
+
+Rank 0 prints ONE JSON line.  Besides the driver contract it carries
+  roofline      dominant kernel: algorithmic FLOP/s (or B/s) from per-launch HIP events on the launch stream
+  kernels       every instrumented kernel (GEMMs, attention, local correlation, grid-sample warp, ...)
+  parity        the timed configuration's outputs against the committed reference golden (tools/parity_metrics.py)
+  cpu_baseline  the CPU oracle on the host cores: 1 warm-up + 3 timed calls, median
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -25,25 +37,54 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PMC_SUMMARIES = ("profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json")
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_round.sh: separate
     --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    wide coalesced reads on gfx950).  None when no summary matches."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if not os.path.exists(path):
-        return None
-    pm = json.load(open(path))
+    wide coalesced reads on gfx950).  Returns (bytes or None, source file or None)."""
     # "gemm_kernel<bf16,f32,2,4,4,2,dense>" -> "void roma::gemm_kernel<unsigned short, float, 2, 4, 4, 2, false>"
     base, _, targs = kernel.partition("<")
-    targs = targs.rstrip(">").split(",")
+    targs = targs.rstrip(">").split(",") if targs else []
     conv = {"bf16": "unsigned short", "f32": "float", "dense": "false", "conv3x3": "true"}
-    want = "void roma::" + base + "<" + ", ".join(conv.get(t, t) for t in targs) + ">"
-    f, w = pm.get("FETCH_SIZE", {}).get(want), pm.get("WRITE_SIZE", {}).get(want)
-    if not f or not w or not f["launches"]:
-        return None
-    return (2.0 * f["sum_kb"] / f["launches"] + w["sum_kb"] / w["launches"]) * 1024.0
+    want = "void roma::" + base + ("<" + ", ".join(conv.get(t, t) for t in targs) + ">" if targs else "")
+    for rel in PMC_SUMMARIES:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        pm = json.load(open(path))
+        f, w = pm.get("FETCH_SIZE", {}).get(want), pm.get("WRITE_SIZE", {}).get(want)
+        if f and w and f["launches"]:
+            return (2.0 * f["sum_kb"] / f["launches"] + w["sum_kb"] / w["launches"]) * 1024.0, rel
+    return None, None
+
+
+def respawn_distributed(args):
+    """`python bench.py --gpus N` with N > 1 outside a launcher: run ourselves as N ranks (one per GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL needs dmabuf IPC on this driver
+    env["ROMA_BENCH_SPAWNED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+class DryMatcher:
+    """CPU stand-in used by --dry (no GPU, gloo): same output shapes and pair order as match(), no arithmetic."""
+
+    def __init__(self, res):
+        self.res = res
+
+    def match(self, a, b, **kw):
+        n = a.shape[0]
+        tag = a.reshape(n, -1)[:, 0]
+        warp = tag[:, None, None, None].expand(n, self.res, 2 * self.res, 4).contiguous()
+        return warp, warp[..., 0].contiguous()
 
 
 def main():
@@ -51,46 +92,82 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="image pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (default 8; 1 for --config coarse)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--config", default="full", choices=["full", "coarse"],
+                    help="full = 560 -> 864 upsample path (the metric); coarse = coarse-only 560 (BASELINE config 2)")
     ap.add_argument("--coarse", type=int, default=560)
     ap.add_argument("--upsample", type=int, default=864)
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
-                    help="sub-batch HIP streams per GPU (2 = experimental stream split, see DESIGN.md)")
+                    help="sub-batch HIP streams per GPU (2 = stream split, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cpu-baseline-reps", type=int, default=3)
+    ap.add_argument("--dry", action="store_true", help="CPU-only launch-logic check: gloo backend, stand-in match()")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 1 if args.config == "coarse" else 8
+    full = args.config == "full"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_distributed(args))
 
     import torch.distributed as dist
-    from roma_amd import _lib, roma_outdoor, synthetic
+    from roma_amd import synthetic
     from roma_amd.distributed import gather_results
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+    if args.dry:
+        dev = torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
 
-    sd, dsd = synthetic.make_matcher_state_dict(0), synthetic.make_dinov2_state_dict(0)
-    amp = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = roma_outdoor(device=dev, weights=sd, dinov2_weights=dsd, coarse_res=args.coarse, upsample_res=args.upsample,
-                         amp_dtype=amp, symmetric=True, upsample_preds=True, max_batch=args.batch)
-    model.dual_stream = args.streams == 2
-    inp = {k: v.to(dev) for k, v in synthetic.make_inputs(args.batch, args.coarse, args.upsample, seed=1 + rank).items()}
+    if args.dry:
+        res = 16
+        model = DryMatcher(res)
+        inp = {"im_A": torch.full((args.batch, 3, 4, 4), float(rank)), "im_B": torch.zeros(args.batch, 3, 4, 4)}
+        sd = dsd = None
+    else:
+        from roma_amd import _lib, roma_outdoor
+        sd, dsd = synthetic.make_matcher_state_dict(0), synthetic.make_dinov2_state_dict(0)
+        amp = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        model = roma_outdoor(device=dev, weights=sd, dinov2_weights=dsd, coarse_res=args.coarse, upsample_res=args.upsample,
+                             amp_dtype=amp, symmetric=True, upsample_preds=full, max_batch=args.batch)
+        model.dual_stream = args.streams == 2
+        inp = {k: v.to(dev) for k, v in synthetic.make_inputs(args.batch, args.coarse, args.upsample if full else None,
+                                                              seed=1 + rank).items()}
     n_pairs = args.batch * world
+    kw = dict(im_A_high_res=inp["im_A_high_res"], im_B_high_res=inp["im_B_high_res"]) if (full and not args.dry) else {}
 
     pending = [None]  # N > 1: the result gather of step i runs on RCCL's stream under the match() of step i + 1
+    gather_ms = []
 
     def drain():
-        res, pending[0] = (pending[0].wait() if pending[0] is not None else None), None
+        if pending[0] is None:
+            return None
+        t = time.perf_counter()
+        res = pending[0].wait()
+        gather_ms.append(1e3 * (time.perf_counter() - t))
+        pending[0] = None
         return res
 
+    def sync():
+        if not args.dry:
+            torch.cuda.synchronize()
+
     def step():
-        warp, cert = model.match(inp["im_A"], inp["im_B"], im_A_high_res=inp["im_A_high_res"], im_B_high_res=inp["im_B_high_res"])
+        warp, cert = model.match(inp["im_A"], inp["im_B"], **kw)
         if world > 1:
             drain()  # queued behind this step's kernels: the previous gather has had the whole match() to finish
             pending[0] = gather_results(warp, cert, n_pairs, async_op=True)
@@ -101,37 +178,71 @@ def main():
     if world > 1:
         drain()
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
+    gather_ms.clear()
+    evs = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if not args.dry:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()  # torch's current stream IS the stream roma_match launches on (matcher.py passes it down)
         out = step()
+        if not args.dry:
+            e1.record()
+            evs.append((e0, e1))
     if world > 1:
         gathered = drain()  # every step's results are on rank 0 before the clock stops
         out = gathered if rank == 0 else out
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     dt = time.perf_counter() - t0
+    dt_rank = dt
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        per_rank = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([n_pairs / world * args.steps / dt_rank], device=dev, dtype=torch.float64))
+        per_rank = [float(x.item()) for x in per_rank]
+    step_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
     finite = bool(torch.isfinite(out[1]).all()) if out[1] is not None else True
 
+    what = (f"{args.coarse}->{args.upsample}, symmetric, upsample_preds" if full else f"{args.coarse} coarse-only, symmetric")
     result = {
-        "metric": "image-pairs/sec, roma_outdoor 560->864, batch=8 per GPU",
+        "metric": "image-pairs/sec, roma_outdoor 560->864, batch=8 per GPU" if full else
+                  "image-pairs/sec, roma_outdoor coarse-only 560, batch=1 (BASELINE config 2; not the headline metric)",
         "value": n_pairs * args.steps / dt,
         "unit": "image-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"roma_outdoor match() {args.coarse}->{args.upsample}, symmetric, upsample_preds, "
-                               f"{args.batch} pairs/GPU/step, seeded synthetic weights + N(0,1) images",
-                   "global_batch": n_pairs, "streams_per_gpu": int(os.environ.get("ROMA_STREAMS", args.streams)), "parallelism": f"pairs sharded x{world}, RCCL gather of results (step i's gather overlaps step i+1's match)" if world > 1 else "single GPU",
+        "config": {"workload": f"roma_outdoor match() {what}, {args.batch} pairs/GPU/step, seeded synthetic weights + N(0,1) images",
+                   "global_batch": n_pairs, "streams_per_gpu": int(os.environ.get("ROMA_STREAMS", args.streams)),
+                   "parallelism": (f"pairs sharded x{world}, {'gloo (dry run)' if args.dry else 'RCCL'} gather of results "
+                                   "(step i's gather overlaps step i+1's match)") if world > 1 else "single GPU",
                    "outputs_finite": finite},
     }
+    if step_ms:
+        result["ms_per_step_median_hip_events"] = statistics.median(step_ms)
+    if world > 1:
+        result["rccl_ranks"] = world
+        result["pairs_per_s_per_rank"] = per_rank
+        result["gather_wait_ms_rank0"] = {"median": statistics.median(gather_ms) if gather_ms else None,
+                                          "last": gather_ms[-1] if gather_ms else None}
+        result["launched_by"] = "bench.py self-spawn" if os.environ.get("ROMA_BENCH_SPAWNED") else "external launcher"
+    if args.dry:
+        if rank == 0 and world > 1:  # the gathered result must hold every rank's shard in pair order
+            tags = out[0][:, 0, 0, 0].tolist()
+            assert tags == [float(r) for r in range(world) for _ in range(args.batch)], tags
+        result["dry"] = True
+        if rank == 0:
+            print(json.dumps(result))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     if rank == 0 and world == 1 and not args.no_roofline:
         # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream (separate instrumented pass)
@@ -160,7 +271,11 @@ def main():
         else:
             ach = v["work"] / (v["total_ms"] * 1e-3) / 1e9
             roof = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}
-        roof.update({"traffic": pmc_traffic(name), "launches_per_step": v["calls"] / nprof, "avg_launch_ms": v["total_ms"] / v["calls"],
+        traffic, src = pmc_traffic(name)
+        roof.update({"traffic": traffic,
+                     "traffic_source": (f"{src}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench "
+                                        "(tools/pmc_round.sh), not measured in this run") if src else None,
+                     "launches_per_step": v["calls"] / nprof, "avg_launch_ms": v["total_ms"] / v["calls"],
                      "share_of_instrumented_time": v["total_ms"] / tot_ms})
         if args.streams == 2:
             roof["mode"] = ("instrumented pass with the sub-batch stream split off: full-batch launches, one kernel on the "
@@ -171,16 +286,60 @@ def main():
                                      x["work"] / (x["total_ms"] * 1e-3) / (1e12 if x["unit"] == "flop" else 1e9)}
                              for k, x in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
 
+    if rank == 0 and not args.no_parity:
+        # ---- parity of the timed configuration (rank 0's shard = seeds 0 / 1) against the reference's own output
+        gold = os.path.join(ROOT, "tests", "golden", "match_full8.npz" if full else "match_full_coarse.npz")
+        default_cfg = args.coarse == 560 and (not full or args.upsample == 864) and args.batch == (8 if full else 1)
+        if default_cfg and os.path.exists(gold):
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import numpy as np
+            import parity_metrics as PM
+            g = np.load(gold)
+            tol = 1e-3
+
+            def run(inject):
+                model.debug = True
+                model.debug_inject("gm_flow16", PM.nchw_to_tokens(g["gm_flow16"]) if inject else None)
+                model.debug_inject("gm_cert16", PM.nchw_to_tokens(g["gm_cert16"]) if inject else None)
+                w, c = model.match(inp["im_A"], inp["im_B"], **kw)
+                torch.cuda.synchronize()
+                own = model.debug_fetch("gm_flow16_own").reshape(-1, 1600, 2).copy()
+                model.debug = False
+                model.debug_inject("gm_flow16", None)
+                model.debug_inject("gm_cert16", None)
+                return w.cpu().numpy()[:, ::8, ::8], c.cpu().numpy()[:, ::8, ::8], own
+
+            w, c, own = run(False)
+            par = {"golden": os.path.relpath(gold, ROOT) + " (unmodified reference, CPU fp32, same seeds; 1/8 sub-sampled)",
+                   "tolerance_f32": tol,
+                   "coarse_argmax": PM.coarse_flips(own, PM.nchw_to_tokens(g["gm_flow16"]),
+                                                    PM.nchw_to_tokens(g["cls16_top2gap"][:, None])),
+                   "outputs": PM.output_errors(w, c, g["warp_sub"], g["cert_sub"], tol=tol)}
+            if args.dtype == "bf16":  # continuous part of the pipeline: the reference's coarse match injected
+                w, c, _ = run(True)
+                par["outputs_with_reference_coarse_match_injected"] = PM.output_errors(w, c, g["warp_sub"], g["cert_sub"], tol=tol)
+            result["parity"] = par
+        else:
+            result["parity"] = None
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # ---- CPU baseline: the oracle (CPU restatement of the reference) on the host cores, ONE pair of the same workload
+        # ---- CPU baseline: the oracle (CPU restatement of the reference; the reference itself is not on the GPU box) on
+        # the host cores, ONE symmetric pair of the same workload per call: 1 warm-up + N timed calls, median
         from oracle import roma_oracle
         torch.set_num_threads(min(os.cpu_count(), 32))  # MKL/oneDNN stop scaling (and regress) beyond ~32 threads at these sizes
-        cin = synthetic.make_inputs(1, args.coarse, args.upsample, seed=1)
-        t0 = time.perf_counter()
-        roma_oracle.match(cin["im_A"], cin["im_B"], sd, dsd, cin["im_A_high_res"], cin["im_B_high_res"])
-        cdt = time.perf_counter() - t0
-        result["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "image-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-                                  "sample": f"1 symmetric pair {args.coarse}->{args.upsample}, fp32, torch CPU, no warm-up ({cdt:.1f} s)"}
+        cin = synthetic.make_inputs(1, args.coarse, args.upsample if full else None, seed=1)
+        ckw = dict(upsample_preds=full)
+        times = []
+        for i in range(1 + max(1, args.cpu_baseline_reps)):
+            t0 = time.perf_counter()
+            roma_oracle.match(cin["im_A"], cin["im_B"], sd, dsd, cin.get("im_A_high_res"), cin.get("im_B_high_res"), **ckw)
+            if i > 0:
+                times.append(time.perf_counter() - t0)
+        med = statistics.median(times)
+        result["cpu_baseline"] = {"value": 1.0 / med, "unit": "image-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": f"1 symmetric pair {what}, fp32, torch CPU oracle: 1 warm-up + {len(times)} timed calls, "
+                                            f"median {med:.1f} s (all: {', '.join(f'{t:.1f}' for t in times)})",
+                                  "host_cores_available": os.cpu_count()}
 
     if rank == 0:
         print(json.dumps(result))

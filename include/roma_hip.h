@@ -55,6 +55,10 @@ int roma_finalize(roma_handle_t h);
  *         (+5 % at batch 8 with 2; side workspaces are allocated on first use; bf16 results are then reproducible only
  *         to ~1 bf16 ulp, f32 results exactly - DESIGN.md) */
 int roma_set_option(roma_handle_t h, const char* key, int value);
+/* "coarse_scale_factor": the displacement-embedding scale of the COARSE pass, sqrt(h_resized * w_resized / 560^2) of the
+ * matcher's configured resolution (matcher.py:805) - it differs from the handle's own resolution only when the caller
+ * feeds tensors of another size than the matcher was configured for (matcher.py:822-826).  0 = derive from the handle. */
+int roma_set_option_f(roma_handle_t h, const char* key, double value);
 /* im_*: [B,3,H,W] float32 normalised images (already on the device). *_hr may be NULL when
  * upsample_preds == 0.  warp_out: [B,Ho,2*Wo,4] (symmetric) or [B,Ho,Wo,4]; cert_out: [B,Ho,2*Wo] / [B,Ho,Wo]. */
 int roma_match(roma_handle_t h, int B, const float* im_a, const float* im_b, const float* im_a_hr,
@@ -62,9 +66,18 @@ int roma_match(roma_handle_t h, int B, const float* im_a, const float* im_b, con
 /* debug stage capture (enabled by roma_set_option(h,"debug",1)): copies a named intermediate to HOST memory.
  * Returns the number of bytes available when dst == NULL. */
 long roma_debug_fetch(roma_handle_t h, const char* name, void* dst_host, long nbytes);
+/* debug mode only: replace a named intermediate of the following roma_match calls by the HOST buffer given here
+ * (copied; src_host == NULL removes the override).  Stages: "gm_flow16" [b, h16*w16, 2] and "gm_cert16" [b, h16*w16]
+ * f32, b = decoder batch - the output of cls_to_flow_refine (utils/utils.py:300-322), whose arg-max is discontinuous:
+ * parity tests of the reduced-precision mode inject the oracle's coarse match and bound everything downstream. */
+int roma_debug_inject(roma_handle_t h, const char* name, const void* src_host, long nbytes);
 int roma_destroy(roma_handle_t h);
 /* Per-launch HIP-event timing of the dominant kernels (bench.py roofline pass). roma_profile_report writes a JSON
  * object {kernel: {calls,total_ms,work,unit}} (work = algorithmic FLOPs or bytes); returns bytes needed when buf==NULL. */
+/* process-wide kernel-selection switches for A/B measurements and tests (not needed for normal use): "gemm8p" 1 / 0 =
+ * route the large bf16 GEMMs to the 8-phase kernel or keep them on the one-barrier-per-slab kernel (-1 = environment
+ * ROMA_GEMM8P, default on); "gemm_dbg" = experiment bits of the GEMM kernels (-1 = environment ROMA_GEMM_DBG). */
+int roma_tuning(const char* key, int value);
 int roma_profile_enable(int on);
 long roma_profile_report(char* buf, long nbytes);
 

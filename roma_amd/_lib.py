@@ -30,9 +30,12 @@ SIGNATURES = {
     "roma_set_tensor": (_i, [_vp, C.c_char_p, _i, C.POINTER(C.c_int64), _vp, _i]),
     "roma_finalize": (_i, [_vp]),
     "roma_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "roma_set_option_f": (_i, [_vp, C.c_char_p, C.c_double]),
     "roma_match": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "roma_debug_fetch": (_l, [_vp, C.c_char_p, _vp, _l]),
+    "roma_debug_inject": (_i, [_vp, C.c_char_p, _vp, _l]),
     "roma_destroy": (_i, [_vp]),
+    "roma_tuning": (_i, [C.c_char_p, _i]),
     "roma_profile_enable": (_i, [_i]),
     "roma_profile_report": (_l, [C.c_char_p, _l]),
     "roma_op_local_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -100,6 +100,19 @@ int roma_set_option(roma_handle_t h, const char* key, int value) {
   return 0;
 }
 
+int roma_set_option_f(roma_handle_t h, const char* key, double value) {
+  ROMA_REQUIRE(h && key, "roma_set_option_f: null argument");
+  const std::string k(key);
+  if (k == "coarse_scale_factor") {
+    ROMA_REQUIRE(value >= 0.0, "roma_set_option_f: coarse_scale_factor must be >= 0 (0 = derive from the handle's resolution)");
+    h->m.coarse_scale_factor = value;
+  } else {
+    set_error("roma_set_option_f: unknown key " + k);
+    return ROMA_ERR_ARG;
+  }
+  return 0;
+}
+
 int roma_match(roma_handle_t h, int B, const float* im_a, const float* im_b, const float* im_a_hr, const float* im_b_hr,
                float* warp_out, float* cert_out, void* stream) {
   ROMA_REQUIRE(h, "roma_match: null handle");
@@ -123,8 +136,25 @@ long roma_debug_fetch(roma_handle_t h, const char* name, void* dst_host, long nb
   return (long)it->second.second;
 }
 
+int roma_debug_inject(roma_handle_t h, const char* name, const void* src_host, long nbytes) {
+  ROMA_REQUIRE(h, "roma_debug_inject: null handle");
+  return h->m.debug_inject(name, src_host, nbytes > 0 ? (size_t)nbytes : 0);
+}
+
 int roma_destroy(roma_handle_t h) {
   delete h;
+  return 0;
+}
+
+int roma_tuning(const char* key, int value) {
+  ROMA_REQUIRE(key, "roma_tuning: null key");
+  const std::string k(key);
+  if (k == "gemm8p") g_gemm_tuning[0] = value;
+  else if (k == "gemm_dbg") g_gemm_tuning[1] = value;
+  else {
+    set_error("roma_tuning: unknown key " + k);
+    return ROMA_ERR_ARG;
+  }
   return 0;
 }
 

@@ -43,10 +43,14 @@ struct GemmArgs {
   const float *nx = nullptr, *ny = nullptr;
   long sNx = 0, sNy = 0;
   float inv_t = 0.f, diag_add = 0.f;
+  int m_alg = 0;  // set by gemm_launch with qkv_pad: the caller's (algorithmic) M, for the FLOP count of the profile scope
   int dbg = 0;  // tuning experiments only (ROMA_GEMM_DBG): 1 = skip output stores, 2 = skip the K loop
 };
 
 // Launches on `stream`; returns 0 or a negative error code (message via roma_last_error()).
 int gemm_launch(const GemmArgs& a, hipStream_t stream);
+// 8-phase 256 x 256 bf16 kernel (gemm8p.hip): 0 = launched, 1 = not its problem (gemm.hip runs it), < 0 = error
+int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream);
+extern int g_gemm_tuning[2];  // process-wide A/B switches (roma_tuning): [0] use gemm8p (-1 = env ROMA_GEMM8P, default on), [1] dbg bits
 
 }  // namespace roma

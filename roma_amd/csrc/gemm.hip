@@ -497,12 +497,16 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   char pname[96];
   snprintf(pname, sizeof pname, "gemm_kernel<%s,%s,%d,%d,%d,%d,%s>", sizeof(TIN) == 4 ? "f32" : "bf16",
            sizeof(TOUT) == 4 ? "f32" : "bf16", WM, WN, TM, TN, CONV ? "conv3x3" : "dense");
-  ProfScope ps(pname, 2.0 * (double)a.M * a.N * a.K * a.batch * (a.lower_only ? 0.5 : 1.0), "flop", stream);
-  static bool attr_set = false;
-  if (!attr_set) {
+  // algorithmic FLOPs: the caller's M (a.M may have been padded to npad tokens per image for the QKV epilogue)
+  ProfScope ps(pname, 2.0 * (double)(a.m_alg > 0 ? a.m_alg : a.M) * a.N * a.K * a.batch * (a.lower_only ? 0.5 : 1.0), "flop", stream);
+  // the > 64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: one flag per device ordinal
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  ROMA_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TIN, TOUT, WM, WN, TM, TN, CONV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL((gemm_kernel<TIN, TOUT, WM, WN, TM, TN, CONV>), grid, dim3(WM * WN * 64), lds, stream, a);
   ROMA_LAUNCH_CHECK();
@@ -536,7 +540,7 @@ static int launch_shape(const GemmArgs& a, hipStream_t stream) {
 int gemm_launch(const GemmArgs& a0, hipStream_t stream) {
   GemmArgs a = a0;
   static const int dbg_env = getenv("ROMA_GEMM_DBG") ? atoi(getenv("ROMA_GEMM_DBG")) : 0;
-  a.dbg = dbg_env;
+  a.dbg = g_gemm_tuning[1] >= 0 ? g_gemm_tuning[1] : dbg_env;
   const int ce = a.in_dt == DT_F32 ? 4 : 8;
   ROMA_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "gemm: empty problem");
   ROMA_REQUIRE(a.K % ce == 0, "gemm: K must be a multiple of the 16-byte chunk");
@@ -567,8 +571,13 @@ int gemm_launch(const GemmArgs& a0, hipStream_t stream) {
         (reinterpret_cast<uintptr_t>(a.q) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.k) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(a.vt) & 15) == 0) {
       a.qkv_pad = 1;
+      a.m_alg = a.M;
       a.M = (a.M / a.ntok) * a.npad;
     }
+  }
+  {
+    const int r8 = gemm8p_try_launch(a, stream);
+    if (r8 <= 0) return r8;
   }
 #define ROMA_GEMM_DISPATCH(TIN, TOUT)                                              \
   return conv ? launch_shape<TIN, TOUT, true>(a, stream) : launch_shape<TIN, TOUT, false>(a, stream)

@@ -1,0 +1,413 @@
+// 8-phase bf16 MFMA GEMM for gfx950: the large, MFMA-bound problems of the match() path (DINOv2 / decoder linears,
+// stride-16 refiner 1x1, VGG 3x3 implicit GEMM with >= 256 output channels).  C[M,N] = epi(A[M,K] . W[N,K]^T).
+//
+// Why a second main loop (gemm.hip keeps every other shape): gemm.hip's loop has ONE barrier per 64-deep K slab, both
+// wave groups in lock-step, a vmcnt(0) drain per slab and ~1000 instructions of branchy per-slab DMA address selection
+// (tails, zero page, conv taps).  SQ counters (profiles/r01_pmc_sq_summary.json): 39 % of the wave cycles parked at
+// s_waitcnt / s_barrier, 33 % issue stalls, MFMA busy 0.33.  This kernel follows the "256^2 8-phase" anatomy of
+// /opt/skills/guides/cdna_hip_programming.md section 5, restated for the 32x32x16 MFMA and 128-byte swizzled LDS rows:
+//
+//   * 256 x 256 x 64 tiles, 8 waves = 2 wave groups (wr) x 4 column slices (wc); waves w and w + 4 share a SIMD and
+//     belong to different groups.  Group 1 runs ONE s_barrier behind group 0, so between two consecutive barriers one
+//     group is in its load block (LDS fragment reads + one half-tile of LDS-DMA) while the other is in its MFMA block:
+//     the matrix pipe of every SIMD always has a wave with operands in registers.
+//   * wave (wr, wc) owns the contiguous 128 x 64 block rows [128 wr, +128) x cols [64 wc, +64) of the tile (so the
+//     staged row-writer epilogues of gemm_device.h apply unchanged), as four 64 x 32 quadrants (mh, nh).  The LDS image
+//     is permuted so that quadrant operands are whole half-tiles: A half mh = rows {128 wr + 64 mh + [0, 64)},
+//     W half nh = rows {64 wc + 32 nh + [0, 32)}.  LDS-DMA writes lane-linear, the SOURCE address is per lane, so the
+//     permutation (and the XOR bank swizzle) costs nothing.
+//   * one K tile = 4 phases: P1 reads A0 + W0 -> quadrant (0,0); P2 reads W1 -> (0,1); P3 reads A1 -> (1,1);
+//     P4 reads nothing -> (1,0).  Every phase: [fragment reads][DMA of one half-tile][vmcnt at P4] s_barrier,
+//     lgkmcnt(0), 8 MFMAs, s_barrier.
+//   * LDS-DMA runs 1.5 K tiles ahead of the math through two 64 KB buffers, as ONE stream over all the (tile, k)
+//     positions a persistent workgroup will visit - P1(s): W1(s+1), P2(s): A1(s+1), P3(s): A0(s+2), P4(s): W0(s+2),
+//     then vmcnt(4) - so the first K tiles of the next output tile arrive under the current tile's last MFMAs and its
+//     epilogue.  A region is re-staged >= 2 phases after its last read; the counted vmcnt at P4 leaves only the two
+//     half-tiles of s+2 in flight and sits before P4's first barrier, the first read of s+1 is in the next phase
+//     (wait -> barrier -> read).  vmcnt also counts the epilogue's global stores; they are older than the DMA pieces the
+//     wait must leave in flight, so a counted wait stays conservative.
+//   * the per-phase DMA issue is 2 instructions + 2 64-bit adds per wave: M / N tails and padded QKV tokens point at
+//     a zero buffer (fixed once per tile), K must be a multiple of 64; the 3x3 convolution selects {pixel + tap offset,
+//     zero page} per piece from a 9-bit validity mask computed once per tile.
+//   * fragment reads are inline asm (hipcc would drain the DMA queue before any LDS read it can see).  The wait that
+//     covers them names every destination register as a read-write operand, so no consumer can be scheduled above it;
+//     tools/audit_gemm8p_isa.py checks in the emitted ISA that nothing touches those registers between a read and its
+//     wait.
+#include "gemm.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "gemm_device.h"
+
+namespace roma {
+
+// zero source for out-of-range rows of the dense form: the per-k-tile byte offset (k * 128) is added to EVERY lane's
+// pointer, so the zero "row" must be as long as the longest K row (K <= 32704 bf16)
+static __device__ __attribute__((aligned(256))) unsigned int g_zero_rows[16384];
+
+int g_gemm_tuning[2] = {-1, -1};  // [0] gemm8p on / off, [1] dbg bits; -1 = environment (roma_tuning, tests / A-B runs)
+
+enum { E8_NONE = 0, E8_RELU = 1, E8_GELU = 2, E8_RESBF16 = 3, E8_QKV = 4 };
+
+#define R8_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define R8_DS_READ(REG, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(REG) : "v"(ADDR), "n"(OFF))
+
+template <typename TOUT, bool CONV, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int TILE_A = BM * ROWB, BUF = TILE_A + BN * ROWB;  // 64 KiB per K tile
+  constexpr int TM = 4, TN = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // ---- persistent tile walk, XCD-aware (workgroup b runs on XCD b % 8; each XCD walks a contiguous band, n fastest)
+  const int NT = (a.N + BN - 1) / BN;
+  const long nblk = (long)((a.M + BM - 1) / BM) * NT;
+  const long per_xcd = (nblk + 7) / 8;
+  const int xcd = blockIdx.x % 8;
+  const long wg_per_xcd = gridDim.x / 8;
+  long li = blockIdx.x / 8;
+  if (li >= per_xcd || (long)xcd * per_xcd + li >= nblk) return;
+
+  const bf16_t* Ab = reinterpret_cast<const bf16_t*>(a.A);
+  const bf16_t* Wb = reinterpret_cast<const bf16_t*>(a.W);
+  const char* zrows = reinterpret_cast<const char*>(g_zero_rows);
+  const int nk = a.K / BK;
+
+  // ---- LDS-DMA descriptors.  A half-tile is 128 LDS rows = 16 pieces of 8 rows; wave w stages pieces 2w, 2w + 1 of
+  // every half-tile.  lane -> (row r8 of the piece, 16-byte slot); the slot holds source chunk slot ^ ((row >> 1) & 7).
+  const char* a_src[2][2];  // [half][piece]
+  const char* w_src[2][2];
+  unsigned a_mask[2][2];    // conv: bit t = tap t of this row is inside the image
+  // descriptors of tile (TMI, TNI) - the DMA stream runs ahead of the math, so they may describe the NEXT output tile
+#define R8_TILE_SETUP(TMI, TNI)                                                                               \
+  {                                                                                                           \
+    const int d_m0 = (TMI) * BM, d_n0 = (TNI) * BN;                                                           \
+    /* opaque lane id: everything derived from it is computed HERE, once per tile, instead of being hoisted to */ \
+    /* kernel entry and kept (or spilled) across the K loop, which has no registers to spare                    */ \
+    int ln_ = lane;                                                                                           \
+    asm volatile("" : "+v"(ln_));                                                                             \
+    const int r8 = ln_ >> 3, slot = ln_ & 7;                                                                  \
+    _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) _Pragma("unroll") for (int j = 0; j < 2; ++j) {          \
+      const int i = 16 * wave + 8 * j + r8; /* LDS row inside the half-tile */                                \
+      const int chunk = slot ^ ((i >> 1) & 7);                                                                \
+      const int gm = d_m0 + (i >> 6) * 128 + hf * 64 + (i & 63); /* M < 2^31: 32-bit divisions below */        \
+      const int gn = d_n0 + (i >> 5) * 64 + hf * 32 + (i & 31);                                               \
+      w_src[hf][j] = gn < a.N ? reinterpret_cast<const char*>(Wb + (long)gn * a.ldw + chunk * 8) : zrows + chunk * 16; \
+      if constexpr (CONV) {                                                                                   \
+        unsigned mk = 0;                                                                                      \
+        const char* p = zrows;                                                                                \
+        if (gm < a.M) {                                                                                       \
+          const int hw = a.conv_h * a.conv_w;                                                                 \
+          const int b = gm / hw;                                                                              \
+          const int rem = gm - b * hw;                                                                        \
+          const int y = rem / a.conv_w, x = rem - y * a.conv_w;                                               \
+          _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                     \
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;                                                 \
+            if (yy >= 0 && yy < a.conv_h && xx >= 0 && xx < a.conv_w) mk |= 1u << t;                          \
+          }                                                                                                   \
+          p = reinterpret_cast<const char*>(Ab + (long)gm * a.conv_c + chunk * 8);                            \
+        }                                                                                                     \
+        a_mask[hf][j] = mk;                                                                                   \
+        a_src[hf][j] = p;                                                                                     \
+      } else {                                                                                                \
+        a_mask[hf][j] = 0;                                                                                    \
+        const char* p = zrows + chunk * 16;                                                                   \
+        if (gm < a.M) {                                                                                       \
+          if (a.qkv_pad) { /* rows = (image, padded token); tokens >= ntok read zeros */                      \
+            const int qb_ = gm / a.npad;                                                                      \
+            const int qt_ = gm - qb_ * a.npad;                                                                \
+            if (qt_ < a.ntok) p = reinterpret_cast<const char*>(Ab + ((long)qb_ * a.ntok + qt_) * a.lda + chunk * 8); \
+          } else {                                                                                            \
+            p = reinterpret_cast<const char*>(Ab + (long)gm * a.lda + chunk * 8);                             \
+          }                                                                                                   \
+        }                                                                                                     \
+        a_src[hf][j] = p;                                                                                     \
+      }                                                                                                       \
+    }                                                                                                         \
+  }
+
+  // K position KP (in K tiles, of the DMA tile) of A half HF into LDS buffer BSEL
+#define R8_ISSUE_A(HF, KP, BSEL)                                                                              \
+  {                                                                                                           \
+    char* dst_ = smem + (BSEL) * BUF + (HF) * 128 * ROWB + (2 * wave) * 1024;                                 \
+    if constexpr (CONV) {                                                                                     \
+      const int tap_ = ((KP) * conv_inv) >> 16;                                                               \
+      const int c0_ = ((KP) - tap_ * conv_spt) * BK;                                                          \
+      const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                                          \
+      const long soff_ = (((long)dy_ * a.conv_w + dx_) * a.conv_c + c0_) * 2;                                 \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                         \
+        const bool ok_ = (a_mask[HF][j] >> tap_) & 1u;                                                        \
+        glds16(ok_ ? a_src[HF][j] + soff_ : zrows + (lane & 7) * 16, dst_ + j * 1024);                        \
+      }                                                                                                       \
+    } else {                                                                                                  \
+      const long soff_ = (long)(KP) * (BK * 2);                                                               \
+      glds16(a_src[HF][0] + soff_, dst_);                                                                     \
+      glds16(a_src[HF][1] + soff_, dst_ + 1024);                                                              \
+    }                                                                                                         \
+  }
+#define R8_ISSUE_W(HF, KP, BSEL)                                                                              \
+  {                                                                                                           \
+    char* dst_ = smem + (BSEL) * BUF + TILE_A + (HF) * 128 * ROWB + (2 * wave) * 1024;                        \
+    const long soff_ = (long)(KP) * (BK * 2);                                                                 \
+    glds16(w_src[HF][0] + soff_, dst_);                                                                       \
+    glds16(w_src[HF][1] + soff_, dst_ + 1024);                                                                \
+  }
+  const int conv_spt = CONV ? a.conv_c / BK : 1;                  // K tiles per 3x3 tap
+  const int conv_inv = CONV ? 65536 / conv_spt + 1 : 0;           // tap = (k * inv) >> 16, exact for k < 9 * spt <= 72
+
+  // ---- fragment read addresses: row = block_row0 + l31 (block_row0 % 32 == 0), 16-byte slot (2g + h) ^ ((l31 >> 1) & 7)
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+  const int sw = (l31 >> 1) & 7;
+  unsigned rd[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) rd[g] = (unsigned)(l31 * ROWB + (((2 * g + h) ^ sw) << 4));
+  const unsigned a_row0 = (unsigned)((64 * wr) * ROWB);           // + mh * 128 rows + mt * 32 rows
+  const unsigned w_row0 = (unsigned)(TILE_A + (32 * wc) * ROWB);  // + nh * 128 rows
+
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 af[2][4], bf0[4], bf1[4];  // A fragments [mt][k-group] of the current 64-row half; W fragments of both halves
+
+#define R8_READ_A(MH, SB)                                                                                     \
+  _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int g = 0; g < 4; ++g)               \
+      R8_DS_READ(af[mt][g], (SB) + a_row0 + rd[g], ((MH) * 128 + mt * 32) * ROWB);
+#define R8_READ_W(BF, NH, SB) \
+  _Pragma("unroll") for (int g = 0; g < 4; ++g) R8_DS_READ(BF[g], (SB) + w_row0 + rd[g], ((NH) * 128) * ROWB);
+  // waits: every register the covered reads write is a read-write operand, so no consumer can move above the wait
+#define R8_WAIT_LGKM_W(BF) \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(BF[0]), "+v"(BF[1]), "+v"(BF[2]), "+v"(BF[3])::"memory")
+#define R8_WAIT_LGKM_A()                                                                                       \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                          \
+               : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(af[1][0]), "+v"(af[1][1]), \
+                 "+v"(af[1][2]), "+v"(af[1][3])::"memory")
+#define R8_WAIT_LGKM_AW(BF)                                                                                    \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                          \
+               : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(af[1][0]), "+v"(af[1][1]), \
+                 "+v"(af[1][2]), "+v"(af[1][3]), "+v"(BF[0]), "+v"(BF[1]), "+v"(BF[2]), "+v"(BF[3])::"memory")
+  // D[n][m] += W[n][k] A[m][k]: the W fragment is the first operand, so a lane owns 4 consecutive n of one m
+#define R8_MFMA_Q(MH, NH, BF)                                                                                  \
+  _Pragma("unroll") for (int g = 0; g < 4; ++g) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                 \
+      acc[NH][(MH) * 2 + mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, BF[g]),    \
+                                                                       __builtin_bit_cast(bf16x8_t, af[mt][g]), \
+                                                                       acc[NH][(MH) * 2 + mt], 0, 0, 0);
+#define R8_PHASE(WAIT, MF)                       \
+  __builtin_amdgcn_sched_barrier(0);             \
+  __builtin_amdgcn_s_barrier();                  \
+  WAIT;                                          \
+  __builtin_amdgcn_sched_barrier(0);             \
+  if (prio) __builtin_amdgcn_s_setprio(1);       \
+  MF;                                            \
+  if (prio) __builtin_amdgcn_s_setprio(0);       \
+  __builtin_amdgcn_sched_barrier(0);             \
+  __builtin_amdgcn_s_barrier();                  \
+  __builtin_amdgcn_sched_barrier(0);
+
+  const bool prio = !(a.dbg & 64);
+  const bool stagger = !(a.dbg & 128);
+
+  // tile coordinates advance incrementally (one scalar division pair here, none per tile)
+  int c_tm = (int)(((long)xcd * per_xcd + li) / NT), c_tn = (int)(((long)xcd * per_xcd + li) % NT);
+  const int step_m = (int)(wg_per_xcd / NT), step_n = (int)(wg_per_xcd % NT);
+
+  // ---- prologue: K tile 0 complete, A0 / W0 of K tile 1 under way (nk >= 2 is guaranteed by the dispatcher)
+  R8_TILE_SETUP(c_tm, c_tn);
+  R8_ISSUE_A(0, 0, 0) R8_ISSUE_W(0, 0, 0) R8_ISSUE_W(1, 0, 0) R8_ISSUE_A(1, 0, 0)
+  R8_ISSUE_A(0, 1, 1) R8_ISSUE_W(0, 1, 1)
+  R8_WAIT_VM(4);
+  __builtin_amdgcn_s_barrier();
+  if (stagger && wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0 from here on
+
+  unsigned gk = 0;  // stream position of the math (parity = LDS buffer)
+  for (;;) {
+    const long m0 = (long)c_tm * BM;
+    const int n0 = c_tn * BN;
+    const long li_next = li + wg_per_xcd;
+    const bool has_next = li_next < per_xcd && (long)xcd * per_xcd + li_next < nblk;
+    int n_tm = c_tm + step_m, n_tn = c_tn + step_n;
+    if (n_tn >= NT) {
+      n_tn -= NT;
+      ++n_tm;
+    }
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt, ++gk) {
+      const unsigned cb = gk & 1u;
+      const unsigned sb = lds0 + cb * BUF;
+      // stream positions s+1 (P1, P2) and s+2 (P3, P4): inside this tile, or the head of the next one
+      const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
+      const bool n1 = in1 || has_next, n2 = in2 || has_next;
+      const int k1 = in1 ? kt + 1 : 0, k2 = in2 ? kt + 2 : kt + 2 - nk;
+      // Nothing of this wave is outstanding on LGKM here (P4 reads nothing).  Saying so in a form the compiler sees keeps
+      // its loop-carried bookkeeping (the epilogue's own LDS reads) from dropping an s_waitcnt lgkmcnt(0) between the
+      // asm fragment reads below (it did: one ~100-cycle stall per K tile).
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+      // P1: A0 + W0 -> (0,0); stage W1(s+1)
+      R8_READ_W(bf0, 0, sb)
+      __builtin_amdgcn_sched_barrier(0);
+      R8_READ_A(0, sb)
+      if (n1) R8_ISSUE_W(1, k1, cb ^ 1u)
+      R8_PHASE(R8_WAIT_LGKM_AW(bf0), R8_MFMA_Q(0, 0, bf0))
+      // P2: W1 -> (0,1); stage A1(s+1)
+      R8_READ_W(bf1, 1, sb)
+      if (n1) R8_ISSUE_A(1, k1, cb ^ 1u)
+      R8_PHASE(R8_WAIT_LGKM_W(bf1), R8_MFMA_Q(0, 1, bf1))
+      // P3: A1 -> (1,1); stage A0(s+2).  The DMA stream enters the next output tile here when kt == nk - 2.
+      R8_READ_A(1, sb)
+      if (in1 && !in2 && has_next) R8_TILE_SETUP(n_tm, n_tn)
+      if (n2) R8_ISSUE_A(0, k2, cb)
+      R8_PHASE(R8_WAIT_LGKM_A(), R8_MFMA_Q(1, 1, bf1))
+      // P4: no reads -> (1,0); stage W0(s+2); all of s+1 must have landed before this phase's first barrier
+      if (n2) {
+        R8_ISSUE_W(0, k2, cb)
+        R8_WAIT_VM(4);
+      } else {
+        R8_WAIT_VM(0);
+      }
+      R8_PHASE(, R8_MFMA_Q(1, 0, bf0))
+    }
+    li = li_next;
+    c_tm = n_tm;
+    c_tn = n_tn;
+
+    // ---------------------------------------------------------------- epilogue (staged row writers, gemm_device.h)
+    {
+      constexpr int SLICE = 4096;  // bf16: 32 rows x 128 B of the wave's 64 columns; f32: one 32 x 32 block
+      char* ws = smem + 2 * BUF + wave * SLICE;
+      const long mw0 = m0 + (long)wr * 128;
+      const int nw0 = n0 + wc * 64;
+      int lane_e = lane;  // opaque copy: the epilogue's lane-dependent addresses are built here, not before the K loop
+      asm volatile("" : "+v"(lane_e));
+      const bool full_tile = m0 + BM <= a.M && n0 + BN <= a.N;
+      if constexpr (sizeof(TOUT) == 2) {
+        bf16_t* Cbb = reinterpret_cast<bf16_t*>(a.C);
+        if constexpr (EPI == E8_QKV) {
+          epi_staged_qkv<TM, TN>(acc, a, ws, mw0, nw0, lane_e);
+        } else if constexpr (EPI == E8_GELU) {
+          if (full_tile) epi_staged_bf16<TM, TN, ACT_GELU, true>(acc, a, Cbb, ws, mw0, nw0, lane_e);
+          else epi_staged_bf16<TM, TN, ACT_GELU, false>(acc, a, Cbb, ws, mw0, nw0, lane_e);
+        } else if constexpr (EPI == E8_RELU) {
+          if (full_tile) epi_staged_bf16<TM, TN, ACT_RELU, true>(acc, a, Cbb, ws, mw0, nw0, lane_e);
+          else epi_staged_bf16<TM, TN, ACT_RELU, false>(acc, a, Cbb, ws, mw0, nw0, lane_e);
+        } else if constexpr (EPI == E8_RESBF16) {
+          const bf16_t* Rbb = reinterpret_cast<const bf16_t*>(a.res_bf16);
+          if (full_tile) epi_staged_bf16<TM, TN, ACT_NONE, true, true>(acc, a, Cbb, ws, mw0, nw0, lane_e, Rbb);
+          else epi_staged_bf16<TM, TN, ACT_NONE, false, true>(acc, a, Cbb, ws, mw0, nw0, lane_e, Rbb);
+        } else {
+          if (full_tile) epi_staged_bf16<TM, TN, ACT_NONE, true>(acc, a, Cbb, ws, mw0, nw0, lane_e);
+          else epi_staged_bf16<TM, TN, ACT_NONE, false>(acc, a, Cbb, ws, mw0, nw0, lane_e);
+        }
+      } else {
+        float* Cbf = reinterpret_cast<float*>(a.C);
+        if constexpr (EPI == E8_RELU) {
+          if (full_tile) epi_staged_f32<TM, TN, ACT_RELU, true>(acc, a, Cbf, a.res, ws, mw0, nw0, lane_e);
+          else epi_staged_f32<TM, TN, ACT_RELU, false>(acc, a, Cbf, a.res, ws, mw0, nw0, lane_e);
+        } else {
+          if (full_tile) epi_staged_f32<TM, TN, ACT_NONE, true>(acc, a, Cbf, a.res, ws, mw0, nw0, lane_e);
+          else epi_staged_f32<TM, TN, ACT_NONE, false>(acc, a, Cbf, a.res, ws, mw0, nw0, lane_e);
+        }
+      }
+    }
+    if (!has_next) break;
+  }
+  if (stagger && wr == 0) __builtin_amdgcn_s_barrier();  // group 0 meets group 1's extra barrier
+#undef R8_PHASE
+#undef R8_MFMA_Q
+#undef R8_WAIT_LGKM_AW
+#undef R8_WAIT_LGKM_A
+#undef R8_WAIT_LGKM_W
+#undef R8_READ_W
+#undef R8_READ_A
+#undef R8_ISSUE_W
+#undef R8_ISSUE_A
+#undef R8_TILE_SETUP
+}
+
+template <typename TOUT, bool CONV, int EPI>
+static int launch8p(const GemmArgs& a, hipStream_t stream, const char* epi_name) {
+  constexpr int BM = 256, BN = 256;
+  const long nblk = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  const size_t lds = (size_t)2 * (BM + BN) * ROWB + 8 * 4096;  // 160 KiB: one persistent workgroup per CU
+  const long gx = std::min<long>(((nblk + 7) / 8) * 8, 256);
+  char pname[96];
+  snprintf(pname, sizeof pname, "gemm8p_kernel<bf16,%s,%s,%s>", sizeof(TOUT) == 4 ? "f32" : "bf16", CONV ? "conv3x3" : "dense", epi_name);
+  ProfScope ps(pname, 2.0 * (double)(a.m_alg > 0 ? a.m_alg : a.M) * a.N * a.K, "flop", stream);
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  ROMA_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<TOUT, CONV, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((gemm8p_kernel<TOUT, CONV, EPI>), dim3((unsigned)gx), dim3(512), lds, stream, a);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// Decides whether this problem belongs to the 8-phase kernel and launches it; returns 1 when it did not take the
+// problem (the caller falls back to gemm.hip), 0 on success, < 0 on error.  `a` is the argument block AFTER
+// gemm_launch's own normalisation (qkv_pad / m_alg already applied).
+int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
+  static const int use_env = getenv("ROMA_GEMM8P") ? atoi(getenv("ROMA_GEMM8P")) : 1;
+  const int use = g_gemm_tuning[0] >= 0 ? g_gemm_tuning[0] : use_env;
+  if (!use) return 1;
+  if ((long)a.M * 1 >= (1L << 31) - 512) return 1;
+  if (a.in_dt != DT_BF16 || a.batch != 1 || a.lower_only || a.alpha != 1.0f) return 1;
+  if (a.K % 64 != 0 || a.K < 4 * 64 || a.K > 32704) return 1;
+  const bool conv = a.conv_c > 0;
+  if (conv && (a.conv_c % 64 != 0 || a.conv_c > 512)) return 1;
+  // shapes gemm.hip would run on 256 x 256 tiles
+  const bool big_m = (long)a.M >= 8192;
+  if (!big_m) return 1;
+  bool tile256 = false;
+  if (a.N >= 384) {
+    const long w256 = ((a.N + 255) / 256) * 256, w192 = ((a.N + 191) / 192) * 192;
+    tile256 = !(w192 < w256);
+  } else if (a.N > 192 && a.N <= 256) {
+    tile256 = true;
+  }
+  if (!tile256) return 1;
+  if ((reinterpret_cast<uintptr_t>(a.C) & 15) != 0) return 1;
+  if (a.out_dt == DT_BF16) {
+    if (a.mode == EPI_QKV) {
+      if (!a.qkv_pad || conv || (a.heads * a.hd) % 64 != 0) return 1;
+      return launch8p<bf16_t, false, E8_QKV>(a, stream, "qkv");
+    }
+    if (a.mode != EPI_STD || a.res != nullptr || (a.ldc & 7) != 0) return 1;
+    if (a.res_bf16) {
+      if (conv || a.act != ACT_NONE) return 1;
+      return launch8p<bf16_t, false, E8_RESBF16>(a, stream, "res_bf16");
+    }
+    if (conv) {
+      if (a.act != ACT_RELU) return 1;
+      return launch8p<bf16_t, true, E8_RELU>(a, stream, "relu");
+    }
+    if (a.act == ACT_GELU) return launch8p<bf16_t, false, E8_GELU>(a, stream, "gelu");
+    if (a.act == ACT_RELU) return launch8p<bf16_t, false, E8_RELU>(a, stream, "relu");
+    return launch8p<bf16_t, false, E8_NONE>(a, stream, "none");
+  }
+  if (a.out_dt == DT_F32) {
+    if (conv || a.mode != EPI_STD || a.act == ACT_GELU || a.res_bf16) return 1;
+    if ((a.ldc & 3) != 0 || (a.N & 3) != 0) return 1;
+    if (a.res && ((a.ldr & 3) != 0 || (reinterpret_cast<uintptr_t>(a.res) & 15) != 0)) return 1;
+    if (a.act == ACT_RELU) return launch8p<float, false, E8_RELU>(a, stream, "relu");
+    return launch8p<float, false, E8_NONE>(a, stream, "none");
+  }
+  return 1;
+}
+
+}  // namespace roma

@@ -69,6 +69,7 @@ class Model {
   // input are cast to amp_dtype); the decoder transformer keeps f32 (autocast leaves its residual f32).  Option
   // "vit_bf16_residual"; env ROMA_VIT_RES_F32=1 forces the f32 stream for A/B runs.
   bool vit_bf16_residual = true;
+  double coarse_scale_factor = 0.0;  // roma_set_option_f; 0 = sqrt(coarse_h * coarse_w / 560^2)
   std::map<std::string, HostTensor> host;
 
   // packed weights (device)
@@ -102,6 +103,11 @@ class Model {
   hipEvent_t ev_fork = nullptr, ev_join[MAX_STREAMS - 1] = {nullptr};
   std::vector<void*> owned;  // device allocations to free
   std::map<std::string, std::pair<void*, size_t>> dbg;
+  // debug mode only (roma_debug_inject): device buffers that REPLACE a named intermediate of the next match() calls.
+  // "gm_flow16" [ndp, T, 2] / "gm_cert16" [ndp, T] f32 overwrite the output of cls_to_flow_refine, so a parity test can
+  // pin the (discontinuous) coarse arg-max to the oracle's and hold everything downstream to a continuous bound.
+  std::map<std::string, std::pair<void*, size_t>> inject;
+  int debug_inject(const char* name, const void* host, size_t bytes);
 
   ~Model();
   int set_tensor(const char* name, int ndim, const int64_t* shape, const void* data, int is_int64);

@@ -33,6 +33,26 @@ Model::~Model() {
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   for (void* p : owned) (void)hipFree(p);
   for (auto& kv : dbg) (void)hipFree(kv.second.first);
+  for (auto& kv : inject) (void)hipFree(kv.second.first);
+}
+
+int Model::debug_inject(const char* name, const void* host, size_t bytes) {
+  ROMA_REQUIRE(name, "roma_debug_inject: null name");
+  const std::string k(name);
+  ROMA_REQUIRE(k == "gm_flow16" || k == "gm_cert16", "roma_debug_inject: unknown stage (gm_flow16, gm_cert16)");
+  ROMA_CHECK_HIP(hipSetDevice(cfg.device));
+  auto it = inject.find(k);
+  if (it != inject.end()) {
+    ROMA_CHECK_HIP(hipDeviceSynchronize());
+    (void)hipFree(it->second.first);
+    inject.erase(it);
+  }
+  if (!host || bytes == 0) return 0;
+  void* p = nullptr;
+  ROMA_CHECK_HIP(hipMalloc(&p, bytes));
+  ROMA_CHECK_HIP(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+  inject[k] = {p, bytes};
+  return 0;
 }
 
 int Model::set_tensor(const char* name, int ndim, const int64_t* shape, const void* data, int is_int64) {
@@ -764,7 +784,8 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       RUN(resize_bilinear_launch(flow_p1, flow, ndp, cfg.coarse_h, cfg.coarse_w, ch, cw, 2, st));
       RUN(resize_bilinear_launch(cert_p1, cert, ndp, cfg.coarse_h, cfg.coarse_w, ch, cw, 1, st));
     }
-    const double scale_factor = sqrt((double)H * (double)W / (560.0 * 560.0));  // matcher.py:805, 877-881
+    double scale_factor = sqrt((double)H * (double)W / (560.0 * 560.0));  // matcher.py:805, 877-881
+    if (!up && coarse_scale_factor > 0.0) scale_factor = coarse_scale_factor;
     for (int si = up ? 1 : 0; si < 5; ++si) {
       const int ins = SCALE_INT[si];
       const int hs = ins == 16 ? th : H / ins, ws = ins == 16 ? tw : W / ins;
@@ -859,6 +880,18 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           if (int rc = dbg_save("logits16", logits, (size_t)rows_t * ldl * 4, st)) return rc;
         RUN(cls_to_flow_launch(logits, ldl, flow, cert, rows_t, st));
         ch = th; cw = tw;
+        if (debug && !dry) {  // tests: the computed coarse match first (so the flips can be counted), then the override
+          if (int rc = dbg_save("gm_flow16_own", flow, (size_t)rows_t * 2 * 4, st)) return rc;
+          auto inj = [&](const char* nm, float* dst, size_t bytes) -> int {
+            auto it = inject.find(nm);
+            if (it == inject.end()) return 0;
+            ROMA_REQUIRE(it->second.second == bytes, "roma_debug_inject: injected stage has the wrong size for this batch");
+            ROMA_CHECK_HIP(hipMemcpyAsync(dst, it->second.first, bytes, hipMemcpyDeviceToDevice, st));
+            return 0;
+          };
+          if (int rc = inj("gm_flow16", flow, (size_t)rows_t * 2 * 4)) return rc;
+          if (int rc = inj("gm_cert16", cert, (size_t)rows_t * 4)) return rc;
+        }
         if (debug && !dry) {
           if (int rc = dbg_save("gm_flow16", flow, (size_t)rows_t * 2 * 4, st)) return rc;
           if (int rc = dbg_save("gm_cert16", cert, (size_t)rows_t * 4, st)) return rc;

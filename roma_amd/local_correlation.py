@@ -46,9 +46,10 @@ def local_corr(feature0: torch.Tensor, feature1: torch.Tensor, warp: torch.Tenso
     wp = warp.float().contiguous()
     out = torch.empty((B, H * W, K), device=f0.device, dtype=torch.float32)
     stream = torch.cuda.current_stream(f0.device).cuda_stream
-    _lib.check(_lib.load().roma_op_local_corr(C.c_void_p(f0.data_ptr()), C.c_void_p(f1.data_ptr()),
-                                              C.c_void_p(wp.data_ptr()), C.c_void_p(out.data_ptr()), B, H, W, Cc, K,
-                                              _dt(f0), _lib.ROMA_F32, C.c_void_p(stream)))
+    with torch.cuda.device(f0.device):  # the C ABI launches on the CURRENT device: make it the tensors' device
+        _lib.check(_lib.load().roma_op_local_corr(C.c_void_p(f0.data_ptr()), C.c_void_p(f1.data_ptr()),
+                                                  C.c_void_p(wp.data_ptr()), C.c_void_p(out.data_ptr()), B, H, W, Cc, K,
+                                                  _dt(f0), _lib.ROMA_F32, C.c_void_p(stream)))
     return out
 
 
@@ -71,7 +72,8 @@ def local_correlation(feature0: torch.Tensor, feature1: torch.Tensor, local_radi
     wp = warp.permute(0, 2, 3, 1).float().contiguous()
     out = torch.empty((B, h * w, K), device=f0.device, dtype=torch.float32)
     stream = torch.cuda.current_stream(f0.device).cuda_stream
-    _lib.check(_lib.load().roma_op_local_corr_window(C.c_void_p(f0.data_ptr()), C.c_void_p(f1.data_ptr()),
-                                                     C.c_void_p(wp.data_ptr()), C.c_void_p(out.data_ptr()), B, h, w, c, r,
-                                                     1.0 / (c ** 0.5), K, _dt(f0), _lib.ROMA_F32, C.c_void_p(stream)))
+    with torch.cuda.device(f0.device):
+        _lib.check(_lib.load().roma_op_local_corr_window(C.c_void_p(f0.data_ptr()), C.c_void_p(f1.data_ptr()),
+                                                         C.c_void_p(wp.data_ptr()), C.c_void_p(out.data_ptr()), B, h, w, c, r,
+                                                         1.0 / (c ** 0.5), K, _dt(f0), _lib.ROMA_F32, C.c_void_p(stream)))
     return out.permute(0, 2, 1).reshape(B, K, h, w)

@@ -87,6 +87,13 @@ class RegressionMatcher:
         self.upsample_res = _to_hw(upsample_res) or (14 * 16 * 6, 14 * 16 * 6)
         self.symmetric = symmetric
         self.sample_thresh = sample_thresh
+        if amp_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError(f"amp_dtype must be torch.float32, torch.bfloat16 or torch.float16 (got {amp_dtype})")
+        if amp_dtype == torch.float16:
+            # the reference's GPU default (model_zoo/__init__.py:37); gfx950's MFMA has one 16-bit rate for both formats
+            # and this library stores its reduced-precision activations as bf16 (8-bit mantissa, f32 range)
+            warn("roma_amd: amp_dtype=torch.float16 runs in bfloat16 (f32 accumulate); pass torch.float32 for the "
+                 "exact-f32 parity mode", stacklevel=3)
         self.amp_dtype = amp_dtype
         self.max_batch = int(max_batch)
         self.training = False
@@ -104,15 +111,20 @@ class RegressionMatcher:
         self._ensure_handle()
 
     # ------------------------------------------------------------------ handle management
-    def _config_key(self):
+    def _config_key(self, hw=None):
+        """(coarse h, w, upsample (h, w) or (0, 0), precision, max_batch, device).  `hw` = the resolution of THIS call's
+        tensors when it differs from the configured one (the attributes are never mutated, as in the reference)."""
+        h, w = hw if hw is not None else (self.h_resized, self.w_resized)
         up = tuple(int(v) for v in self.upsample_res) if self.upsample_preds else (0, 0)
-        return (int(self.h_resized), int(self.w_resized), up,
+        return (int(h), int(w), up,
                 _lib.ROMA_F32 if self.amp_dtype == torch.float32 else _lib.ROMA_BF16, self.max_batch, self.device.index)
 
-    def _ensure_handle(self):
-        key = self._config_key()
+    def _ensure_handle(self, hw=None):
+        key = self._config_key(hw)
         if self._handle is not None and self._built == key:
             return
+        if (self._handle is not None and key[2] == (0, 0) and self._built[:2] + self._built[3:] == key[:2] + key[3:]):
+            return  # upsample_preds switched off: the handle planned for the upsample pass also runs coarse-only
         self._release()
         lib = _lib.load()
         uh, uw = key[2]
@@ -187,6 +199,8 @@ class RegressionMatcher:
         im_A = _check_input(im_A_input)
         im_B = _check_input(im_B_input)
         hs, ws = self.h_resized, self.w_resized
+        scale_factor = math.sqrt(hs * ws / (560 ** 2))  # matcher.py:805: from the CONFIGURED resolution
+        call_hw = None
         if isinstance(im_A, Image.Image) and isinstance(im_B, Image.Image):
             a = _pil_to_normalised(im_A, (hs, ws))[None].to(device)
             b_ = _pil_to_normalised(im_B, (hs, ws))[None].to(device)
@@ -197,7 +211,7 @@ class RegressionMatcher:
             a, b_ = im_A.to(device), im_B.to(device)
             if h != self.h_resized or self.w_resized != w:
                 warn("Model resolution and batch resolution differ, may produce unexpected results")
-                self.h_resized, self.w_resized = h, w  # the HIP handle is resolution-specific: rebuild it
+                call_hw = (h, w)  # the HIP handle is resolution-specific; the attributes stay as configured (matcher.py:822-826)
         else:
             raise ValueError(f"Unsupported input type: {type(im_A)=} and {type(im_B)=}")
         a_hr = b_hr = None
@@ -212,10 +226,14 @@ class RegressionMatcher:
                 self.upsample_res = tuple(a_hr.shape[-2:])
         elif self.upsample_preds:
             raise ValueError(f"Invalid upsample_preds and high_res inputs with {im_A_high_res=} and {im_B_high_res=}")
-        self._ensure_handle()
+        if device.index is not None and device.index != self.device.index:
+            raise ValueError(f"roma_amd.match: inputs live on {device} but this matcher was built for {self.device}; "
+                             "use one matcher (one handle) per GPU")
+        self._ensure_handle(call_hw)
         lib = _lib.load()
         for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug", "vit_bf16_residual", "dual_stream"):
             _lib.check(lib.roma_set_option(self._handle, k.encode(), int(bool(getattr(self, k)))))
+        _lib.check(lib.roma_set_option_f(self._handle, b"coarse_scale_factor", float(scale_factor)))
         B = a.shape[0]
         Ho, Wo = self.get_output_resolution() if self.upsample_preds else (a.shape[-2], a.shape[-1])
         Wout = 2 * Wo if self.symmetric else Wo
@@ -244,6 +262,17 @@ class RegressionMatcher:
         if got < 0:
             raise _lib.RomaHipError(_lib.last_error())
         return buf
+
+    def debug_inject(self, name: str, value: Optional[np.ndarray]):
+        """Tests only (needs `self.debug`): override the named intermediate ("gm_flow16" [b,T,2], "gm_cert16" [b,T]) of
+        the following match() calls with `value`; None removes the override."""
+        lib = _lib.load()
+        self._ensure_handle()
+        if value is None:
+            _lib.check(lib.roma_debug_inject(self._handle, name.encode(), None, 0))
+            return
+        a = np.ascontiguousarray(value, dtype=np.float32)
+        _lib.check(lib.roma_debug_inject(self._handle, name.encode(), C.c_void_p(a.ctypes.data), a.nbytes))
 
     # ------------------------------------------------------------------ sampling (matcher.py:598-629)
     def sample(self, matches, certainty, num=10000):
@@ -357,7 +386,11 @@ def roma_model(resolution, upsample_preds, device=None, weights=None, dinov2_wei
                amp_dtype: torch.dtype = torch.float16, use_custom_corr=True, symmetric=True, upsample_res=None,
                sample_thresh=0.05, sample_mode="threshold_balanced", attenuate_cert=True, max_batch=8, **kwargs):
     """romatch/models/model_zoo/roma_models.py:32-205.  `use_custom_corr` is accepted for API
-    compatibility; the fused HIP local-correlation kernel is always used."""
+    compatibility; the fused HIP local-correlation kernel is always used.
+
+    Accepted: `amp_dtype` float32 (exact-f32 MFMA parity mode), bfloat16, float16 (runs as bfloat16, with a warning);
+    `resolution` a multiple of 56 per side (14 for the DINOv2 patch grid as in the reference, and 8 because the VGG
+    pyramid is kept un-floored down to stride 8); `upsample_res` a multiple of 8."""
     resolution = _to_hw(resolution)
     upsample_res = _to_hw(upsample_res)
     assert resolution[0] % 14 == 0, "Needs to be multiple of 14 for backbone"

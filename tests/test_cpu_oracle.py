@@ -216,3 +216,18 @@ def test_gloo_world2_gather(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
                          capture_output=True, text=True, timeout=300)
     assert "GATHER_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_self_spawn_n2_dry_run():
+    """`python bench.py --gpus 2` outside a launcher must re-execute itself as 2 ranks (what the driver's scaling run
+    does for N > 1) and rank 0 must print ONE JSON line with the whole-job aggregate; --dry swaps RCCL / the HIP path
+    for gloo / a stand-in match() so the launch, shard and gather logic is exercised without a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--steps", "3", "--warmup", "1",
+                          "--batch", "2"], capture_output=True, text=True, timeout=300, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout + out.stderr
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["config"]["global_batch"] == 4 and r["rccl_ranks"] == 2
+    assert r["launched_by"] == "bench.py self-spawn" and len(r["pairs_per_s_per_rank"]) == 2
+    assert abs(r["value"] - 4 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-6 * r["value"]

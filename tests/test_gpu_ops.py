@@ -178,6 +178,61 @@ def test_conv3x3_implicit_gemm(lib, dt, B, H, W, Cin, Cout):
     assert torch.allclose(out.cpu().double(), ref, atol=tol, rtol=tol)
 
 
+# ------------------------------------------------------------------ the 8-phase kernel (gemm8p.hip) against the classic one
+@pytest.mark.parametrize("M,N,K,act,out_f32", [
+    (8192, 256, 256, 0, False),      # smallest problem it takes: one n-tile, 4 K tiles (prologue + stream tail only)
+    (9000, 768, 1024, 2, False),     # ragged last m-tile, 3 n-tiles, GELU
+    (25616, 1024, 1024, 0, False),   # DINOv2 proj shape: 101 m-tiles, the last with 16 rows, several tiles per workgroup
+    (25600, 1408, 1408, 1, False),   # stride-16 refiner 1x1: half-empty last n-tile (1408 = 5.5 x 256), ReLU
+    (16384, 1024, 512, 0, True),     # f32 output
+    (70000, 512, 320, 0, False),     # many tiles per persistent workgroup, K = 5 tiles
+])
+def test_gemm8p_matches_classic_and_reference(lib, M, N, K, act, out_f32):
+    """Both main loops accumulate in the same k order, so the 8-phase kernel must reproduce the classic kernel BIT FOR
+    BIT (any race / mis-synchronised LDS-DMA shows up as a difference); the result is also checked against f64, and the
+    8-phase launch is repeated (timing-dependent hazards)."""
+    A, W, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, std=K ** -0.5).bfloat16(), rnd(N, seed=3)
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    dto = F32 if out_f32 else BF16
+    try:
+        lib.roma_tuning(b"gemm8p", 0)
+        base = gemm(lib, Ad, Wd, bias=bd, act=act, dt_in=BF16, dt_out=dto)
+        lib.roma_tuning(b"gemm8p", 1)
+        for _ in range(3):
+            out = gemm(lib, Ad, Wd, bias=bd, act=act, dt_in=BF16, dt_out=dto)
+            assert torch.equal(out, base), float((out.float() - base.float()).abs().max())
+    finally:
+        lib.roma_tuning(b"gemm8p", -1)
+    ref = A[:2048].double() @ W.double().T + b.double()
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    assert torch.allclose(out[:2048].cpu().double(), ref, atol=2e-3 if out_f32 else 0.03, rtol=1e-4 if out_f32 else 1e-2)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 70, 70, 256, 512), (3, 56, 60, 128, 256), (2, 72, 70, 64, 256), (1, 108, 108, 512, 512)])
+def test_conv3x3_gemm8p_matches_classic_and_reference(lib, B, H, W, Cin, Cout):
+    """3x3 implicit GEMM on the 8-phase kernel (per-tap validity masks, zero page): bitwise vs the classic kernel and
+    against torch conv2d (image borders, ragged last m-tile)."""
+    x, w, b = rnd(B, Cin, H, W, seed=1).bfloat16(), rnd(Cout, Cin, 3, 3, seed=2, std=(9 * Cin) ** -0.5).bfloat16(), rnd(Cout, seed=3)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).permute(0, 2, 3, 1)
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().cuda()
+    bd = b.cuda()
+    outs = {}
+    try:
+        for mode in (0, 1, 1):
+            lib.roma_tuning(b"gemm8p", mode)
+            out = torch.zeros((B, H, W, Cout), device="cuda", dtype=torch.bfloat16)
+            ok(lib, lib.roma_op_conv3x3(P(xin), P(wp), P(bd), P(out), B, H, W, Cin, Cout, 1, BF16, None))
+            torch.cuda.synchronize()
+            if mode in outs:
+                assert torch.equal(out, outs[mode])
+            outs[mode] = out
+    finally:
+        lib.roma_tuning(b"gemm8p", -1)
+    assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
+    assert torch.allclose(outs[1].cpu().double(), ref, atol=3e-2, rtol=3e-2)
+
+
 def _attention_case(lib, B, heads, hd, N, dt):
     D = heads * hd
     tdt = torch.float32 if dt == F32 else torch.bfloat16

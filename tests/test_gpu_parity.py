@@ -1,0 +1,242 @@
+"""Parity gates for the modes and sizes the bench actually runs (MI355X only).
+
+* bf16 (the benchmarked mode) at 112 -> 168 stage by stage against the live CPU oracle, and at the full 560 -> 864
+  size (B = 1 and the bench's own B = 8 workload) against goldens produced by the unmodified reference;
+* f32 at B = 8, 560 -> 864 (BASELINE configs 3 / 5 geometry: batch-index arithmetic (b + B) mod 2B and the arena at
+  max_batch) against the reference goldens, tolerance 1e-3 max-abs (BASELINE.json north_star);
+* coarse-only 560 x 560, B = 1 (BASELINE config 2) in f32 and bf16.
+
+How the reduced-precision mode is gated (tools/parity_metrics.py): errors are taken over the FLOW channels of `warp`
+and over `certainty`; the coarse arg-max (utils/utils.py:315) is discontinuous, so (a) the class logits must agree
+with the oracle within LOGIT_TOL and every token whose class differs must have an oracle top-2 gap below 2 x its own
+logit error (i.e. the flip is explained by the logit error, never by something else), and (b) with the oracle's coarse
+match injected (roma_debug_inject) every later stage and the final outputs are held to the bounds below.  The bounds
+are ~3x what was measured on MI355X (profiles/r02_bf16_parity.json); bf16 carries 8 mantissa bits through ~60 layers.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+import sys
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import parity_metrics as PM  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+TOL_F32 = 1e-3
+# bf16 bounds (flow in [-1, 1] normalised coordinates, certainty in [0, 1])
+BF16 = dict(logit=0.5,            # max |class logit - oracle| (logits are O(10), top-2 gaps O(1))
+            flow_max=2e-2, flow_p99=4e-3, cert_max=0.25, cert_p99=5e-2,   # final outputs, coarse match injected
+            feat_rel=4e-2)        # max |stage - oracle| / max |oracle| of the encoder pyramids
+
+
+def _dev(d):
+    return {k: v.cuda() for k, v in d.items()}
+
+
+def _bf16_np(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def _fetch(m, name, bf16):
+    return _bf16_np(m.debug_fetch(name, dtype=np.uint16)) if bf16 else m.debug_fetch(name)
+
+
+def _report(name, obj):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    path = os.path.join(ROOT, "gpurun_out", "parity_report.json")
+    rep = json.load(open(path)) if os.path.exists(path) else {}
+    rep[name] = obj
+    json.dump(rep, open(path, "w"), indent=1)
+    print(name, json.dumps(obj))
+
+
+def _check_out(tag, e, b=BF16):
+    assert e["grid_channels_exact"], tag
+    assert e["flow"]["max"] < b["flow_max"] and e["flow"]["p99"] < b["flow_p99"], (tag, e["flow"])
+    assert e["cert"]["max"] < b["cert_max"] and e["cert"]["p99"] < b["cert_p99"], (tag, e["cert"])
+
+
+# ------------------------------------------------------------------------------------------------ 112 -> 168, stage-wise
+def test_bf16_tiny_stagewise_vs_oracle(built_lib, weights0):
+    from oracle import roma_oracle as O
+    from roma_amd import roma_model, synthetic
+    sd, dsd = weights0
+    inp = synthetic.make_inputs(1, 112, 168, seed=1)
+    st = {}
+    w_ref, c_ref = O.match(inp["im_A"], inp["im_B"], sd, dsd, inp["im_A_high_res"], inp["im_B_high_res"], stages=st)
+    w_ref, c_ref = w_ref.numpy(), c_ref.numpy()
+    d = _dev(inp)
+    kw = dict(im_A_high_res=d["im_A_high_res"], im_B_high_res=d["im_B_high_res"])
+    m = roma_model((112, 112), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=torch.bfloat16,
+                   symmetric=True, upsample_res=(168, 168), max_batch=1)
+    m.debug = True
+    rep = {}
+    for res16 in (True, False):  # DINOv2 residual stream in bf16 (default) / f32
+        m.vit_bf16_residual = res16
+        m.debug_inject("gm_flow16", None)
+        m.debug_inject("gm_cert16", None)
+        warp, cert = m.match(d["im_A"], d["im_B"], **kw)
+        torch.cuda.synchronize()
+        r = {}
+        # ---- encoder pyramids (bf16 storage)
+        for s, c in ((1, 64), (2, 128), (4, 256), (8, 512)):
+            h = 112 // s
+            got = torch.from_numpy(_fetch(m, f"feat{s}", True).reshape(2, h, h, c)).permute(0, 3, 1, 2)
+            r[f"feat{s}_rel"] = float((got - st[f"feat{s}"]).abs().max() / st[f"feat{s}"].abs().max())
+            assert r[f"feat{s}_rel"] < BF16["feat_rel"], (s, r)
+        got = torch.from_numpy(_fetch(m, "feat16", True).reshape(2, 8, 8, 1024)).permute(0, 3, 1, 2)
+        r["feat16_rel"] = float((got - st["feat16"]).abs().max() / st["feat16"].abs().max())
+        assert r["feat16_rel"] < 2 * BF16["feat_rel"], r
+        tok = m.debug_fetch("tokens16").reshape(2, 64, 1024)
+        gp = torch.from_numpy(tok[:, :, :512]).permute(0, 2, 1).reshape(2, 512, 8, 8)
+        r["gp16_rel"] = float((gp - st["gp16"]).abs().max() / st["gp16"].abs().max())
+        assert r["gp16_rel"] < 2 * BF16["feat_rel"], r
+        # ---- class logits and the arg-max
+        logits = m.debug_fetch("logits16").reshape(2, 64, 4104)[:, :, :4096]
+        ref_l = st["cls16"].permute(0, 2, 3, 1).reshape(2, 64, 4096).numpy()
+        err_tok = np.abs(logits - ref_l).max(-1)
+        r["logit_err_max"] = float(err_tok.max())
+        assert r["logit_err_max"] < BF16["logit"], r
+        top2 = np.sort(ref_l, -1)[..., -2:]
+        gap = top2[..., 1] - top2[..., 0]
+        flipped = logits.argmax(-1) != ref_l.argmax(-1)
+        r["flips"] = int(flipped.sum())
+        assert np.all(gap[flipped] <= 2 * err_tok[flipped] + 1e-6), "an arg-max flip not explained by the logit error"
+        # ---- everything after the arg-max, with the oracle's coarse match injected
+        m.debug_inject("gm_flow16", PM.nchw_to_tokens(st["gm_flow16"].numpy()))
+        m.debug_inject("gm_cert16", PM.nchw_to_tokens(st["gm_cert16"].numpy()))
+        warp, cert = m.match(d["im_A"], d["im_B"], **kw)
+        torch.cuda.synchronize()
+        for p, res in (("p1", 112), ("p2", 168)):
+            for s in (16, 8, 4, 2, 1):
+                if p == "p2" and s == 16:
+                    continue
+                h = 8 if s == 16 else res // s
+                f = torch.from_numpy(m.debug_fetch(f"{p}_flow{s}").reshape(2, h, h, 2)).permute(0, 3, 1, 2)
+                c = torch.from_numpy(m.debug_fetch(f"{p}_cert{s}").reshape(2, 1, h, h))
+                r[f"{p}_flow{s}"] = float((f - st[f"{p}_flow{s}"]).abs().max())
+                r[f"{p}_cert{s}"] = float((c - st[f"{p}_cert{s}"]).abs().max())
+                assert r[f"{p}_flow{s}"] < BF16["flow_max"], (p, s, r)
+                assert r[f"{p}_cert{s}"] < 1.0, (p, s, r)  # certainty LOGITS (before the sigmoid)
+        e = PM.output_errors(warp.cpu().numpy(), cert.cpu().numpy(), w_ref, c_ref)
+        r["final_injected"] = e
+        _check_out("tiny injected", e)
+        rep[f"vit_bf16_residual={res16}"] = r
+    _report("bf16_tiny_stagewise", rep)
+
+
+# ------------------------------------------------------------------------------------------------ 560 -> 864 fixtures
+@pytest.fixture(scope="module")
+def full_models(built_lib, weights0):
+    """One f32 and one bf16 handle at the benchmark geometry (max_batch 8); B = 1 calls reuse them."""
+    from roma_amd import roma_model
+    sd, dsd = weights0
+    out = {}
+    for name, amp in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        out[name] = roma_model((560, 560), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=amp,
+                               symmetric=True, upsample_res=(864, 864), max_batch=8)
+    return out
+
+
+def _run(m, inp, debug=False, inject=None):
+    m.debug = debug
+    m.debug_inject("gm_flow16", None if inject is None else PM.nchw_to_tokens(inject["gm_flow16"]))
+    m.debug_inject("gm_cert16", None if inject is None else PM.nchw_to_tokens(inject["gm_cert16"]))
+    kw = {}
+    if m.upsample_preds:
+        kw = dict(im_A_high_res=inp["im_A_high_res"], im_B_high_res=inp["im_B_high_res"])
+    warp, cert = m.match(inp["im_A"], inp["im_B"], **kw)
+    torch.cuda.synchronize()
+    w, c = warp.cpu().numpy(), cert.cpu().numpy()
+    own = m.debug_fetch("gm_flow16_own").reshape(-1, 1600, 2).copy() if debug else None
+    m.debug = False
+    m.debug_inject("gm_flow16", None)
+    m.debug_inject("gm_cert16", None)
+    return w, c, own
+
+
+def _bf16_vs_golden(tag, m, inp, g):
+    """uninjected run: flips counted and explained; injected run: bounded."""
+    w, c, own = _run(m, inp, debug=True)
+    fl = PM.coarse_flips(own, PM.nchw_to_tokens(g["gm_flow16"]), PM.nchw_to_tokens(g["cls16_top2gap"][:, None]))
+    e_raw = PM.output_errors(w[:, ::8, ::8], c[:, ::8, ::8], g["warp_sub"], g["cert_sub"])
+    w, c, _ = _run(m, inp, debug=True, inject=g)
+    e_inj = PM.output_errors(w[:, ::8, ::8], c[:, ::8, ::8], g["warp_sub"], g["cert_sub"])
+    _report(tag, {"coarse": fl, "uninjected": e_raw, "injected": e_inj})
+    assert np.isfinite(w).all() and np.isfinite(c).all()
+    assert fl["max_gap_of_flipped"] < 2 * BF16["logit"], fl       # flips only where the reference itself is undecided
+    assert fl["flips"] <= 0.05 * fl["tokens"], fl
+    assert fl["max_flow16_err_unflipped"] < 1e-2, fl
+    _check_out(tag, e_inj)
+    return fl, e_raw, e_inj
+
+
+def test_bf16_full_b1_vs_reference_golden(full_models):
+    """BASELINE config 3 geometry at B = 1, bf16, against the reference's own output (tests/golden/match_full.npz)."""
+    from roma_amd import synthetic
+    g = np.load(os.path.join(GOLDEN, "match_full.npz"))
+    _bf16_vs_golden("bf16_full_b1", full_models["bf16"], _dev(synthetic.make_inputs(1, 560, 864, seed=1)), g)
+
+
+def test_f32_full8_vs_reference_golden(full_models):
+    """B = 8 symmetric 560 -> 864 in f32 (16 directed pairs, arena at max_batch) against the reference: 1e-3 max-abs."""
+    from roma_amd import synthetic
+    g = np.load(os.path.join(GOLDEN, "match_full8.npz"))
+    inp = _dev(synthetic.make_inputs(8, 560, 864, seed=1))
+    w, c, own = _run(full_models["f32"], inp, debug=True)
+    fl = PM.coarse_flips(own, PM.nchw_to_tokens(g["gm_flow16"]), PM.nchw_to_tokens(g["cls16_top2gap"][:, None]))
+    e = PM.output_errors(w[:, ::8, ::8], c[:, ::8, ::8], g["warp_sub"], g["cert_sub"], tol=TOL_F32)
+    _report("f32_full8", {"coarse": fl, "outputs": e})
+    assert fl["flips"] == 0, fl
+    assert e["flow"]["max"] < TOL_F32 and e["cert"]["max"] < TOL_F32, e
+    assert np.allclose(w.sum(axis=(2, 3), dtype=np.float64), g["warp_rowsum"], atol=0.05)
+    assert np.allclose(c.sum(axis=2, dtype=np.float64), g["cert_rowsum"], atol=0.05)
+
+
+def test_bf16_full8_vs_reference_golden(full_models):
+    """The benchmarked configuration itself (bench.py rank 0: B = 8, seeds 0 / 1, bf16) against the reference."""
+    from roma_amd import synthetic
+    g = np.load(os.path.join(GOLDEN, "match_full8.npz"))
+    _bf16_vs_golden("bf16_full8", full_models["bf16"], _dev(synthetic.make_inputs(8, 560, 864, seed=1)), g)
+
+
+def test_f32_full8_indoor_vs_reference_golden(built_lib):
+    """BASELINE config 5: "indoor" weights (same graph, seeds 2 / 3), f32, B = 8, 560 -> 864."""
+    from roma_amd import roma_indoor, synthetic
+    g = np.load(os.path.join(GOLDEN, "match_full8_indoor.npz"))
+    sd, dsd = synthetic.make_matcher_state_dict(2), synthetic.make_dinov2_state_dict(2)
+    m = roma_indoor(device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=torch.float32, max_batch=8)
+    inp = _dev(synthetic.make_inputs(8, 560, 864, seed=3))
+    w, c, own = _run(m, inp, debug=True)
+    fl = PM.coarse_flips(own, PM.nchw_to_tokens(g["gm_flow16"]), PM.nchw_to_tokens(g["cls16_top2gap"][:, None]))
+    e = PM.output_errors(w[:, ::8, ::8], c[:, ::8, ::8], g["warp_sub"], g["cert_sub"], tol=TOL_F32)
+    _report("f32_full8_indoor", {"coarse": fl, "outputs": e})
+    assert fl["flips"] == 0, fl
+    assert e["flow"]["max"] < TOL_F32 and e["cert"]["max"] < TOL_F32, e
+
+
+def test_coarse_only_b1_vs_reference_golden(full_models):
+    """BASELINE config 2: coarse-only 560 x 560 (upsample_preds=False), B = 1: f32 at 1e-3, bf16 gated like above."""
+    from roma_amd import synthetic
+    g = np.load(os.path.join(GOLDEN, "match_full_coarse.npz"))
+    inp = _dev(synthetic.make_inputs(1, 560, None, seed=1))
+    for name in ("f32", "bf16"):
+        m = full_models[name]
+        m.upsample_preds = False
+        try:
+            if name == "f32":
+                w, c, _ = _run(m, inp)
+                assert w.shape == (1, 560, 1120, 4)
+                e = PM.output_errors(w[:, ::8, ::8], c[:, ::8, ::8], g["warp_sub"], g["cert_sub"], tol=TOL_F32)
+                _report("f32_coarse_b1", e)
+                assert e["flow"]["max"] < TOL_F32 and e["cert"]["max"] < TOL_F32, e
+            else:
+                _bf16_vs_golden("bf16_coarse_b1", m, inp, g)
+        finally:
+            m.upsample_preds = True

@@ -1,0 +1,214 @@
+"""A/B of the two bf16 GEMM main loops on the model's shapes (GPU box), through the C ABI:
+
+    gemm8p  = roma_amd/csrc/gemm8p.hip   (8-phase, staggered wave groups, counted vmcnt, streamed tiles)
+    classic = roma_amd/csrc/gemm.hip     (one barrier + vmcnt(0) per K slab)
+
+selected per call with roma_tuning("gemm8p", 1 / 0).  For every shape: bitwise comparison of the two kernels' outputs
+(both accumulate in the same k order, so they must agree exactly), a check against an f32 torch matmul of the same bf16
+operands, a run-to-run bitwise race screen of the 8-phase kernel, and interleaved timing rounds (median of N).
+
+    gpurun --timeout 600 -- 'python tools/bench_gemm8p.py > gpurun_out/bench_gemm8p.log 2>&1'
+"""
+import ctypes as C
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from roma_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+F32, BF16 = 0, 1
+ROUNDS = int(os.environ.get("ROUNDS", "7"))
+RACE = int(os.environ.get("RACE", "20"))
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def ok(rc):
+    assert rc == 0, lib.roma_last_error().decode()
+
+
+def timed(fn, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def ab(name, flops, make_call, ref=None, iters=5):
+    """make_call(out) -> callable running the op into `out`; returns dict of results"""
+    res = {"name": name}
+    outs = {}
+    for mode in (0, 1):
+        lib.roma_tuning(b"gemm8p", mode)
+        call, out = make_call()
+        call()
+        torch.cuda.synchronize()
+        outs[mode] = out.clone() if isinstance(out, torch.Tensor) else [o.clone() for o in out]
+    o0 = outs[0] if isinstance(outs[0], list) else [outs[0]]
+    o1 = outs[1] if isinstance(outs[1], list) else [outs[1]]
+    res["bitwise_equal_to_classic"] = all(torch.equal(a, b) for a, b in zip(o0, o1))
+    res["max_abs_diff_vs_classic"] = max(float((a.float() - b.float()).abs().max()) for a, b in zip(o0, o1))
+    if ref is not None:
+        r = ref()
+        res["max_abs_err_vs_f32_ref"] = float((o1[0].float() - r).abs().max())
+        res["ref_abs_max"] = float(r.abs().max())
+    # race screen (8-phase kernel): bitwise run-to-run
+    lib.roma_tuning(b"gemm8p", 1)
+    call, out = make_call()
+    bad = 0
+    for _ in range(RACE):
+        call()
+        torch.cuda.synchronize()
+        cur = out if isinstance(out, list) else [out]
+        bad += int(not all(torch.equal(a, b) for a, b in zip(cur, o1)))
+    res["race_screen_diff_runs"] = f"{bad}/{RACE}"
+    # interleaved timing rounds
+    t = {0: [], 1: []}
+    calls = {}
+    for mode in (0, 1):
+        lib.roma_tuning(b"gemm8p", mode)
+        calls[mode] = make_call()[0]
+        calls[mode]()
+    torch.cuda.synchronize()
+    for _ in range(ROUNDS):
+        for mode in (0, 1):
+            lib.roma_tuning(b"gemm8p", mode)
+            t[mode].append(timed(calls[mode], iters))
+    for mode, key in ((0, "classic"), (1, "gemm8p")):
+        ms = statistics.median(t[mode])
+        res[key] = {"ms": ms, "TFLOPs": flops / (ms * 1e-3) / 1e12, "min_ms": min(t[mode])}
+    res["speedup"] = res["classic"]["ms"] / res["gemm8p"]["ms"]
+    print(json.dumps(res), flush=True)
+    return res
+
+
+def dense(M, N, K, act=0, out_f32=False, scale=False):
+    A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    W = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda")
+    sc = torch.rand(N, device="cuda") + 0.5 if scale else None
+
+    def make_call():
+        out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if out_f32 else torch.bfloat16)
+
+        def call():
+            ok(lib.roma_op_gemm(P(A), K, P(W), K, P(out), N, M, N, K, 1, 0, 0, 0, P(b), P(sc), None, 0, act, 1.0, BF16,
+                                F32 if out_f32 else BF16, None))
+        return call, out
+
+    def ref():
+        r = A[:4096].float() @ W.float().t() + b
+        if act == 1:
+            r = r.relu()
+        elif act == 2:
+            r = torch.nn.functional.gelu(r)
+        if sc is not None:
+            r = r * sc
+        return r
+
+    def make_call_sub():
+        return make_call()
+    name = f"dense M={M} N={N} K={K} act={act} out={'f32' if out_f32 else 'bf16'}"
+    r = ab(name, 2.0 * M * N * K, make_call, ref=None)
+    # f32 reference on the first 4096 rows
+    lib.roma_tuning(b"gemm8p", 1)
+    call, out = make_call()
+    call()
+    torch.cuda.synchronize()
+    rr = ref()
+    print(json.dumps({"name": name, "max_abs_err_vs_f32_ref_first_4096_rows": float((out[:4096].float() - rr).abs().max()),
+                      "ref_abs_max": float(rr.abs().max())}), flush=True)
+    return r
+
+
+def res_bf16(M, N, K):
+    A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    W = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    b, sc = torch.randn(N, device="cuda"), torch.rand(N, device="cuda") * 0.3
+    x0 = torch.randn(M, N, device="cuda").to(torch.bfloat16)
+
+    def make_call():
+        x = x0.clone()
+
+        def call():
+            x.copy_(x0)
+            ok(lib.roma_op_gemm_res_bf16(P(A), K, P(W), K, P(x), N, M, N, K, P(b), P(sc), P(x), N, None))
+        return call, x
+    return ab(f"res_bf16 M={M} N={N} K={K}", 2.0 * M * N * K, make_call)
+
+
+def qkv(B, N, heads, hd, K):
+    npad = (N + 127) // 128 * 128
+    D = heads * hd
+    A = torch.randn(B * N, K, device="cuda").to(torch.bfloat16)
+    W = (torch.randn(3 * D, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(3 * D, device="cuda")
+
+    def make_call():
+        q = torch.zeros(B * heads * npad * hd, device="cuda", dtype=torch.bfloat16)
+        k, vt = torch.zeros_like(q), torch.zeros_like(q)
+
+        def call():
+            ok(lib.roma_op_qkv_scatter_gemm(P(A), P(W), P(b), P(q), P(k), P(vt), B, N, npad, heads, hd, K, BF16, BF16, None))
+        return call, [q, k, vt]
+    return ab(f"qkv B={B} N={N} heads={heads} hd={hd} K={K}", 2.0 * B * N * 3 * D * K, make_call)
+
+
+def conv(B, H, W_, Cin, Cout):
+    x = torch.randn(B, H, W_, Cin, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(Cout, 9 * Cin, device="cuda") * (9 * Cin) ** -0.5).to(torch.bfloat16)
+    b = torch.randn(Cout, device="cuda")
+
+    def make_call():
+        out = torch.zeros(B, H, W_, Cout, device="cuda", dtype=torch.bfloat16)
+
+        def call():
+            ok(lib.roma_op_conv3x3(P(x), P(w), P(b), P(out), B, H, W_, Cin, Cout, 1, BF16, None))
+        return call, out
+    r = ab(f"conv3x3 B={B} {H}x{W_} Cin={Cin} Cout={Cout}", 2.0 * B * H * W_ * Cout * 9 * Cin, make_call)
+    # f32 torch reference on one image
+    lib.roma_tuning(b"gemm8p", 1)
+    call, out = make_call()
+    call()
+    torch.cuda.synchronize()
+    wt = w.float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    refo = torch.nn.functional.conv2d(x[:1].float().permute(0, 3, 1, 2), wt, b, padding=1).relu().permute(0, 2, 3, 1)
+    print(json.dumps({"name": r["name"], "max_abs_err_vs_torch_conv_image0": float((out[:1].float() - refo).abs().max()),
+                      "ref_abs_max": float(refo.abs().max())}), flush=True)
+    return r
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "dense"):
+        dense(25616, 1024, 1024)                    # DINOv2 proj-like (no residual)
+        dense(25616, 4096, 1024, act=2)             # fc1 + GELU
+        dense(25616, 1024, 4096, scale=True)        # fc2-like
+        dense(25600, 1408, 1408)                    # stride-16 refiner 1x1 (Cp = 1408)
+        dense(25600, 1024, 1024, out_f32=True)      # decoder proj (f32 out)
+        dense(65536, 1024, 8192)                    # long-K probe
+        dense(8192, 4096, 4096)                     # square-ish probe (guide's 4096-class reference point)
+        dense(25616 - 16, 1024, 1024)               # exactly 100 m-tiles
+        dense(300, 1024, 1024)                      # stays on the classic kernel (small M): sanity of the dispatcher
+    if which in ("all", "epi"):
+        res_bf16(25616, 1024, 1024)
+        res_bf16(25616, 1024, 4096)
+        qkv(16, 1601, 16, 64, 1024)
+        qkv(16, 1600, 8, 128, 1024)
+    if which in ("all", "conv"):
+        conv(16, 70, 70, 512, 512)
+        conv(16, 108, 108, 256, 512)
+        conv(16, 140, 140, 256, 256)
+        conv(4, 216, 216, 128, 256)
+    lib.roma_tuning(b"gemm8p", -1)

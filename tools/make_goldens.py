@@ -8,6 +8,9 @@ fixtures are what travels to the GPU box.  Usage:
     python tools/make_goldens.py tiny          # match() 112 -> 168, B=1 symmetric (+ stage tensors)
     python tools/make_goldens.py small         # match() 224 -> 336, B=2, non-symmetric and symmetric coarse-only
     python tools/make_goldens.py full          # match() 560 -> 864, B=1 symmetric (sub-sampled)
+    python tools/make_goldens.py full8         # match() 560 -> 864, B=8 symmetric, bench.py's rank-0 workload (sub-sampled)
+    python tools/make_goldens.py full_coarse   # match() 560 coarse-only, B=1 symmetric (BASELINE config 2 geometry)
+    python tools/make_goldens.py full8_indoor  # same geometry, seeds 2 / 3 (BASELINE config 5 "indoor")
     python tools/make_goldens.py kde           # romatch.utils.kde.kde on seeded match-like points
     python tools/make_goldens.py keypoints     # RegressionMatcher.match_keypoints on a seeded warp + keypoints
 """
@@ -113,6 +116,8 @@ def _run_reference(cfg_name, coarse, up, B, symmetric, upsample_preds, seed_w, s
             top2 = o[0].topk(2, dim=1).values
             stages["cls16_top2gap"] = np32(top2[:, 0] - top2[:, 1])
             stages["gm_cert16"] = np32(o[1])
+            from romatch.utils.utils import cls_to_flow_refine
+            stages["gm_flow16"] = np32(cls_to_flow_refine(o[0]).permute(0, 3, 1, 2))  # matcher.py:478-481
         m.decoder.embedding_decoder.register_forward_hook(tdec_hook)
         def proj_hook(mod, a, o):
             if "proj16_first" not in stages:
@@ -160,7 +165,7 @@ def full():
     out = dict(warp_sub=w[:, ::8, ::8], cert_sub=c[:, ::8, ::8],
                warp_rowsum=w.sum(axis=(2, 3), dtype=np.float64), cert_rowsum=c.sum(axis=2, dtype=np.float64),
                cls16_argmax=st["cls16_argmax"], cls16_top2gap=st["cls16_top2gap"], gm_cert16=st["gm_cert16"],
-               gp16_sub=st["gp16"][:, ::8])
+               gm_flow16=st["gm_flow16"], gp16_sub=st["gp16"][:, ::8])
     for k, v in st.items():
         if k.startswith("ref") and v.size <= 200000:
             out[k] = v
@@ -170,6 +175,46 @@ def full():
                 threads=torch.get_num_threads(), torch=torch.__version__)
     json.dump(meta, open(os.path.join(GOLD, "match_full.json"), "w"), indent=1)
     print(meta)
+
+
+def full8(name="match_full8", seed_w=0, seed_in=1):
+    """BASELINE configs 3 / 5 geometry: B=8 symmetric 560 -> 864 fp32 (16 directed pairs: batch-index arithmetic
+    (b + B) mod 2B at full size).  Default seeds = bench.py's rank-0 workload, so the bench line can carry a parity
+    object for the timed configuration; `full8 indoor` (seed 2 / 3) is the BASELINE config-5 "indoor" fixture."""
+    torch.set_num_threads(os.cpu_count())
+    warp, cert, st, dt = _run_reference(name, 560, 864, 8, True, True, seed_w, seed_in)
+    w, c = np32(warp), np32(cert)
+    out = dict(warp_sub=w[:, ::8, ::8], cert_sub=c[:, ::8, ::8],
+               warp_rowsum=w.sum(axis=(2, 3), dtype=np.float64), cert_rowsum=c.sum(axis=2, dtype=np.float64),
+               cls16_argmax=st["cls16_argmax"], cls16_top2gap=st["cls16_top2gap"], gm_cert16=st["gm_cert16"],
+               gm_flow16=st["gm_flow16"])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    meta = dict(coarse=560, up=864, B=8, symmetric=True, seed_w=seed_w, seed_in=seed_in, subsample=8,
+                min_top2_gap=float(st["cls16_top2gap"].min()), ref_seconds=dt,
+                threads=torch.get_num_threads(), torch=torch.__version__)
+    json.dump(meta, open(os.path.join(GOLD, name + ".json"), "w"), indent=1)
+    print(meta)
+
+
+def full_coarse():
+    """BASELINE config 2 geometry: coarse-only (upsample_preds=False) 560 x 560, B=1 symmetric, seeds 0 / 1."""
+    torch.set_num_threads(os.cpu_count())
+    warp, cert, st, dt = _run_reference("full_coarse", 560, 864, 1, True, False, 0, 1)
+    w, c = np32(warp), np32(cert)
+    out = dict(warp_sub=w[:, ::8, ::8], cert_sub=c[:, ::8, ::8],
+               warp_rowsum=w.sum(axis=(2, 3), dtype=np.float64), cert_rowsum=c.sum(axis=2, dtype=np.float64),
+               cls16_argmax=st["cls16_argmax"], cls16_top2gap=st["cls16_top2gap"], gm_cert16=st["gm_cert16"],
+               gm_flow16=st["gm_flow16"])
+    np.savez_compressed(os.path.join(GOLD, "match_full_coarse.npz"), **out)
+    meta = dict(coarse=560, B=1, symmetric=True, upsample_preds=False, seed_w=0, seed_in=1, subsample=8,
+                min_top2_gap=float(st["cls16_top2gap"].min()), ref_seconds=dt,
+                threads=torch.get_num_threads(), torch=torch.__version__)
+    json.dump(meta, open(os.path.join(GOLD, "match_full_coarse.json"), "w"), indent=1)
+    print(meta)
+
+
+def full8_indoor():
+    full8("match_full8_indoor", 2, 3)
 
 
 def kde_golden():
@@ -217,4 +262,4 @@ def keypoints_golden():
 
 if __name__ == "__main__":
     for what in sys.argv[1:]:
-        {"contract": contract, "ops": ops, "tiny": tiny, "small": small, "full": full, "kde": kde_golden, "keypoints": keypoints_golden}[what]()
+        {"contract": contract, "ops": ops, "tiny": tiny, "small": small, "full": full, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden}[what]()
