@@ -76,7 +76,9 @@ int roma_destroy(roma_handle_t h);
  * object {kernel: {calls,total_ms,work,unit}} (work = algorithmic FLOPs or bytes); returns bytes needed when buf==NULL. */
 /* process-wide kernel-selection switches for A/B measurements and tests (not needed for normal use): "gemm8p" 1 / 0 =
  * route the large bf16 GEMMs to the 8-phase kernel or keep them on the one-barrier-per-slab kernel (-1 = environment
- * ROMA_GEMM8P, default on); "gemm_dbg" = experiment bits of the GEMM kernels (-1 = environment ROMA_GEMM_DBG). */
+ * ROMA_GEMM8P, default on); "gemm_dbg" = experiment bits of the GEMM kernels (-1 = environment ROMA_GEMM_DBG);
+ * "lc_mode" = local correlation: 0 tiled LDS form with a per-tile gather work list (default), 1 every tile on the gather
+ * list, 2 the per-pixel kernel of round 1 (-1 = environment ROMA_LC_MODE). */
 int roma_tuning(const char* key, int value);
 int roma_profile_enable(int on);
 long roma_profile_report(char* buf, long nbytes);
@@ -119,9 +121,25 @@ int roma_op_gemm_res_bf16(const void* A, long lda, const void* W, long ldw, void
  * overwritten by X^T.  Workspaces: LT [batch,n,n], Linv/LinvT [batch, n/64, 64, 64].  n multiple of 64. */
 int roma_op_cholesky_solve_t(float* A, float* Ft, float* LT, float* Linv, float* LinvT, int n, int d, int batch,
                              void* stream);
+/* GP.forward (matcher.py:291-323) with the cosine kernel (matcher.py:191-200, T = 0.2) and sigma_noise = 0.1:
+ *   mu[i] = K(x_i, y_i) (K(y_i, y_i) + 0.1 I)^-1 cos(8 pi (pos_w . grid + pos_b))
+ * x, y: [b, h*w, 512] channels-last stride-16 features (dt), pos_w [512,2], pos_b [512] f32 (decoder.gps.16.pos_conv),
+ * mu: [b, h*w, 512] f32.  Always evaluated in f32 (Gram matrices via exact-f32 MFMA when dt = ROMA_F32, blocked
+ * Cholesky, two triangular solves); scratch is stream-ordered. */
+int roma_op_gp(const void* x, const void* y, const float* pos_w, const float* pos_b, float* mu, int b, int h, int w, int dt,
+               void* stream);
 int roma_op_cls_to_flow(const float* logits, long ld, float* flow, float* cert, long M, void* stream);
 int roma_op_resize_bilinear(const float* in, float* out, int B, int Hin, int Win, int Hout, int Wout, int nc,
                             void* stream);
+/* The ConvRefiner input writer = F.grid_sample warp + concat (matcher.py:132-148, 166), one pass:
+ *   d[b,p,:] = [ x[b,p,0:C] | bilinear_zeropad(y[(b+shift) % nimg], flow[b,p]) (align_corners=False) |
+ *                emb_w . (disp_scale * (flow[b,p] - grid[p])) + emb_b (E values) | Kcorr columns left untouched (local
+ *                correlation writes them) | zeros up to ldd ]
+ * feat: projected features of all nimg images [nimg, H*W, ldf] (x = image b, y = image (b+shift) % nimg), flow [B,H*W,2]
+ * f32 normalised (x,y), emb_w [E,2], emb_b [E] f32, disp_scale = 40/32 * scale_factor. */
+int roma_op_refiner_input(const void* feat, long ldf, const float* flow, void* d, long ldd, const float* emb_w,
+                          const float* emb_b, int B, int H, int W, int C, int E, int Kcorr, int nimg, int shift,
+                          float disp_scale, int dt, void* stream);
 int roma_op_dwconv5x5(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp, int dt,
                       void* stream);
 /* One fused ConvRefiner block (matcher.py:88-117 create_block): out = conv1x1(relu(bn(dwconv5x5(in)))), BN folded into

@@ -48,8 +48,10 @@ SIGNATURES = {
     "roma_op_layernorm_dt": (_i, [_vp, _i, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
     "roma_op_gemm_res_bf16": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _l, _vp]),
     "roma_op_cholesky_solve_t": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "roma_op_gp": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "roma_op_cls_to_flow": (_i, [_vp, _l, _vp, _vp, _l, _vp]),
     "roma_op_resize_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "roma_op_refiner_input": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "roma_op_dwconv5x5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "roma_op_refiner_block": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "roma_op_kde": (_i, [_vp, _l, _i, _f, _i, _vp, _vp]),

@@ -151,6 +151,7 @@ int roma_tuning(const char* key, int value) {
   const std::string k(key);
   if (k == "gemm8p") g_gemm_tuning[0] = value;
   else if (k == "gemm_dbg") g_gemm_tuning[1] = value;
+  else if (k == "lc_mode") g_lc_mode = value;
   else {
     set_error("roma_tuning: unknown key " + k);
     return ROMA_ERR_ARG;
@@ -268,6 +269,32 @@ int roma_op_cholesky_solve_t(float* A, float* Ft, float* LT, float* Linv, float*
   return cholesky_solve_t(A, Ft, LT, Linv, LinvT, n, d, batch, S(stream));
 }
 
+int roma_op_gp(const void* x, const void* y, const float* pos_w, const float* pos_b, float* mu, int b, int h, int w, int dt,
+               void* stream) {
+  ROMA_REQUIRE(x && y && pos_w && pos_b && mu && b > 0 && h > 0 && w > 0, "roma_op_gp: bad arguments");
+  hipStream_t st = S(stream);
+  const int n = h * w;
+  const size_t esz = DT(dt) == DT_F32 ? 4 : 2;
+  // one feature buffer [2b, n, 512]: images [0, b) = x (queries), [b, 2b) = y (supports); non-symmetric pairing
+  Arena plan;
+  plan.alloc((size_t)2 * b * n * 512 * esz);
+  if (int rc = gp_posterior(nullptr, 512, DT(dt), b, false, h, w, pos_w, pos_b, mu, 512, plan, st, true)) return rc;
+  Arena ar;
+  ar.cap = plan.peak + 4096;
+  ar.dry = false;
+  ROMA_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&ar.base), ar.cap, st));
+  char* pf = static_cast<char*>(ar.alloc((size_t)2 * b * n * 512 * esz));
+  int rc = 0;
+  if (hipMemcpyAsync(pf, x, (size_t)b * n * 512 * esz, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(pf + (size_t)b * n * 512 * esz, y, (size_t)b * n * 512 * esz, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    set_error("roma_op_gp: device copy failed");
+    rc = ROMA_ERR_HIP;
+  }
+  if (!rc) rc = gp_posterior(pf, 512, DT(dt), b, false, h, w, pos_w, pos_b, mu, 512, ar, st, false);
+  (void)hipFreeAsync(ar.base, st);
+  return rc;
+}
+
 int roma_op_cls_to_flow(const float* logits, long ld, float* flow, float* cert, long M, void* stream) {
   return cls_to_flow_launch(logits, ld, flow, cert, M, S(stream));
 }
@@ -275,6 +302,18 @@ int roma_op_cls_to_flow(const float* logits, long ld, float* flow, float* cert, 
 int roma_op_resize_bilinear(const float* in, float* out, int B, int Hin, int Win, int Hout, int Wout, int nc,
                             void* stream) {
   return resize_bilinear_launch(in, out, B, Hin, Win, Hout, Wout, nc, S(stream));
+}
+
+int roma_op_refiner_input(const void* feat, long ldf, const float* flow, void* d, long ldd, const float* emb_w,
+                          const float* emb_b, int B, int H, int W, int C, int E, int Kcorr, int nimg, int shift,
+                          float disp_scale, int dt, void* stream) {
+  RefinerInputArgs a;
+  a.feat = feat; a.ldf = ldf; a.flow = flow; a.d = d; a.ldd = ldd; a.emb_w = emb_w; a.emb_b = emb_b;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.E = E; a.Kcorr = Kcorr; a.nimg = nimg; a.shift = shift;
+  a.disp_scale = disp_scale; a.dt = DT(dt);
+  ROMA_REQUIRE(feat && flow && d && B > 0 && H > 0 && W > 0 && C > 0 && nimg > 0, "roma_op_refiner_input: bad arguments");
+  ROMA_REQUIRE(ldd >= 2 * C + E + Kcorr && ldf >= C, "roma_op_refiner_input: row strides too small");
+  return refiner_input_launch(a, S(stream));
 }
 
 int roma_op_dwconv5x5(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp, int dt,

@@ -2,6 +2,7 @@
 // Conventions: channels-last activations, 16-byte (or 8-byte for bf16 quads) vector accesses,
 // one wave64 per row for row reductions, f32 math everywhere.
 #include "elementwise.h"
+#include <stdio.h>
 
 #include <stdlib.h>
 #include "gemm.h"  // DT_*
@@ -790,6 +791,12 @@ __global__ __launch_bounds__(256) void refiner_input_vec_kernel(const RefinerInp
 
 int refiner_input_launch(const RefinerInputArgs& a, hipStream_t s) {
   const long npix = (long)a.B * a.H * a.W;
+  // grid_sample warp + concat writer (matcher.py:132-148,166).  Algorithmic bytes: x and the sampled y
+  // read once (2 s C), the flow (8), the written row of d without the correlation slice another kernel fills
+  const double es = a.dt == DT_F32 ? 4.0 : 2.0;
+  char pname[64];
+  snprintf(pname, sizeof pname, "refiner_input_warp<C=%d,%s>", a.C, a.dt == DT_F32 ? "f32" : "bf16");
+  ProfScope ps(pname, (double)npix * (2.0 * a.C * es + 8.0 + (double)(a.ldd - a.Kcorr) * es), "byte", s);
   if (a.C == 9 && a.E == 6 && a.Kcorr == 0 && a.ldf == 16 && a.ldd == 24) {
     dim3 grid((unsigned)((npix + 255) / 256));
     ROMA_DT_SWITCH(a.dt, T, hipLaunchKernelGGL((refiner_input_pix_kernel<T, 9, 6>), grid, dim3(256), 0, s, a));

@@ -19,7 +19,13 @@ struct LocalCorrArgs {
   int nimg = 0, f1_shift = 0;  // image of f0 = b, image of f1 = (b + f1_shift) % nimg
   float scale = 1.f;           // 1/sqrt(C) when f0 is not pre-scaled
   int in_dt = 0, out_dt = 0;
+  // window form: device scratch for the tile work list, (tiles + 1) ints with tiles = B * ceil(H/8) * ceil(W/8); nullptr =
+  // allocate stream-ordered scratch for the call.  force_gather is set by the launcher (tuning switch).
+  int* ws = nullptr;
+  long ws_bytes = 0;
+  int force_gather = 0;
 };
+extern int g_lc_mode;  // roma_tuning("lc_mode")
 
 // Window form (integer-patch identity: all K taps share one fractional offset).
 int local_corr_window_launch(const LocalCorrArgs& a, hipStream_t stream);

@@ -15,6 +15,7 @@
 // (2r+2) fully used 64..128-byte segments.  f0 is staged once per wave in LDS as f32.
 #include "local_corr.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include "gemm.h"  // DT_*
 
 namespace roma {
@@ -47,41 +48,41 @@ __device__ inline void unnormalize_floor(float w, int size, int& i0, float& frac
   frac = ix - f;
 }
 
+// One query pixel by one wave64: gathers its own (2r+2)^2 patch (the form that serves scattered warps).  `myf0` is this
+// wave's LDS slice of C floats; the caller provides the block-wide barriers around the staging of f0.
 template <int R, typename T, typename TOUT>
-__global__ __launch_bounds__(256) void local_corr_window_kernel(const LocalCorrArgs a) {
-  constexpr int P = 2 * R + 2;
-  constexpr int PP = (P <= 8) ? 8 : 16;
-  constexpr int S = 64 / PP;
+__device__ __forceinline__ void lc_gather_stage_f0(const LocalCorrArgs& a, long pix, bool active, int lane, float* myf0) {
   constexpr int CE = LcIO<T>::CE;
-  constexpr int KW = 2 * R + 1;
-  extern __shared__ __attribute__((aligned(16))) float f0s[];  // [4 waves][C]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long HW = (long)a.H * a.W;
-  const long total = (long)a.B * HW;
-  long pix = (long)blockIdx.x * 4 + wave;
-  const bool active = pix < total;
-  if (!active) pix = total - 1;
+  if (!active) return;
   const int b = (int)(pix / HW);
   const long p = pix - (long)b * HW;
-  const int pos = lane / S, s = lane % S;
-
-  // ---- stage f0 row (as f32) into this wave's LDS slice
   const T* f0p = reinterpret_cast<const T*>(a.f0) + ((long)b * HW + p) * a.ld0;
-  float* myf0 = f0s + wave * a.C;
   for (int c = lane * CE; c < a.C; c += 64 * CE) {
     float v[CE];
     LcIO<T>::ld(f0p + c, v);
 #pragma unroll
     for (int j = 0; j < CE; ++j) myf0[c + j] = v[j];
   }
-  __syncthreads();
+}
 
+template <int R, typename T, typename TOUT>
+__device__ __forceinline__ void lc_gather_pixel(const LocalCorrArgs& a, long pix, bool active, int lane, const float* myf0) {
+  constexpr int P = 2 * R + 2;
+  constexpr int PP = (P <= 8) ? 8 : 16;
+  constexpr int S = 64 / PP;
+  constexpr int CE = LcIO<T>::CE;
+  constexpr int KW = 2 * R + 1;
+  const long HW = (long)a.H * a.W;
+  if (!active) pix = 0;
+  const int b = (int)(pix / HW);
+  const int pos = lane / S, s = lane % S;
   int x0, y0;
   float fx, fy;
   unnormalize_floor(a.warp[pix * 2 + 0], a.W, x0, fx);
   unnormalize_floor(a.warp[pix * 2 + 1], a.H, y0, fy);
   const int x = x0 - R + pos;
-  const bool xok = pos < P && x >= 0 && x < a.W;
+  const bool xok = active && pos < P && x >= 0 && x < a.W;
   const int simg = (b + a.f1_shift) % a.nimg;
   const T* f1p = reinterpret_cast<const T*>(a.f1) + (long)simg * HW * a.ld1;
   const int NI = a.C / (CE * S);
@@ -126,6 +127,281 @@ __global__ __launch_bounds__(256) void local_corr_window_kernel(const LocalCorrA
       }
     }
   }
+}
+
+template <int R, typename T, typename TOUT>
+__global__ __launch_bounds__(256) void local_corr_window_kernel(const LocalCorrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float f0s[];  // [4 waves][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long total = (long)a.B * a.H * a.W;
+  const long pix = (long)blockIdx.x * 4 + wave;
+  const bool active = pix < total;
+  float* myf0 = f0s + wave * a.C;
+  lc_gather_stage_f0<R, T, TOUT>(a, pix, active, lane, myf0);
+  __syncthreads();
+  lc_gather_pixel<R, T, TOUT>(a, pix, active, lane, myf0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tiled form (the default): a workgroup owns an 8 x 8 tile of query pixels.
+//
+// With a coherent warp (what a trained matcher produces: neighbouring queries look at neighbouring places) the 64
+// windows of a tile overlap almost completely, so the union of their integer patches is a small rectangle of f1 -
+// (8 + 2r + 1)^2 pixels for a unit-scale warp - and every f1 pixel of that rectangle is needed by up to (2r+2)^2
+// queries.  The tile stages that rectangle ONCE, channels-last, in LDS (in chunks of 128 bytes of channels per pixel,
+// 144-byte pitch so that the 16 queries of a ds_read_b128 lane group hit different banks), together with the 64
+// f0 rows, and all (2r+2)^2 x 64 dot products are evaluated from LDS: HBM / L2 traffic per tile = the algorithmic
+// bytes (f0 tile + f1 rectangle), instead of (2r+2)^2 x that for per-query gathers.  Lanes = queries, the 4 waves
+// split the patch rows; bf16 dots use v_dot2c_f32_bf16 on packed pairs (f32 accumulate), f32 dots are fmaf chains.
+//
+// A tile whose windows do NOT overlap (its bounding rectangle exceeds the LDS stage: an incoherent warp, e.g. the
+// random-weight benchmark model, or a strongly zooming one) needs (2r+2)^2 x the bytes whatever the kernel does; it is
+// appended to a work list (one atomic per tile) and local_corr_list_kernel serves its 64 pixels with per-query gathers
+// at the high occupancy that latency-bound form wants (8 KB of LDS per workgroup instead of 74 KB).  The choice is per
+// tile, data dependent and made on the device; results do not depend on it beyond f32 summation order.
+constexpr int LC_TQ = 8;                 // tile edge (queries)
+constexpr int LC_PITCH = 144;            // bytes per staged pixel: 128 B of channels + 16 B pad (bank spread)
+// f1 pixels the stage can hold (the 64 f0 rows take 64 more slots): r <= 3 -> 73 728 B, two workgroups per CU
+// (a unit-scale warp needs 13^2 / 15^2 pixels, so zoom factors up to ~1.5 still fit); r > 3 -> 110 592 B, one per CU
+// (r = 7: 23^2 = 529 pixels at unit scale)
+template <int R> struct LcGeom {
+  static constexpr int PXMAX = R <= 3 ? 448 : 704;
+  static constexpr int NSLOT = PXMAX + LC_TQ * LC_TQ;
+  static constexpr int STAGE = NSLOT * LC_PITCH;
+  static constexpr int NPRE = (NSLOT * 8 + 255) / 256;  // 16-byte pieces per thread per chunk
+  static constexpr bool PREFETCH = R <= 3;              // larger windows: the accumulators need the registers
+};
+
+template <typename T> struct LcDot;
+template <> struct LcDot<float> {  // 32 channels per 128-byte chunk
+  static constexpr int CC = 32;
+  __device__ static __forceinline__ float dot(const uint4 (&q)[8], const char* p, float acc) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint4 v = *reinterpret_cast<const uint4*>(p + 16 * i);
+      acc = fmaf(__uint_as_float(v.x), __uint_as_float(q[i].x), acc);
+      acc = fmaf(__uint_as_float(v.y), __uint_as_float(q[i].y), acc);
+      acc = fmaf(__uint_as_float(v.z), __uint_as_float(q[i].z), acc);
+      acc = fmaf(__uint_as_float(v.w), __uint_as_float(q[i].w), acc);
+    }
+    return acc;
+  }
+};
+template <> struct LcDot<bf16_t> {  // 64 channels per 128-byte chunk, packed pairs
+  static constexpr int CC = 64;
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  __device__ static __forceinline__ float d2(unsigned x, unsigned y, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x), __builtin_bit_cast(bf16x2, y), acc, false);
+  }
+  __device__ static __forceinline__ float dot(const uint4 (&q)[8], const char* p, float acc) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint4 v = *reinterpret_cast<const uint4*>(p + 16 * i);
+      acc = d2(v.x, q[i].x, acc);
+      acc = d2(v.y, q[i].y, acc);
+      acc = d2(v.z, q[i].z, acc);
+      acc = d2(v.w, q[i].w, acc);
+    }
+    return acc;
+  }
+};
+
+template <int R, typename T, typename TOUT>
+__global__ __launch_bounds__(256, 2) void local_corr_tile_kernel(const LocalCorrArgs a) {
+  constexpr int P = 2 * R + 2, KW = 2 * R + 1, K = KW * KW;
+  constexpr int NR = (P + 3) / 4;  // patch rows per wave
+  constexpr int CC = LcDot<T>::CC;
+  constexpr int LC_STAGE = LcGeom<R>::STAGE, LC_PXMAX = LcGeom<R>::PXMAX, NPRE = LcGeom<R>::NPRE;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  // [0, LC_STAGE): staged pixels (f1 rectangle, then the 64 f0 rows); later reused for the D exchange
+  int* qx0 = reinterpret_cast<int*>(lds + LC_STAGE);       // [64]
+  int* qy0 = qx0 + 64;                                      // [64]
+  float* qfx = reinterpret_cast<float*>(qy0 + 64);          // [64]
+  float* qfy = qfx + 64;                                    // [64]
+  int* tinfo = reinterpret_cast<int*>(qfy + 64);            // bx0, by0, bw, bh
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (a.W + LC_TQ - 1) / LC_TQ, tiles_y = (a.H + LC_TQ - 1) / LC_TQ;
+  const int tpi = tiles_x * tiles_y;
+  const int b = blockIdx.x / tpi;
+  const int trem = blockIdx.x - b * tpi;
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const long HW = (long)a.H * a.W;
+
+  // ---- per-query window origin (lane = query), bounding rectangle of the tile's integer patches
+  const int qy = ty * LC_TQ + (lane >> 3), qx = tx * LC_TQ + (lane & 7);
+  const bool qvalid = qy < a.H && qx < a.W;
+  const long qpix = (long)b * HW + (long)qy * a.W + qx;
+  int x0 = 0, y0 = 0;
+  float fx = 0.f, fy = 0.f;
+  if (qvalid) {
+    unnormalize_floor(a.warp[qpix * 2 + 0], a.W, x0, fx);
+    unnormalize_floor(a.warp[qpix * 2 + 1], a.H, y0, fy);
+  }
+  if (wave == 0) {
+    int xlo = qvalid ? x0 : 0x3fffffff, xhi = qvalid ? x0 : -0x3fffffff;
+    int ylo = qvalid ? y0 : 0x3fffffff, yhi = qvalid ? y0 : -0x3fffffff;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      xlo = min(xlo, __shfl_xor(xlo, off));
+      xhi = max(xhi, __shfl_xor(xhi, off));
+      ylo = min(ylo, __shfl_xor(ylo, off));
+      yhi = max(yhi, __shfl_xor(yhi, off));
+    }
+    qx0[lane] = x0; qy0[lane] = y0; qfx[lane] = fx; qfy[lane] = fy;
+    if (lane == 0) {
+      // rectangle of f1 pixels any query of the tile touches, clipped to the image (outside taps contribute zero)
+      const int bx0 = max(xlo - R, 0), bx1 = min(xhi + R + 1, a.W - 1);
+      const int by0 = max(ylo - R, 0), by1 = min(yhi + R + 1, a.H - 1);
+      tinfo[0] = bx0; tinfo[1] = by0;
+      tinfo[2] = max(bx1 - bx0 + 1, 0);
+      tinfo[3] = max(by1 - by0 + 1, 0);
+    }
+  }
+  __syncthreads();
+  const int bx0 = tinfo[0], by0 = tinfo[1], bw = tinfo[2], bh = tinfo[3];
+  const long npx = (long)bw * bh;
+  const int simg = (b + a.f1_shift) % a.nimg;
+  TOUT* outp = reinterpret_cast<TOUT*>(a.out);
+
+  if (npx > LC_PXMAX || a.force_gather) {
+    // ---- incoherent tile: hand its 64 pixels to the gather kernel
+    if (tid == 0) a.ws[1 + atomicAdd(a.ws, 1)] = (int)blockIdx.x;
+    return;
+  }
+
+  // ---- coherent tile: stage the rectangle + the f0 rows chunk by chunk, dots from LDS
+  const T* f1p = reinterpret_cast<const T*>(a.f1) + (long)simg * HW * a.ld1;
+  const T* f0p = reinterpret_cast<const T*>(a.f0) + (long)b * HW * a.ld0;
+  float acc[NR][P];
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int j = 0; j < P; ++j) acc[i][j] = 0.f;
+  const int nslots = (int)npx + LC_TQ * LC_TQ;  // staged rows: f1 rectangle then the tile's f0 rows
+  const int my_x = x0 - R - bx0, my_y = y0 - R - by0;  // patch origin inside the rectangle (may be negative: clipped)
+  char* f0slot = lds + ((int)npx + lane) * LC_PITCH;
+
+  // staging is split (issue early / write late): the global loads of chunk c + 1 are issued before the dots of chunk c
+  // and written to LDS after them, so HBM latency hides under the LDS / VALU work of this workgroup too
+  constexpr bool PREFETCH = LcGeom<R>::PREFETCH;
+  constexpr int NP = PREFETCH ? NPRE : 1;
+  uint4 pre[NP];
+  const char* psrc[NP];  // per-piece source (chunk 0), nullptr = zero fill; advanced by the chunk offset
+#pragma unroll
+  for (int k = 0; k < (PREFETCH ? NPRE : 0); ++k) {
+    const int i = tid + 256 * k;
+    const int slotp = i >> 3, piece = i & 7;
+    const char* src = nullptr;
+    if (slotp < (int)npx) {
+      const int py = slotp / bw, px = slotp - py * bw;
+      src = reinterpret_cast<const char*>(f1p + ((long)(by0 + py) * a.W + (bx0 + px)) * a.ld1) + piece * 16;
+    } else if (slotp < nslots) {
+      const int q = slotp - (int)npx;
+      const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
+      if (gy < a.H && gx < a.W) src = reinterpret_cast<const char*>(f0p + ((long)gy * a.W + gx) * a.ld0) + piece * 16;
+    }
+    psrc[k] = src;
+    pre[k] = make_uint4(0, 0, 0, 0);
+    if (src) pre[k] = *reinterpret_cast<const uint4*>(src);
+  }
+  for (int c0 = 0; c0 < a.C; c0 += CC) {
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int k = 0; k < NPRE; ++k) {
+        const int i = tid + 256 * k;
+        if (i < nslots * 8) *reinterpret_cast<uint4*>(lds + (i >> 3) * LC_PITCH + (i & 7) * 16) = pre[k];
+      }
+    } else {  // plain staging loop: load and store the pieces of this chunk
+      for (int i = tid; i < nslots * 8; i += 256) {
+        const int slotp = i >> 3, piece = i & 7;
+        const char* src = nullptr;
+        if (slotp < (int)npx) {
+          const int py = slotp / bw, px = slotp - py * bw;
+          src = reinterpret_cast<const char*>(f1p + ((long)(by0 + py) * a.W + (bx0 + px)) * a.ld1 + c0) + piece * 16;
+        } else {
+          const int q = slotp - (int)npx;
+          const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
+          if (gy < a.H && gx < a.W) src = reinterpret_cast<const char*>(f0p + ((long)gy * a.W + gx) * a.ld0 + c0) + piece * 16;
+        }
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (src) v = *reinterpret_cast<const uint4*>(src);
+        *reinterpret_cast<uint4*>(lds + slotp * LC_PITCH + piece * 16) = v;
+      }
+    }
+    __syncthreads();
+    if constexpr (PREFETCH) {
+      if (c0 + CC < a.C) {
+        const long coff = (long)(c0 + CC) * (long)sizeof(T);
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k)
+          if (psrc[k]) pre[k] = *reinterpret_cast<const uint4*>(psrc[k] + coff);
+      }
+    }
+    if (qvalid) {
+      uint4 q[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) q[i] = *reinterpret_cast<const uint4*>(f0slot + 16 * i);
+#pragma unroll
+      for (int ri = 0; ri < NR; ++ri) {
+        const int r = wave + 4 * ri;
+        const int yy = my_y + r;
+        if (r < P && yy >= 0 && yy < bh) {
+#pragma unroll
+          for (int j = 0; j < P; ++j) {
+            const int xx = my_x + j;
+            if (xx >= 0 && xx < bw) acc[ri][j] = LcDot<T>::dot(q, lds + (yy * bw + xx) * LC_PITCH, acc[ri][j]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- exchange the integer-patch dots through LDS: D[q][r][j] (f32), then the bilinear combination per output tap
+  float* Dl = reinterpret_cast<float*>(lds);  // [64][P*P]   (64 * 256 * 4 B = 64 KiB at r = 7)
+#pragma unroll
+  for (int ri = 0; ri < NR; ++ri) {
+    const int r = wave + 4 * ri;
+    if (r < P) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) Dl[lane * (P * P) + r * P + j] = acc[ri][j];
+    }
+  }
+  __syncthreads();
+  for (int o = tid; o < LC_TQ * LC_TQ * K; o += 256) {
+    const int q = o / K, k = o - q * K;
+    const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
+    if (gy >= a.H || gx >= a.W) continue;
+    const int j = k / KW, i = k - j * KW;
+    const float wfx = qfx[q], wfy = qfy[q];
+    const float* d = Dl + q * (P * P) + j * P + i;
+    const float c = (1.f - wfy) * (1.f - wfx) * d[0] + (1.f - wfy) * wfx * d[1] + wfy * (1.f - wfx) * d[P] + wfy * wfx * d[P + 1];
+    ElemIO<TOUT>::st(outp + ((long)b * HW + (long)gy * a.W + gx) * a.ldo + k, c * a.scale);
+  }
+}
+
+// Per-query gathers for the pixels of the tiles local_corr_tile_kernel put on the work list: block = (list entry, round),
+// 4 queries per block (one per wave).  The grid covers every tile; blocks beyond the list exit at once.
+template <int R, typename T, typename TOUT>
+__global__ __launch_bounds__(256) void local_corr_list_kernel(const LocalCorrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float f0s[];  // [4 waves][C]
+  const int li = blockIdx.x >> 4, rnd = blockIdx.x & 15;
+  if (li >= a.ws[0]) return;
+  const int tile = a.ws[1 + li];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles_x = (a.W + LC_TQ - 1) / LC_TQ, tiles_y = (a.H + LC_TQ - 1) / LC_TQ;
+  const int tpi = tiles_x * tiles_y;
+  const int b = tile / tpi;
+  const int trem = tile - b * tpi;
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int q = rnd * 4 + wave;
+  const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
+  const bool act = gy < a.H && gx < a.W;
+  const long pix = (long)b * a.H * a.W + (long)gy * a.W + gx;
+  float* myf0 = f0s + wave * a.C;
+  lc_gather_stage_f0<R, T, TOUT>(a, pix, act, lane, myf0);
+  __syncthreads();
+  lc_gather_pixel<R, T, TOUT>(a, pix, act, lane, myf0);
 }
 
 // General per-tap form: warp[B,HW,K,2] arbitrary coordinates (plugin signature).
@@ -181,6 +457,40 @@ static int check_common(const LocalCorrArgs& a, int ce) {
   return 0;
 }
 
+int g_lc_mode = -1;  // roma_tuning("lc_mode"): -1 / 0 = tiled + work list (default), 1 = every tile to the gather list, 2 = legacy per-pixel launch
+
+template <int R, typename T, typename TOUT>
+static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
+  LocalCorrArgs a = a0;
+  const int tiles = a.B * ((a.H + LC_TQ - 1) / LC_TQ) * ((a.W + LC_TQ - 1) / LC_TQ);
+  const size_t need = (size_t)(tiles + 1) * sizeof(int);
+  bool own_ws = false;
+  if (!a.ws) {  // operator entry points: stream-ordered scratch (the model passes a slice of its arena)
+    ROMA_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&a.ws), need, stream));
+    own_ws = true;
+  } else {
+    ROMA_REQUIRE((size_t)a.ws_bytes >= need, "local_corr(window): work-list scratch too small");
+  }
+  a.force_gather = g_lc_mode == 1 ? 1 : 0;
+  ROMA_CHECK_HIP(hipMemsetAsync(a.ws, 0, sizeof(int), stream));
+  const size_t lds_tile = (size_t)LcGeom<R>::STAGE + 4 * 64 * 4 + 16;
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  ROMA_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_tile_kernel<R, T, TOUT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT>), dim3((unsigned)tiles), dim3(256), lds_tile, stream, a);
+  ROMA_LAUNCH_CHECK();
+  hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
+                     stream, a);
+  ROMA_LAUNCH_CHECK();
+  if (own_ws) ROMA_CHECK_HIP(hipFreeAsync(a.ws, stream));
+  return 0;
+}
+
 template <int R>
 static int launch_window_r(const LocalCorrArgs& a, hipStream_t stream) {
   const long total = (long)a.B * a.H * a.W;
@@ -191,6 +501,15 @@ static int launch_window_r(const LocalCorrArgs& a, hipStream_t stream) {
   char pname[64];
   snprintf(pname, sizeof pname, "local_corr_window_kernel<%d,%s>", R, a.in_dt == DT_F32 ? "f32" : "bf16");
   ProfScope ps(pname, (double)total * (2.0 * a.C * es_in + 8.0 + (2.0 * R + 1) * (2.0 * R + 1) * es_out), "byte", stream);
+  static const int env_mode = getenv("ROMA_LC_MODE") ? atoi(getenv("ROMA_LC_MODE")) : 0;
+  const int mode = g_lc_mode >= 0 ? g_lc_mode : env_mode;
+  const int cc = a.in_dt == DT_F32 ? 32 : 64;  // channels per 128-byte chunk of the tiled form
+  if (mode != 2 && a.C % cc == 0) {
+    if (a.in_dt == DT_F32 && a.out_dt == DT_F32) return launch_tiled<R, float, float>(a, stream);
+    if (a.in_dt == DT_F32) return launch_tiled<R, float, bf16_t>(a, stream);
+    if (a.out_dt == DT_F32) return launch_tiled<R, bf16_t, float>(a, stream);
+    return launch_tiled<R, bf16_t, bf16_t>(a, stream);
+  }
 #define ROMA_LC(T, TOUT) hipLaunchKernelGGL((local_corr_window_kernel<R, T, TOUT>), grid, dim3(256), lds, stream, a)
   if (a.in_dt == DT_F32 && a.out_dt == DT_F32) ROMA_LC(float, float);
   else if (a.in_dt == DT_F32) ROMA_LC(float, bf16_t);

@@ -127,6 +127,10 @@ class Model {
   int make_lin(const std::vector<float>& w, const std::vector<float>* b, int N, int K, Lin* out);
 };
 
+// GP match encoder for all directed pairs of a call (model.hip); scratch comes from `arena` (dry = plan sizes only)
+int gp_posterior(const void* pf, long ldf, int act_dt, int B, bool symmetric, int th, int tw, const float* gp_w,
+                 const float* gp_b, float* mu, long ld_mu, Arena& arena, hipStream_t st, bool dry);
+
 // Batched SPD solve via blocked Cholesky (see include/roma_hip.h roma_op_cholesky_solve_t)
 int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, int n, int d, int batch, hipStream_t st);
 

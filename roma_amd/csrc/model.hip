@@ -587,6 +587,75 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
   return 0;
 }
 
+// ---------------------------------------------------------------- GP match encoder (matcher.py:291-323, 191-200, 274-289)
+// pf: projected stride-16 features of the 2B images [2B, n, ldf] (n = th * tw tokens, 512 channels; images [0, B) = A,
+// [B, 2B) = B).  Directed pair i (i < B, or i < 2B when symmetric) has query image i and support image (i + B) % 2B.
+// mu[i, :, 0:512] = K_xy (K_yy + 0.1 I)^-1 cos(8 pi (W_pos grid + b_pos)), written with row stride ld_mu (f32).
+// K_yy, its Cholesky factor and alpha depend only on the SUPPORT image, so they are computed once per image.
+#define GP_RUN(expr)              \
+  do {                            \
+    if (!dry) {                   \
+      int _rc = (expr);           \
+      if (_rc) return _rc;        \
+    }                             \
+  } while (0)
+int gp_posterior(const void* pf, long ldf, int act_dt, int B, bool symmetric, int th, int tw, const float* gp_w,
+                 const float* gp_b, float* mu, long ld_mu, Arena& arena, hipStream_t st, bool dry) {
+  const size_t esz = act_dt == DT_F32 ? 4 : 2;
+  const int nimg = 2 * B, ndp = symmetric ? 2 * B : B, shift = B;
+  const int n = th * tw, npad = (int)round_up(n, 64), nblk = npad / 64;
+  auto AL = [&](size_t elems, size_t es) { return arena.alloc(elems * es); };
+  auto off = [&](const void* p, long elems) -> const void* { return static_cast<const char*>(p) + elems * (long)esz; };
+  float* norms = (float*)AL((size_t)nimg * n, 4);
+  float* Kyy = (float*)AL((size_t)nimg * npad * npad, 4);
+  float* LT = (float*)AL((size_t)nimg * npad * npad, 4);
+  float* Kxy = (float*)AL((size_t)ndp * n * npad, 4);
+  float* Linv = (float*)AL((size_t)nimg * nblk * 4096, 4);
+  float* LinvT = (float*)AL((size_t)nimg * nblk * 4096, 4);
+  float* Ft = (float*)AL((size_t)512 * npad, 4);
+  float* Rt = (float*)AL((size_t)nimg * 512 * npad, 4);
+  GP_RUN(rownorm_launch(pf, ldf, act_dt, norms, (long)nimg * n, 512, st));
+  // support images actually needed: symmetric -> all, else images [B, 2B)
+  const int j0 = symmetric ? 0 : B, nj = symmetric ? nimg : B;
+  {
+    GemmArgs g;  // K_yy + sigma^2 I  (cosine kernel, CosKernel matcher.py:191-200)
+    g.A = off(pf, (long)j0 * n * ldf); g.lda = ldf; g.sA = (long)n * ldf;
+    g.W = g.A; g.ldw = ldf; g.sW = g.sA;
+    g.C = Kyy + (long)j0 * npad * npad; g.ldc = npad; g.sC = (long)npad * npad;
+    g.M = n; g.N = n; g.K = 512; g.batch = nj; g.in_dt = act_dt; g.out_dt = DT_F32; g.mode = EPI_COSK;
+    g.nx = norms + (long)j0 * n; g.ny = g.nx; g.sNx = n; g.sNy = n; g.inv_t = 1.0f / 0.2f; g.diag_add = 0.1f;
+    GP_RUN(gemm_launch(g, st));
+  }
+  GP_RUN(pad_identity_launch(Kyy + (long)j0 * npad * npad, npad, (long)npad * npad, n, npad, nj, st));
+  if (!dry) ROMA_CHECK_HIP(hipMemsetAsync(Kxy, 0, (size_t)ndp * n * npad * 4, st));
+  for (int half = 0; half < (symmetric ? 2 : 1); ++half) {
+    GemmArgs g;  // K_xy for directed pairs [half*B, half*B + B): x = image i, y = image (i + B) % nimg
+    const int i0 = half * B, s0 = (i0 + shift) % nimg;
+    g.A = off(pf, (long)i0 * n * ldf); g.lda = ldf; g.sA = (long)n * ldf;
+    g.W = off(pf, (long)s0 * n * ldf); g.ldw = ldf; g.sW = (long)n * ldf;
+    g.C = Kxy + (long)i0 * n * npad; g.ldc = npad; g.sC = (long)n * npad;
+    g.M = n; g.N = n; g.K = 512; g.batch = B; g.in_dt = act_dt; g.out_dt = DT_F32; g.mode = EPI_COSK;
+    g.nx = norms + (long)i0 * n; g.ny = norms + (long)s0 * n; g.sNx = n; g.sNy = n; g.inv_t = 1.0f / 0.2f;
+    GP_RUN(gemm_launch(g, st));
+  }
+  GP_RUN(gp_basis_launch(gp_w, gp_b, Ft, 512, th, tw, npad, st));
+  for (int j = j0; j < j0 + nj; ++j)
+    if (!dry) ROMA_CHECK_HIP(hipMemcpyAsync(Rt + (long)j * 512 * npad, Ft, (size_t)512 * npad * 4, hipMemcpyDeviceToDevice, st));
+  GP_RUN(cholesky_solve_t(Kyy + (long)j0 * npad * npad, Rt + (long)j0 * 512 * npad, LT + (long)j0 * npad * npad,
+                          Linv + (long)j0 * nblk * 4096, LinvT + (long)j0 * nblk * 4096, npad, 512, nj, st));
+  for (int half = 0; half < (symmetric ? 2 : 1); ++half) {
+    GemmArgs g;  // mu = K_xy alpha
+    const int i0 = half * B, s0 = (i0 + shift) % nimg;
+    g.A = Kxy + (long)i0 * n * npad; g.lda = npad; g.sA = (long)n * npad;
+    g.W = Rt + (long)s0 * 512 * npad; g.ldw = npad; g.sW = (long)512 * npad;
+    g.C = mu + (long)i0 * n * ld_mu; g.ldc = ld_mu; g.sC = (long)n * ld_mu;
+    g.M = n; g.N = 512; g.K = npad; g.batch = B;
+    GP_RUN(gemm_launch(g, st));
+  }
+  return 0;
+}
+#undef GP_RUN
+
 // ---------------------------------------------------------------- the match() schedule
 #define RUN(expr)                 \
   do {                            \
@@ -806,56 +875,10 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         if (debug && !dry)
           if (int rc = dbg_save("proj16", pf, (size_t)nimg * hw * ldf * esz, st)) return rc;
         // ================= GP match encoder (matcher.py:291-323), f32
-        const int n = T, npad = (int)round_up(n, 64), nblk = npad / 64;
         const size_t gmark = arena.mark();
         float* tokens = (float*)AL((size_t)rows_t * 1024, 4);
         const size_t gmark2 = arena.mark();
-        float* norms = (float*)AL((size_t)nimg * n, 4);
-        float* Kyy = (float*)AL((size_t)nimg * npad * npad, 4);
-        float* LT = (float*)AL((size_t)nimg * npad * npad, 4);
-        float* Kxy = (float*)AL((size_t)ndp * n * npad, 4);
-        float* Linv = (float*)AL((size_t)nimg * nblk * 4096, 4);
-        float* LinvT = (float*)AL((size_t)nimg * nblk * 4096, 4);
-        float* Ft = (float*)AL((size_t)512 * npad, 4);
-        float* Rt = (float*)AL((size_t)nimg * 512 * npad, 4);
-        RUN(rownorm_launch(pf, ldf, act_dt, norms, (long)nimg * n, 512, st));
-        // support images actually needed: symmetric -> all, else images [B, 2B)
-        const int j0 = cfg.symmetric ? 0 : B, nj = cfg.symmetric ? nimg : B;
-        {
-          GemmArgs g;  // K_yy + sigma^2 I  (cosine kernel, CosKernel matcher.py:191-200)
-          g.A = off(pf, (long)j0 * n * ldf); g.lda = ldf; g.sA = (long)n * ldf;
-          g.W = g.A; g.ldw = ldf; g.sW = g.sA;
-          g.C = Kyy + (long)j0 * npad * npad; g.ldc = npad; g.sC = (long)npad * npad;
-          g.M = n; g.N = n; g.K = 512; g.batch = nj; g.in_dt = act_dt; g.out_dt = DT_F32; g.mode = EPI_COSK;
-          g.nx = norms + (long)j0 * n; g.ny = g.nx; g.sNx = n; g.sNy = n; g.inv_t = 1.0f / 0.2f; g.diag_add = 0.1f;
-          RUN(gemm_launch(g, st));
-        }
-        RUN(pad_identity_launch(Kyy + (long)j0 * npad * npad, npad, (long)npad * npad, n, npad, nj, st));
-        if (!dry) ROMA_CHECK_HIP(hipMemsetAsync(Kxy, 0, (size_t)ndp * n * npad * 4, st));
-        for (int half = 0; half < (cfg.symmetric ? 2 : 1); ++half) {
-          GemmArgs g;  // K_xy for directed pairs [half*B, half*B + B): x = image i, y = image (i + B) % nimg
-          const int i0 = half * B, s0 = (i0 + shift) % nimg;
-          g.A = off(pf, (long)i0 * n * ldf); g.lda = ldf; g.sA = (long)n * ldf;
-          g.W = off(pf, (long)s0 * n * ldf); g.ldw = ldf; g.sW = (long)n * ldf;
-          g.C = Kxy + (long)i0 * n * npad; g.ldc = npad; g.sC = (long)n * npad;
-          g.M = n; g.N = n; g.K = 512; g.batch = B; g.in_dt = act_dt; g.out_dt = DT_F32; g.mode = EPI_COSK;
-          g.nx = norms + (long)i0 * n; g.ny = norms + (long)s0 * n; g.sNx = n; g.sNy = n; g.inv_t = 1.0f / 0.2f;
-          RUN(gemm_launch(g, st));
-        }
-        RUN(gp_basis_launch(gp_w, gp_b, Ft, 512, th, tw, npad, st));
-        for (int j = j0; j < j0 + nj; ++j)
-          if (!dry) ROMA_CHECK_HIP(hipMemcpyAsync(Rt + (long)j * 512 * npad, Ft, (size_t)512 * npad * 4, hipMemcpyDeviceToDevice, st));
-        RUN(cholesky_solve_t(Kyy + (long)j0 * npad * npad, Rt + (long)j0 * 512 * npad, LT + (long)j0 * npad * npad,
-                             Linv + (long)j0 * nblk * 4096, LinvT + (long)j0 * nblk * 4096, npad, 512, nj, st));
-        for (int half = 0; half < (cfg.symmetric ? 2 : 1); ++half) {
-          GemmArgs g;  // mu = K_xy alpha  -> tokens[:, 0:512]
-          const int i0 = half * B, s0 = (i0 + shift) % nimg;
-          g.A = Kxy + (long)i0 * n * npad; g.lda = npad; g.sA = (long)n * npad;
-          g.W = Rt + (long)s0 * 512 * npad; g.ldw = npad; g.sW = (long)512 * npad;
-          g.C = tokens + (long)i0 * n * 1024; g.ldc = 1024; g.sC = (long)n * 1024;
-          g.M = n; g.N = 512; g.K = npad; g.batch = B;
-          RUN(gemm_launch(g, st));
-        }
+        if (int rc = gp_posterior(pf, ldf, act_dt, B, cfg.symmetric != 0, th, tw, gp_w, gp_b, tokens, 1024, arena, st, dry)) return rc;
         arena.release(gmark2);
         RUN(copy2d_launch(pf, ldf, act_dt, tokens + 512, 1024, DT_F32, rows_t, 512, st));
         if (debug && !dry)
@@ -914,6 +937,8 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           lc.f0 = pf; lc.f1 = pf; lc.warp = flow; lc.out = off(d0, 2 * r.Cf + r.E);
           lc.B = ndp; lc.H = hs; lc.W = ws; lc.C = r.Cf; lc.radius = r.radius; lc.ld0 = ldf; lc.ld1 = ldf; lc.ldo = r.Cp;
           lc.nimg = nimg; lc.f1_shift = shift; lc.scale = 1.0f / sqrtf((float)r.Cf); lc.in_dt = act_dt; lc.out_dt = act_dt;
+          const long lc_tiles = (long)ndp * ((hs + 7) / 8) * ((ws + 7) / 8);  // tile work list (local_corr.h)
+          lc.ws = (int*)AL((size_t)lc_tiles + 1, 4); lc.ws_bytes = (lc_tiles + 1) * 4;
           RUN(local_corr_window_launch(lc, st));
         }
         if (debug && !dry) {

@@ -350,6 +350,96 @@ def test_local_corr_real_shape_vs_oracle(lib):
     assert torch.allclose(outb.cpu(), refb, atol=1e-3, rtol=1e-4), (outb.cpu() - refb).abs().max()
 
 
+@pytest.mark.parametrize("r,c,h,w", [(2, 256, 37, 43), (3, 512, 35, 35), (7, 512, 20, 24)])
+def test_local_corr_tiled_gather_and_legacy_paths_agree(lib, r, c, h, w):
+    """The three forms of the window kernel - LDS-staged tiles (coherent warps), the per-tile gather work list
+    (incoherent warps) and the per-pixel kernel of round 1 - against the oracle and each other, on a warp that mixes
+    both regimes: a smooth zooming / shifting field (tile path, incl. windows that leave the image on two sides and
+    sizes that are not multiples of the 8 x 8 tile), a noisy band (work list) and far-outside targets."""
+    from oracle import roma_oracle
+    from roma_amd.local_correlation import local_correlation
+    B = 2
+    f0, f1 = rnd(B, c, h, w, seed=1), rnd(B, c, h, w, seed=2)
+    warp = roma_oracle.pixel_grid(B, h, w) * 1.15 + 0.08 + rnd(B, 2, h, w, seed=3, std=0.004)
+    warp[:, :, h // 2:h // 2 + 5] += rnd(B, 2, 5, w, seed=4, std=0.5)      # incoherent band
+    warp[1, :, :3, :3] = 3.0                                                  # far outside: all taps zero
+    ref = roma_oracle.local_correlation(f0, f1, r, warp)
+    refb = roma_oracle.local_correlation(f0.bfloat16().float(), f1.bfloat16().float(), r, warp)
+    outs = {}
+    try:
+        for mode in (0, 1, 2):
+            lib.roma_tuning(b"lc_mode", mode)
+            out = local_correlation(f0.cuda(), f1.cuda(), r, warp.cuda())
+            assert torch.allclose(out.cpu(), ref, atol=1e-4, rtol=1e-5), (mode, float((out.cpu() - ref).abs().max()))
+            outb = local_correlation(f0.cuda().bfloat16(), f1.cuda().bfloat16(), r, warp.cuda())
+            assert torch.allclose(outb.cpu(), refb, atol=1e-3, rtol=1e-4), (mode, float((outb.cpu() - refb).abs().max()))
+            outs[mode] = (out.cpu(), outb.cpu())
+    finally:
+        lib.roma_tuning(b"lc_mode", -1)
+    # the work-list and legacy forms run the same per-pixel code: bit-identical; the tiled form sums in another order
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
+    assert torch.allclose(outs[0][0], outs[1][0], atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("C,E,K,ldf,ldd,h,w", [(512, 64, 49, 512, 1152, 21, 19),   # stride 8: vector kernel, 64 lanes per pixel
+                                               (256, 32, 25, 256, 576, 30, 28),    # stride 4
+                                               (64, 16, 0, 64, 144, 33, 40),       # stride 2: several pixels per wave
+                                               (9, 6, 0, 16, 24, 50, 47)])         # stride 1: the pix<9,6> kernel
+def test_refiner_input_grid_sample_warp(lib, dt, C, E, K, ldf, ldd, h, w):
+    """roma_op_refiner_input (the F.grid_sample warp of matcher.py:132-134 fused with the concat writer and disp_emb) in
+    isolation against torch float64: x copy, bilinear zero-padded sample of the support image (incl. out-of-range and
+    exact-centre coordinates), displacement embedding, zero padding, correlation slice left untouched."""
+    B, nimg, shift = 2, 4, 2
+    tdt = torch.float32 if dt == F32 else torch.bfloat16
+    feat = torch.zeros(nimg, h * w, ldf)
+    feat[:, :, :C] = rnd(nimg, h * w, C, seed=1)
+    feat = feat.to(tdt)
+    ys, xs = torch.linspace(-1 + 1 / h, 1 - 1 / h, h), torch.linspace(-1 + 1 / w, 1 - 1 / w, w)
+    gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+    grid = torch.stack((gx, gy), dim=-1)[None].expand(B, h, w, 2)
+    flow = (grid * 1.1 + rnd(B, h, w, 2, seed=2, std=0.2)).contiguous()
+    flow[0, 0, 0] = torch.tensor([-1.9, 0.3])                          # far outside: zeros
+    flow[0, 0, 1] = torch.tensor([1 - 1 / w, -1 + 1 / h])              # exact pixel centre
+    flow[1, 1, 2] = torch.tensor([1.0, 1.0])                           # on the border: partly outside
+    emb_w, emb_b = rnd(E, 2, seed=3, std=0.7), rnd(E, seed=4, std=0.1)
+    disp_scale = 1.25 * 1.5428
+    d = torch.full((B, h * w, ldd), 7.0).to(tdt).cuda()                # sentinel: the correlation slice must survive
+    ok(lib, lib.roma_op_refiner_input(P(feat.cuda()), ldf, P(flow.cuda()), P(d), ldd, P(emb_w.cuda()), P(emb_b.cuda()), B, h, w, C,
+                                      E, K, nimg, shift, disp_scale, dt, None))
+    torch.cuda.synchronize()
+    got = d.cpu().double()
+    f64 = feat.double()
+    x = f64[:B, :, :C]
+    ysrc = f64[[(b + shift) % nimg for b in range(B)], :, :C].reshape(B, h, w, C).permute(0, 3, 1, 2)
+    xhat = F.grid_sample(ysrc, flow.double(), mode="bilinear", padding_mode="zeros", align_corners=False).permute(0, 2, 3, 1).reshape(B, h * w, C)
+    emb = (disp_scale * (flow.double() - grid.double())).reshape(B, h * w, 2) @ emb_w.double().T + emb_b.double()
+    tol = 2e-5 if dt == F32 else 2e-2
+    assert torch.allclose(got[:, :, :C], x, atol=0, rtol=0)
+    assert torch.allclose(got[:, :, C:2 * C], xhat, atol=tol, rtol=tol), float((got[:, :, C:2 * C] - xhat).abs().max())
+    assert torch.allclose(got[:, :, 2 * C:2 * C + E], emb, atol=tol, rtol=tol)
+    assert bool((got[:, :, 2 * C + E:2 * C + E + K] == 7.0).all())
+    assert bool((got[:, :, 2 * C + E + K:] == 0.0).all())
+
+
+@pytest.mark.parametrize("b,h,w", [(2, 8, 8), (1, 12, 10)])
+def test_gp_posterior_vs_oracle(lib, b, h, w):
+    """roma_op_gp = GP.forward (matcher.py:291-323) in isolation against the CPU oracle (which is pinned on the
+    reference's gp16 stage by tests/test_cpu_oracle.py): cosine-kernel Gram matrices, blocked Cholesky, posterior mean."""
+    from oracle import roma_oracle
+    x, y = rnd(b, 512, h, w, seed=1), rnd(b, 512, h, w, seed=2)
+    sd = {"decoder.gps.16.pos_conv.weight": rnd(512, 2, 1, 1, seed=3, std=0.5), "decoder.gps.16.pos_conv.bias": rnd(512, seed=4, std=0.5)}
+    ref = roma_oracle.gp_posterior(x, y, sd)                                   # [b, 512, h, w]
+    xt = x.permute(0, 2, 3, 1).reshape(b, h * w, 512).contiguous().cuda()
+    yt = y.permute(0, 2, 3, 1).reshape(b, h * w, 512).contiguous().cuda()
+    mu = torch.empty(b, h * w, 512, device="cuda")
+    ok(lib, lib.roma_op_gp(P(xt), P(yt), P(sd["decoder.gps.16.pos_conv.weight"].reshape(512, 2).contiguous().cuda()),
+                           P(sd["decoder.gps.16.pos_conv.bias"].cuda()), P(mu), b, h, w, F32, None))
+    torch.cuda.synchronize()
+    got = mu.cpu().reshape(b, h, w, 512).permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=2e-4, rtol=1e-4), float((got - ref).abs().max())
+
+
 @pytest.mark.parametrize("hin,hout,nc", [(40, 70, 2), (70, 140, 1), (560, 108, 2), (8, 14, 1)])
 def test_resize_bilinear(lib, hin, hout, nc):
     x = rnd(2, nc, hin, hin, seed=1)
