@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
   const bf16_t* Ab = reinterpret_cast<const bf16_t*>(a.A);
   const bf16_t* Wb = reinterpret_cast<const bf16_t*>(a.W);
   const char* zrows = reinterpret_cast<const char*>(g_zero_rows);
-  const int nk = a.K / BK;
+  const int nk = (a.dbg & 2) ? 2 : a.K / BK;  // dbg 2: two K tiles only (isolates the per-tile overhead in A/B runs)
 
   // ---- LDS-DMA descriptors.  A half-tile is 128 LDS rows = 16 pieces of 8 rows; wave w stages pieces 2w, 2w + 1 of
   // every half-tile.  lane -> (row r8 of the piece, 16-byte slot); the slot holds source chunk slot ^ ((row >> 1) & 7).
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
     c_tn = n_tn;
 
     // ---------------------------------------------------------------- epilogue (staged row writers, gemm_device.h)
-    {
+    if (!(a.dbg & 256)) {  // dbg 256: no epilogue at all (tuning experiments)
       constexpr int SLICE = 4096;  // bf16: 32 rows x 128 B of the wave's 64 columns; f32: one 32 x 32 block
       char* ws = smem + 2 * BUF + wave * SLICE;
       const long mw0 = m0 + (long)wr * 128;

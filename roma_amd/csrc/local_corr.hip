@@ -16,6 +16,7 @@
 #include "local_corr.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "gemm.h"  // DT_*
 
 namespace roma {
@@ -218,15 +219,25 @@ __global__ __launch_bounds__(256, 2) void local_corr_tile_kernel(const LocalCorr
   int* qy0 = qx0 + 64;                                      // [64]
   float* qfx = reinterpret_cast<float*>(qy0 + 64);          // [64]
   float* qfy = qfx + 64;                                    // [64]
-  int* tinfo = reinterpret_cast<int*>(qfy + 64);            // bx0, by0, bw, bh
+  int* tinfo = reinterpret_cast<int*>(qfy + 64);            // bx0, by0, bw, bh, dequeued list index
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (a.W + LC_TQ - 1) / LC_TQ, tiles_y = (a.H + LC_TQ - 1) / LC_TQ;
   const int tpi = tiles_x * tiles_y;
-  const int b = blockIdx.x / tpi;
-  const int trem = blockIdx.x - b * tpi;
-  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
   const long HW = (long)a.H * a.W;
+  const int* tlist = a.ws + 4 + a.B * tpi;  // coherent tiles (local_corr_classify_kernel)
+  // persistent workgroups pull tiles from the list (one atomic per tile): a launch sized for the worst case costs
+  // nothing when most tiles went to the gather list
+  for (;;) {
+  __syncthreads();  // previous tile's readers of tinfo / the stage are done
+  if (tid == 0) tinfo[4] = atomicAdd(a.ws + 2, 1);
+  __syncthreads();
+  const int tidx = tinfo[4];
+  if (tidx >= a.ws[1]) break;
+  const int tile = tlist[tidx];
+  const int b = tile / tpi;
+  const int trem = tile - b * tpi;
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
 
   // ---- per-query window origin (lane = query), bounding rectangle of the tile's integer patches
   const int qy = ty * LC_TQ + (lane >> 3), qx = tx * LC_TQ + (lane & 7);
@@ -264,11 +275,7 @@ __global__ __launch_bounds__(256, 2) void local_corr_tile_kernel(const LocalCorr
   const int simg = (b + a.f1_shift) % a.nimg;
   TOUT* outp = reinterpret_cast<TOUT*>(a.out);
 
-  if (npx > LC_PXMAX || a.force_gather) {
-    // ---- incoherent tile: hand its 64 pixels to the gather kernel
-    if (tid == 0) a.ws[1 + atomicAdd(a.ws, 1)] = (int)blockIdx.x;
-    return;
-  }
+  if (npx > LC_PXMAX) continue;  // (cannot happen: the classifier only lists tiles that fit)
 
   // ---- coherent tile: stage the rectangle + the f0 rows chunk by chunk, dots from LDS
   const T* f1p = reinterpret_cast<const T*>(a.f1) + (long)simg * HW * a.ld1;
@@ -378,30 +385,78 @@ __global__ __launch_bounds__(256, 2) void local_corr_tile_kernel(const LocalCorr
     const float c = (1.f - wfy) * (1.f - wfx) * d[0] + (1.f - wfy) * wfx * d[1] + wfy * (1.f - wfx) * d[P] + wfy * wfx * d[P + 1];
     ElemIO<TOUT>::st(outp + ((long)b * HW + (long)gy * a.W + gx) * a.ldo + k, c * a.scale);
   }
+  }  // tile loop
 }
 
-// Per-query gathers for the pixels of the tiles local_corr_tile_kernel put on the work list: block = (list entry, round),
-// 4 queries per block (one per wave).  The grid covers every tile; blocks beyond the list exit at once.
-template <int R, typename T, typename TOUT>
-__global__ __launch_bounds__(256) void local_corr_list_kernel(const LocalCorrArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float f0s[];  // [4 waves][C]
-  const int li = blockIdx.x >> 4, rnd = blockIdx.x & 15;
-  if (li >= a.ws[0]) return;
-  const int tile = a.ws[1 + li];
+// Tile classifier: one wave per 8 x 8 query tile computes the bounding rectangle of the tile's integer patches (clipped
+// to the image) and appends the tile to the coherent list (rectangle fits the LDS stage) or to the gather list.
+// ws: [0] gather count, [1] coherent count, [2] / [3] dequeue cursors, then the two lists (tiles ints each).
+template <int R>
+__global__ __launch_bounds__(256) void local_corr_classify_kernel(const LocalCorrArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles_x = (a.W + LC_TQ - 1) / LC_TQ, tiles_y = (a.H + LC_TQ - 1) / LC_TQ;
-  const int tpi = tiles_x * tiles_y;
+  const int tpi = tiles_x * tiles_y, tiles = a.B * tpi;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= tiles) return;
   const int b = tile / tpi;
   const int trem = tile - b * tpi;
   const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-  const int q = rnd * 4 + wave;
-  const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
-  const bool act = gy < a.H && gx < a.W;
-  const long pix = (long)b * a.H * a.W + (long)gy * a.W + gx;
+  const int qy = ty * LC_TQ + (lane >> 3), qx = tx * LC_TQ + (lane & 7);
+  const bool qvalid = qy < a.H && qx < a.W;
+  int x0 = 0, y0 = 0;
+  float fx, fy;
+  if (qvalid) {
+    const long qpix = (long)b * a.H * a.W + (long)qy * a.W + qx;
+    unnormalize_floor(a.warp[qpix * 2 + 0], a.W, x0, fx);
+    unnormalize_floor(a.warp[qpix * 2 + 1], a.H, y0, fy);
+  }
+  int xlo = qvalid ? x0 : 0x3fffffff, xhi = qvalid ? x0 : -0x3fffffff;
+  int ylo = qvalid ? y0 : 0x3fffffff, yhi = qvalid ? y0 : -0x3fffffff;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    xlo = min(xlo, __shfl_xor(xlo, off));
+    xhi = max(xhi, __shfl_xor(xhi, off));
+    ylo = min(ylo, __shfl_xor(ylo, off));
+    yhi = max(yhi, __shfl_xor(yhi, off));
+  }
+  if (lane == 0) {
+    const long bw = max(min(xhi + R + 1, a.W - 1) - max(xlo - R, 0) + 1, 0);
+    const long bh = max(min(yhi + R + 1, a.H - 1) - max(ylo - R, 0) + 1, 0);
+    const bool coherent = bw * bh <= LcGeom<R>::PXMAX && !a.force_gather;
+    if (coherent) a.ws[4 + tiles + atomicAdd(a.ws + 1, 1)] = tile;
+    else a.ws[4 + atomicAdd(a.ws + 0, 1)] = tile;
+  }
+}
+
+// Per-query gathers for the pixels of the tiles on the gather list: work item = (list entry, round of 4 queries), one
+// query per wave; persistent workgroups pull items with one atomic each.
+template <int R, typename T, typename TOUT>
+__global__ __launch_bounds__(256) void local_corr_list_kernel(const LocalCorrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float f0s[];  // [4 waves][C] + 1 int
+  int* item_s = reinterpret_cast<int*>(f0s + 4 * a.C);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles_x = (a.W + LC_TQ - 1) / LC_TQ, tiles_y = (a.H + LC_TQ - 1) / LC_TQ;
+  const int tpi = tiles_x * tiles_y;
+  const int nitems = a.ws[0] * 16;
   float* myf0 = f0s + wave * a.C;
-  lc_gather_stage_f0<R, T, TOUT>(a, pix, act, lane, myf0);
-  __syncthreads();
-  lc_gather_pixel<R, T, TOUT>(a, pix, act, lane, myf0);
+  for (;;) {
+    __syncthreads();  // previous item's readers of the f0 slices / item_s are done
+    if (threadIdx.x == 0) *item_s = atomicAdd(a.ws + 3, 1);
+    __syncthreads();
+    const int item = *item_s;
+    if (item >= nitems) break;
+    const int tile = a.ws[4 + (item >> 4)], rnd = item & 15;
+    const int b = tile / tpi;
+    const int trem = tile - b * tpi;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int q = rnd * 4 + wave;
+    const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
+    const bool act = gy < a.H && gx < a.W;
+    const long pix = (long)b * a.H * a.W + (long)gy * a.W + gx;
+    lc_gather_stage_f0<R, T, TOUT>(a, pix, act, lane, myf0);
+    __syncthreads();
+    lc_gather_pixel<R, T, TOUT>(a, pix, act, lane, myf0);
+  }
 }
 
 // General per-tap form: warp[B,HW,K,2] arbitrary coordinates (plugin signature).
@@ -463,7 +518,7 @@ template <int R, typename T, typename TOUT>
 static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   LocalCorrArgs a = a0;
   const int tiles = a.B * ((a.H + LC_TQ - 1) / LC_TQ) * ((a.W + LC_TQ - 1) / LC_TQ);
-  const size_t need = (size_t)(tiles + 1) * sizeof(int);
+  const size_t need = (size_t)(2 * tiles + 4) * sizeof(int);
   bool own_ws = false;
   if (!a.ws) {  // operator entry points: stream-ordered scratch (the model passes a slice of its arena)
     ROMA_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&a.ws), need, stream));
@@ -472,8 +527,8 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
     ROMA_REQUIRE((size_t)a.ws_bytes >= need, "local_corr(window): work-list scratch too small");
   }
   a.force_gather = g_lc_mode == 1 ? 1 : 0;
-  ROMA_CHECK_HIP(hipMemsetAsync(a.ws, 0, sizeof(int), stream));
-  const size_t lds_tile = (size_t)LcGeom<R>::STAGE + 4 * 64 * 4 + 16;
+  ROMA_CHECK_HIP(hipMemsetAsync(a.ws, 0, 4 * sizeof(int), stream));
+  const size_t lds_tile = (size_t)LcGeom<R>::STAGE + 4 * 64 * 4 + 32;
   static bool attr_set[64] = {false};
   int dev = 0;
   ROMA_CHECK_HIP(hipGetDevice(&dev));
@@ -482,10 +537,15 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT>), dim3((unsigned)tiles), dim3(256), lds_tile, stream, a);
+  hipLaunchKernelGGL((local_corr_classify_kernel<R>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
   ROMA_LAUNCH_CHECK();
-  hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
+  // persistent grids: what the chip can hold (LDS-limited for the tiled form), never more than there is work
+  const int per_cu = (160 * 1024) / (int)lds_tile;
+  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT>), dim3((unsigned)std::min(tiles, 256 * per_cu)), dim3(256), lds_tile,
                      stream, a);
+  ROMA_LAUNCH_CHECK();
+  hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT>), dim3((unsigned)std::min(tiles * 16, 256 * 8)), dim3(256),
+                     (size_t)4 * a.C * sizeof(float) + 16, stream, a);
   ROMA_LAUNCH_CHECK();
   if (own_ws) ROMA_CHECK_HIP(hipFreeAsync(a.ws, stream));
   return 0;
@@ -504,11 +564,15 @@ static int launch_window_r(const LocalCorrArgs& a, hipStream_t stream) {
   static const int env_mode = getenv("ROMA_LC_MODE") ? atoi(getenv("ROMA_LC_MODE")) : 0;
   const int mode = g_lc_mode >= 0 ? g_lc_mode : env_mode;
   const int cc = a.in_dt == DT_F32 ? 32 : 64;  // channels per 128-byte chunk of the tiled form
-  if (mode != 2 && a.C % cc == 0) {
-    if (a.in_dt == DT_F32 && a.out_dt == DT_F32) return launch_tiled<R, float, float>(a, stream);
-    if (a.in_dt == DT_F32) return launch_tiled<R, float, bf16_t>(a, stream);
-    if (a.out_dt == DT_F32) return launch_tiled<R, bf16_t, float>(a, stream);
-    return launch_tiled<R, bf16_t, bf16_t>(a, stream);
+  // the tiled form is instantiated for the radii RoMa uses (roma_models.py:103-139: 7, 3, 2); other radii keep the
+  // per-pixel kernel
+  if constexpr (R == 2 || R == 3 || R == 7) {
+    if (mode != 2 && a.C % cc == 0) {
+      if (a.in_dt == DT_F32 && a.out_dt == DT_F32) return launch_tiled<R, float, float>(a, stream);
+      if (a.in_dt == DT_F32) return launch_tiled<R, float, bf16_t>(a, stream);
+      if (a.out_dt == DT_F32) return launch_tiled<R, bf16_t, float>(a, stream);
+      return launch_tiled<R, bf16_t, bf16_t>(a, stream);
+    }
   }
 #define ROMA_LC(T, TOUT) hipLaunchKernelGGL((local_corr_window_kernel<R, T, TOUT>), grid, dim3(256), lds, stream, a)
   if (a.in_dt == DT_F32 && a.out_dt == DT_F32) ROMA_LC(float, float);

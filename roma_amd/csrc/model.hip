@@ -938,7 +938,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           lc.B = ndp; lc.H = hs; lc.W = ws; lc.C = r.Cf; lc.radius = r.radius; lc.ld0 = ldf; lc.ld1 = ldf; lc.ldo = r.Cp;
           lc.nimg = nimg; lc.f1_shift = shift; lc.scale = 1.0f / sqrtf((float)r.Cf); lc.in_dt = act_dt; lc.out_dt = act_dt;
           const long lc_tiles = (long)ndp * ((hs + 7) / 8) * ((ws + 7) / 8);  // tile work list (local_corr.h)
-          lc.ws = (int*)AL((size_t)lc_tiles + 1, 4); lc.ws_bytes = (lc_tiles + 1) * 4;
+          lc.ws = (int*)AL((size_t)2 * lc_tiles + 4, 4); lc.ws_bytes = (2 * lc_tiles + 4) * 4;
           RUN(local_corr_window_launch(lc, st));
         }
         if (debug && !dry) {

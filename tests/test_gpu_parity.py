@@ -11,7 +11,7 @@ and over `certainty`; the coarse arg-max (utils/utils.py:315) is discontinuous, 
 with the oracle within LOGIT_TOL and every token whose class differs must have an oracle top-2 gap below 2 x its own
 logit error (i.e. the flip is explained by the logit error, never by something else), and (b) with the oracle's coarse
 match injected (roma_debug_inject) every later stage and the final outputs are held to the bounds below.  The bounds
-are ~3x what was measured on MI355X (profiles/r02_bf16_parity.json); bf16 carries 8 mantissa bits through ~60 layers.
+are ~3x what was measured on MI355X (profiles/r02_parity_report.json); bf16 carries 8 mantissa bits through ~60 layers.
 """
 import json
 import os
@@ -29,10 +29,17 @@ import parity_metrics as PM  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 TOL_F32 = 1e-3
-# bf16 bounds (flow in [-1, 1] normalised coordinates, certainty in [0, 1])
-BF16 = dict(logit=0.5,            # max |class logit - oracle| (logits are O(10), top-2 gaps O(1))
-            flow_max=2e-2, flow_p99=4e-3, cert_max=0.25, cert_p99=5e-2,   # final outputs, coarse match injected
-            feat_rel=4e-2)        # max |stage - oracle| / max |oracle| of the encoder pyramids
+# bf16 bounds (flow in [-1, 1] normalised coordinates, certainty in [0, 1]); measured on MI355X in round 2
+# (profiles/r02_parity_report.json): class logits up to 1.27 off at 112 -> 168 (logits O(10..25), median top-2 gap 2.3), 2.2 %
+# of the coarse tokens flip, every flipped token has a reference gap <= 0.58; with the reference's coarse match injected
+# the outputs differ by <= 1.5e-4 (flow, p99 1.0e-4) / 1.1e-2 (certainty, p99 5.4e-3) at 560 -> 864, 4.8e-4 / 6.5e-3 at
+# 112 -> 168; encoder pyramids <= 0.9 % of their range (stride 16: 2.5 %)
+BF16 = dict(logit=3.0,            # max |class logit - oracle|
+            gap_flipped=1.5,      # a token may only flip where the reference's own top-2 gap is below this
+            flip_frac=0.05,       # and at most this share of the tokens does
+            flow_max=1.5e-3, flow_p99=1.0e-3, cert_max=3e-2, cert_p99=1.5e-2,   # final outputs, coarse match injected
+            cert_logit_stage=0.2, # per-scale certainty logits (before the sigmoid), coarse match injected
+            feat_rel=3e-2)        # max |stage - oracle| / max |oracle| of the encoder pyramids (x2 at stride 16 / GP)
 
 
 def _dev(d):
@@ -124,7 +131,7 @@ def test_bf16_tiny_stagewise_vs_oracle(built_lib, weights0):
                 r[f"{p}_flow{s}"] = float((f - st[f"{p}_flow{s}"]).abs().max())
                 r[f"{p}_cert{s}"] = float((c - st[f"{p}_cert{s}"]).abs().max())
                 checks.append((bool(r[f"{p}_flow{s}"] < BF16["flow_max"]), str((p, s, r))))
-                checks.append((bool(r[f"{p}_cert{s}"] < 1.0), str((p, s, r))))  # certainty LOGITS (before the sigmoid)
+                checks.append((bool(r[f"{p}_cert{s}"] < BF16["cert_logit_stage"]), str((p, s, r))))  # certainty LOGITS
         e = PM.output_errors(warp.cpu().numpy(), cert.cpu().numpy(), w_ref, c_ref)
         r["final_injected"] = e
         checks.append((e["flow"]["max"] < BF16["flow_max"] and e["flow"]["p99"] < BF16["flow_p99"], str(("tiny injected flow", e["flow"]))))
@@ -174,8 +181,8 @@ def _bf16_vs_golden(tag, m, inp, g):
     e_inj = PM.output_errors(w[:, ::8, ::8], c[:, ::8, ::8], g["warp_sub"], g["cert_sub"])
     _report(tag, {"coarse": fl, "uninjected": e_raw, "injected": e_inj})
     assert np.isfinite(w).all() and np.isfinite(c).all()
-    assert fl["max_gap_of_flipped"] < 2 * BF16["logit"], fl       # flips only where the reference itself is undecided
-    assert fl["flips"] <= 0.05 * fl["tokens"], fl
+    assert fl["max_gap_of_flipped"] < BF16["gap_flipped"], fl     # flips only where the reference itself is undecided
+    assert fl["flips"] <= BF16["flip_frac"] * fl["tokens"], fl
     assert fl["max_flow16_err_unflipped"] < 1e-2, fl
     _check_out(tag, e_inj)
     return fl, e_raw, e_inj

@@ -19,6 +19,7 @@ from roma_amd import _lib  # noqa: E402
 lib = _lib.load()
 BF16, F32 = 1, 0
 dev = "cuda"
+_KEEP = []
 
 
 def P(t):
@@ -47,17 +48,26 @@ def make_gemm(M, N, K, ldc, act=0):
 
     def run(stream):
         with torch.cuda.stream(stream):  # zero-fill ordered before the GEMM (pad columns stay zero)
-            out = torch.zeros(M, ldc, device=dev, dtype=torch.bfloat16)
+            out = keep(torch.zeros(M, ldc, device=dev, dtype=torch.bfloat16))
         ok(lib.roma_op_gemm(P(A), K, P(W), K, P(out), ldc, M, N, K, 1, 0, 0, 0, P(b), None, None, 0, act, 1.0, BF16, BF16, S(stream)))
         return out
     return run
+
+
+def keep(t):
+    """Every output stays allocated until the round's torch.cuda.synchronize(): the launches go to side streams through
+    raw pointers, so the caching allocator (which only knows the default stream) would otherwise hand an aggressor's
+    still-being-written buffer to the next victim launch - that aliasing, not a kernel bug, made the first version of
+    this tool report O(1) differences."""
+    _KEEP.append(t)
+    return t
 
 
 def make_dwconv(B, H, W, Cp):
     x, w, b = rnd(B, H, W, Cp, dtype=torch.bfloat16), rnd(25, Cp, std=0.1), rnd(Cp, std=0.1)
 
     def run(stream):
-        out = torch.empty_like(x)
+        out = keep(torch.empty_like(x))
         ok(lib.roma_op_dwconv5x5(P(x), P(out), P(w), P(b), B, H, W, Cp, BF16, S(stream)))
         return out
     return run
@@ -68,7 +78,7 @@ def make_refiner_block(B, H, W, Cp):
     pw, pb = rnd(Cp, Cp, std=0.05, dtype=torch.bfloat16), rnd(Cp)
 
     def run(stream):
-        out = torch.empty_like(x)
+        out = keep(torch.empty_like(x))
         ok(lib.roma_op_refiner_block(P(x), P(out), P(w), P(b), P(pw), P(pb), B, H, W, Cp, BF16, S(stream)))
         return out
     return run
@@ -78,7 +88,7 @@ def make_conv3x3(B, H, W, Cin, Cout):
     x, w, b = rnd(B, H, W, Cin, dtype=torch.bfloat16), rnd(Cout, 9 * Cin, std=0.05, dtype=torch.bfloat16), rnd(Cout)
 
     def run(stream):
-        out = torch.empty(B, H, W, Cout, device=dev, dtype=torch.bfloat16)
+        out = keep(torch.empty(B, H, W, Cout, device=dev, dtype=torch.bfloat16))
         ok(lib.roma_op_conv3x3(P(x), P(w), P(b), P(out), B, H, W, Cin, Cout, 1, BF16, S(stream)))
         return out
     return run
@@ -88,7 +98,7 @@ def make_maxpool(B, H, W, Cc):
     x = rnd(B, H, W, Cc, dtype=torch.bfloat16)
 
     def run(stream):
-        out = torch.empty(B, H // 2, W // 2, Cc, device=dev, dtype=torch.bfloat16)
+        out = keep(torch.empty(B, H // 2, W // 2, Cc, device=dev, dtype=torch.bfloat16))
         ok(lib.roma_op_maxpool2x2(P(x), P(out), B, H, W, Cc, BF16, S(stream)))
         return out
     return run
@@ -98,7 +108,7 @@ def make_conv_c3(B, H, W):
     img, w, b = rnd(B, 3, H, W), rnd(27, 64, std=0.1), rnd(64)
 
     def run(stream):
-        out = torch.empty(B, H, W, 64, device=dev, dtype=torch.bfloat16)
+        out = keep(torch.empty(B, H, W, 64, device=dev, dtype=torch.bfloat16))
         ok(lib.roma_op_conv3x3_c3(P(img), P(w), P(b), P(out), B, H, W, BF16, S(stream)))
         return out
     return run
@@ -126,8 +136,6 @@ def make_chain(B, H, W, Cp, fused):
         return a
     return run
 
-
-_KEEP = []
 
 VICTIMS = {
     "chain 9 x (dwconv + gemm) 4x168x168x24": make_chain(NDP, HF, HF, 24, False),

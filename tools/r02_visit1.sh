@@ -36,6 +36,9 @@ echo "== bench (gemm8p on / off)"
 timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$OUT/bench_8p.json" 2> "$OUT/bench_8p.err"; tail -2 "$OUT/bench_8p.err"; cut -c1-600 "$OUT/bench_8p.json"
 ROMA_GEMM8P=0 timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity > "$OUT/bench_classic.json" 2> "$OUT/bench_classic.err"; cut -c1-400 "$OUT/bench_classic.json"
 
+echo "== local correlation regimes"
+timeout 200 python tools/bench_local_corr.py > "$OUT/bench_local_corr.log" 2>&1; tail -12 "$OUT/bench_local_corr.log" | cut -c1-330
+
 echo "== co-run stress"
 timeout 300 python tools/corun_stress.py 10 > "$OUT/corun_stress.log" 2>&1; grep -v "   0/" "$OUT/corun_stress.log" | tail -30
 
