@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--upsample", type=int, default=864)
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="sub-batch HIP streams per GPU (2 = stream split, see DESIGN.md)")
+    ap.add_argument("--graph", type=int, default=None, choices=[0, 1],
+                    help="replay match() as a captured hipGraph (default: 1 for --config coarse, 0 for the batch-8 metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -145,6 +147,7 @@ def main():
         model = roma_outdoor(device=dev, weights=sd, dinov2_weights=dsd, coarse_res=args.coarse, upsample_res=args.upsample,
                              amp_dtype=amp, symmetric=True, upsample_preds=full, max_batch=args.batch)
         model.dual_stream = args.streams == 2
+        model.graph = bool(args.graph if args.graph is not None else (not full))
         inp = {k: v.to(dev) for k, v in synthetic.make_inputs(args.batch, args.coarse, args.upsample if full else None,
                                                               seed=1 + rank).items()}
     n_pairs = args.batch * world
@@ -220,7 +223,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"roma_outdoor match() {what}, {args.batch} pairs/GPU/step, seeded synthetic weights + N(0,1) images",
-                   "global_batch": n_pairs, "streams_per_gpu": int(os.environ.get("ROMA_STREAMS", args.streams)),
+                   "global_batch": n_pairs, "hip_graph": bool(getattr(model, "graph", False)), "streams_per_gpu": int(os.environ.get("ROMA_STREAMS", args.streams)),
                    "parallelism": (f"pairs sharded x{world}, {'gloo (dry run)' if args.dry else 'RCCL'} gather of results "
                                    "(step i's gather overlaps step i+1's match)") if world > 1 else "single GPU",
                    "outputs_finite": finite},

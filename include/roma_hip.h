@@ -53,7 +53,10 @@ int roma_finalize(roma_handle_t h);
  *         backbone, encoders.py; 0 = keep it in f32),
  *         "streams" (1..4, default 1) / "dual_stream" (1 = 2 streams): run a batch as sub-batches on several HIP streams
  *         (+5 % at batch 8 with 2; side workspaces are allocated on first use; bf16 results are then reproducible only
- *         to ~1 bf16 ulp, f32 results exactly - DESIGN.md) */
+ *         to ~1 bf16 ulp, f32 results exactly - DESIGN.md),
+ *         "graph" (default 0; 1 = capture the kernel schedule of each (batch, options) configuration into a hipGraph on
+ *         its second call and replay it afterwards: one launch instead of ~1 600, for small batches where match() is
+ *         host-bound; images / outputs go through persistent staging copies) */
 int roma_set_option(roma_handle_t h, const char* key, int value);
 /* "coarse_scale_factor": the displacement-embedding scale of the COARSE pass, sqrt(h_resized * w_resized / 560^2) of the
  * matcher's configured resolution (matcher.py:805) - it differs from the handle's own resolution only when the caller

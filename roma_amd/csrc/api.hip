@@ -89,6 +89,7 @@ int roma_set_option(roma_handle_t h, const char* key, int value) {
   else if (k == "fuse_refiner_blocks") h->m.fuse_refiner_blocks = value != 0;
   else if (k == "vit_bf16_residual") h->m.vit_bf16_residual = value != 0;
   else if (k == "dual_stream") h->m.n_streams = value != 0 ? 2 : 1;
+  else if (k == "graph") h->m.graph_mode = value != 0 ? 1 : 0;
   else if (k == "streams") {
     ROMA_REQUIRE(value >= 1 && value <= Model::MAX_STREAMS, "roma_set_option: streams must be 1..4");
     h->m.n_streams = value;

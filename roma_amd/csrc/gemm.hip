@@ -333,7 +333,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
       }
     }
     bool staged = a.mode == EPI_STD && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0;
-    if constexpr (sizeof(TOUT) == 2) staged = staged && Rb == nullptr && (a.ldc & 7) == 0;  // res_bf16: see gemm_launch
+    if constexpr (sizeof(TOUT) == 2)  // res_bf16: see gemm_launch; no per-column scale in the bf16 row writer
+      staged = staged && Rb == nullptr && (a.ldc & 7) == 0 && (a.scale == nullptr || a.res_bf16 != nullptr);
     else staged = staged && vecC && (Rb == nullptr || vecR) && (a.N & 3) == 0 && a.act != ACT_GELU;
     if (staged) {
       if constexpr (NWAVES != 8) __builtin_amdgcn_s_barrier();
@@ -351,8 +352,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
           else epi_staged_bf16<TM, TN, ACT_RELU, false>(acc, a, Cbb, ws, mw0, nw0, lane);
         } else if (a.res_bf16) {
           const bf16_t* Rbb = reinterpret_cast<const bf16_t*>(a.res_bf16) + (long)bz * a.sR;
-          if (full_tile) epi_staged_bf16<TM, TN, ACT_NONE, true, true>(acc, a, Cbb, ws, mw0, nw0, lane, Rbb);
-          else epi_staged_bf16<TM, TN, ACT_NONE, false, true>(acc, a, Cbb, ws, mw0, nw0, lane, Rbb);
+          if (a.scale) {  // operator entry point only (the model folds LayerScale into the weights)
+            epi_staged_bf16<TM, TN, ACT_NONE, false, true, true>(acc, a, Cbb, ws, mw0, nw0, lane, Rbb);
+          } else {
+            if (full_tile) epi_staged_bf16<TM, TN, ACT_NONE, true, true>(acc, a, Cbb, ws, mw0, nw0, lane, Rbb);
+            else epi_staged_bf16<TM, TN, ACT_NONE, false, true>(acc, a, Cbb, ws, mw0, nw0, lane, Rbb);
+          }
         } else {
           if (full_tile) epi_staged_bf16<TM, TN, ACT_NONE, true>(acc, a, Cbb, ws, mw0, nw0, lane);
           else epi_staged_bf16<TM, TN, ACT_NONE, false>(acc, a, Cbb, ws, mw0, nw0, lane);

@@ -60,17 +60,59 @@ template <int CPR> __device__ __forceinline__ int epi_swz(int row) {
   else return 0;
 }
 
-template <int ACT, bool FULL, bool BF16_OUT>
-__device__ __forceinline__ f32x4 epi_vals(f32x4 v, const GemmArgs& a, int n) {
-  if (a.bias) {
-    if (FULL || n + 3 < a.N) {
-      v += *reinterpret_cast<const f32x4*>(a.bias + n);
-    } else {
+// "this value is read here" for the compiler's wait-count bookkeeping (no instruction is emitted)
+__device__ __forceinline__ void epi_consume(f32x4 v) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); }
+__device__ __forceinline__ void epi_consume(uint4 v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+
+// Per-column epilogue vectors (bias, LayerScale) of the wave's TN x 32 columns.  Each lane needs the same 4 consecutive
+// columns of every 8-column group for ALL its rows, so they are loaded ONCE per tile, back to back, before the
+// accumulators are touched: one vmcnt wait per tile.  (Loading them where they are used - inside the (tm, tn, rg) loops -
+// made hipcc emit `global_load ; s_waitcnt vmcnt(0) ; use` 32..64 times per tile, each a serialised L2 round trip that
+// also drains the LDS-DMA queue: ~9 us of the ~12 us epilogue of a 256 x 256 tile, profiles/r02_gemm_overhead.log.)
+template <int TN, bool FULL, bool HAS_S>
+struct EpiCols {
+  f32x4 b[TN][4], s[HAS_S ? TN : 1][4];
+  bool has_b;
+  // columns nw0 + tn * 32 + 8 * rg + 4 * h + [0, 4), tn in [0, TN)
+  __device__ __forceinline__ void load(const GemmArgs& a, int nw0, int h) {
+    has_b = a.bias != nullptr;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (n + j < a.N) v[j] += a.bias[n + j];
-    }
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int n = nw0 + tn * 32 + 8 * rg + 4 * h;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sv = {1.f, 1.f, 1.f, 1.f};
+        if (FULL || n + 3 < a.N) {
+          if (has_b) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+          if (HAS_S && a.scale) sv = *reinterpret_cast<const f32x4*>(a.scale + n);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (n + j < a.N) {
+              if (has_b) bv[j] = a.bias[n + j];
+              if (HAS_S && a.scale) sv[j] = a.scale[n + j];
+            }
+        }
+        b[tn][rg] = bv;
+        if constexpr (HAS_S) s[tn][rg] = sv;
+      }
+    // Consume every vector HERE (an empty asm that reads it): the compiler then places its one vmcnt wait right behind the
+    // loads.  Without it, a path that never uses a vector (padding row blocks, empty tails) leaves "load pending" on those
+    // registers in hipcc's bookkeeping, and the K loop - which reuses them for fragments - gets an s_waitcnt vmcnt(0) at
+    // its top that drains the LDS-DMA pipeline every K tile.
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        epi_consume(b[tn][rg]);
+        if constexpr (HAS_S) epi_consume(s[tn][rg]);
+      }
   }
+};
+
+template <int ACT, bool BF16_OUT, bool HAS_S>
+__device__ __forceinline__ f32x4 epi_apply(f32x4 v, f32x4 bv, f32x4 sv, bool has_b) {
+  if (has_b) v += bv;
   if (ACT == ACT_RELU) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -78,15 +120,7 @@ __device__ __forceinline__ f32x4 epi_vals(f32x4 v, const GemmArgs& a, int n) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = BF16_OUT ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
   }
-  if (a.scale) {
-    if (FULL || n + 3 < a.N) {
-      v *= *reinterpret_cast<const f32x4*>(a.scale + n);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (n + j < a.N) v[j] *= a.scale[n + j];
-    }
-  }
+  if constexpr (HAS_S) v *= sv;  // (1.0 where the caller passed no scale)
   return v;
 }
 
@@ -95,41 +129,60 @@ __device__ __forceinline__ f32x4 epi_vals(f32x4 v, const GemmArgs& a, int n) {
 // whole rows: 16 B per lane, 128..384 contiguous bytes per row.  (One wave's LDS operations complete in order.)
 // RES: add a bf16 residual (a.res_bf16, may alias C) to the rows as they leave LDS - the same lane reads and then
 // writes each 16-byte piece, so the in-place update is race free.
-template <int TM, int TN, int ACT, bool FULL, bool RES = false>
+template <int TM, int TN, int ACT, bool FULL, bool RES = false, bool HAS_S = false>
 __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], const GemmArgs& a, bf16_t* Cb, char* ws,
                                                 long mw0, int nw0, int lane, const bf16_t* Rb = nullptr) {
   constexpr int RB = TN * 64;    // staged row: TN*32 bf16
   constexpr int CPR = TN * 4;    // 16-byte chunks per row
+  constexpr int NPC = (32 * CPR) / 64;  // 16-byte pieces per lane per 32-row block
   const int l31 = lane & 31, h = lane >> 5;
+  // HAS_S: a per-column scale (another 32 registers next to the 128 accumulators: the compiler spills).  The model does
+  // not need it - LayerScale is folded into the weights in bf16 mode (model.hip pack_weights) - it is kept for callers of
+  // the operator entry point, only together with the bf16 residual; gemm_launch routes other uses to the generic epilogue.
+  EpiCols<TN, FULL, HAS_S> cols;
+  cols.load(a, nw0, h);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
+    const long mw = mw0 + tm * 32;
+    // bf16 residual rows of this block: issued before the staging pass, consumed after it (same lane, same addresses)
+    uint4 rres[RES ? NPC : 1];
+    if constexpr (RES) {
+#pragma unroll
+      for (int i = 0; i < NPC; ++i) {
+        const int c = lane + 64 * i;
+        const int row = c / CPR, ch = c - row * CPR;
+        const long m = mw + row;
+        const int n = nw0 + ch * 8;
+        rres[i] = make_uint4(0, 0, 0, 0);
+        if (FULL || (m < a.M && n + 8 <= a.N)) rres[i] = *reinterpret_cast<const uint4*>(Rb + m * a.ldr + n);
+      }
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int n = nw0 + tn * 32 + 8 * rg + 4 * h;
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = a.alpha * acc[tn][tm][4 * rg + j];
-        v = epi_vals<ACT, FULL, true>(v, a, n);
+        v = epi_apply<ACT, true, HAS_S>(v, cols.b[tn][rg], cols.s[HAS_S ? tn : 0][rg], cols.has_b);
         uint2 pk;
         pk.x = pack_bf16x2(v[0], v[1]);
         pk.y = pack_bf16x2(v[2], v[3]);
         const int ch = tn * 4 + rg;
         *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ epi_swz<CPR>(l31)) << 4) + 8 * h) = pk;
       }
-    const long mw = mw0 + tm * 32;
 #pragma unroll
-    for (int c = lane; c < 32 * CPR; c += 64) {
+    for (int i = 0; i < NPC; ++i) {
+      const int c = lane + 64 * i;
       const int row = c / CPR, ch = c - row * CPR;
       const long m = mw + row;
       const int n = nw0 + ch * 8;
       uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ epi_swz<CPR>(row)) << 4));
-      if (a.dbg & 1) continue;
       bf16_t* dst = Cb + m * a.ldc + n;
       if constexpr (RES) {
+        epi_consume(rres[i]);  // consumed on every path (see EpiCols::load)
         if (FULL || (m < a.M && n + 8 <= a.N)) {
-          const uint4 r = *reinterpret_cast<const uint4*>(Rb + m * a.ldr + n);
+          const uint4 r = rres[i];
           const unsigned* vp = reinterpret_cast<const unsigned*>(&v);
           const unsigned* rp = reinterpret_cast<const unsigned*>(&r);
           unsigned o[4];
@@ -140,6 +193,7 @@ __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], con
           v = make_uint4(o[0], o[1], o[2], o[3]);
         }
       }
+      if (a.dbg & 1) continue;
       if (FULL) {
         *reinterpret_cast<uint4*>(dst) = v;
       } else {
@@ -170,6 +224,8 @@ __device__ __forceinline__ void epi_staged_qkv(const f32x16 (&acc)[TN][TM], cons
   const int which = nw0 / D;         // wave-uniform: D % (TN*32) == 0
   const int nrel = nw0 - which * D;  // first column of this wave inside q / k / v
   const float sc = which == 0 ? a.qscale : 1.0f;
+  EpiCols<TN, true, false> cols;  // N = 3 * heads * hd is a multiple of the wave's 64 columns: always a full vector
+  cols.load(a, nw0, h);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const long mw = mw0 + tm * 32;
@@ -186,7 +242,7 @@ __device__ __forceinline__ void epi_staged_qkv(const f32x16 (&acc)[TN][TM], cons
           f32x4 v;
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][4 * rg + j];
-          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+          if (cols.has_b) v += cols.b[tn][rg];
           v *= sc;
           uint2 pk;
           pk.x = pack_bf16x2(v[0], v[1]);
@@ -213,7 +269,7 @@ __device__ __forceinline__ void epi_staged_qkv(const f32x16 (&acc)[TN][TM], cons
           f32x4 v;
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][4 * rg + j];
-          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + nw0 + nl);
+          if (cols.has_b) v += cols.b[tn][rg];
           const uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
           unsigned short* col = reinterpret_cast<unsigned short*>(ws + nl * 64 + l31 * 2);  // [d][token]
           col[0] = (unsigned short)(p0 & 0xffffu);
@@ -243,21 +299,37 @@ template <int TM, int TN, int ACT, bool FULL>
 __device__ __forceinline__ void epi_staged_f32(const f32x16 (&acc)[TN][TM], const GemmArgs& a, float* Cb, const float* Rb,
                                                char* ws, long mw0, int nw0, int lane) {
   const int l31 = lane & 31, h = lane >> 5;
+  // one 32-column block at a time (tn outer): its bias / scale vectors are 32 registers, loaded once for all TM row blocks
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
+  for (int tn = 0; tn < TN; ++tn) {
+    EpiCols<1, FULL, true> cols;
+    cols.load(a, nw0 + tn * 32, h);
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
+    for (int tm = 0; tm < TM; ++tm) {
+      const long mw = mw0 + tm * 32;
+      const int nw = nw0 + tn * 32;
+      // the f32 residual pieces of this 32 x 32 block: issued before the staging pass, added after it (the same lane reads
+      // and then writes each piece, so the in-place update C = res + ... stays race free)
+      f32x4 rres[4];
+      if (Rb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = lane + 64 * i;
+          const int row = c >> 3, ch = c & 7;
+          const long m = mw + row;
+          const int n = nw + ch * 4;
+          rres[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (FULL || (m < a.M && n < a.N)) rres[i] = *reinterpret_cast<const f32x4*>(Rb + m * a.ldr + n);
+        }
+      }
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int n = nw0 + tn * 32 + 8 * rg + 4 * h;
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = a.alpha * acc[tn][tm][4 * rg + j];
-        v = epi_vals<ACT, FULL, false>(v, a, n);
+        v = epi_apply<ACT, false, true>(v, cols.b[0][rg], cols.s[0][rg], cols.has_b);
         *reinterpret_cast<f32x4*>(ws + l31 * 128 + (((2 * rg + h) ^ (l31 & 7)) << 4)) = v;
       }
-      const long mw = mw0 + tm * 32;
-      const int nw = nw0 + tn * 32;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i;
@@ -265,8 +337,11 @@ __device__ __forceinline__ void epi_staged_f32(const f32x16 (&acc)[TN][TM], cons
         f32x4 v = *reinterpret_cast<const f32x4*>(ws + row * 128 + ((ch ^ (row & 7)) << 4));
         const long m = mw + row;
         const int n = nw + ch * 4;
+        if (Rb) {
+          epi_consume(rres[i]);  // consumed on every path (see EpiCols::load)
+          v += rres[i];
+        }
         if (!FULL && (m >= a.M || n >= a.N)) continue;
-        if (Rb) v += *reinterpret_cast<const f32x4*>(Rb + m * a.ldr + n);
         if (a.dbg & 1) continue;
         *reinterpret_cast<f32x4*>(Cb + m * a.ldc + n) = v;
       }

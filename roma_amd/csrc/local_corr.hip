@@ -162,9 +162,10 @@ __global__ __launch_bounds__(256) void local_corr_window_kernel(const LocalCorrA
 // tile, data dependent and made on the device; results do not depend on it beyond f32 summation order.
 constexpr int LC_TQ = 8;                 // tile edge (queries)
 constexpr int LC_PITCH = 144;            // bytes per staged pixel: 128 B of channels + 16 B pad (bank spread)
-// f1 pixels the stage can hold (the 64 f0 rows take 64 more slots): r <= 3 -> 73 728 B, two workgroups per CU
-// (a unit-scale warp needs 13^2 / 15^2 pixels, so zoom factors up to ~1.5 still fit); r > 3 -> 110 592 B, one per CU
-// (r = 7: 23^2 = 529 pixels at unit scale)
+// f1 pixels the stage can hold (the 64 f0 rows take 64 more slots): r <= 3 -> 448 pixels = 73 728 B, two workgroups per
+// CU (a unit-scale warp needs 13^2 / 15^2 pixels, so zoom factors up to ~2 (r = 2) / ~1.75 (r = 3) still fit; stronger
+// zooms go to the gather list); r > 3 -> 704 pixels = 110 592 B, one per CU (r = 7: 23^2 = 529 pixels at unit scale).
+// (Three per CU with a 288-pixel stage was tried: 168 VGPRs do not hold the prefetch registers, ~35 spilled.)
 template <int R> struct LcGeom {
   static constexpr int PXMAX = R <= 3 ? 448 : 704;
   static constexpr int NSLOT = PXMAX + LC_TQ * LC_TQ;
@@ -208,7 +209,7 @@ template <> struct LcDot<bf16_t> {  // 64 channels per 128-byte chunk, packed pa
 };
 
 template <int R, typename T, typename TOUT>
-__global__ __launch_bounds__(256, 2) void local_corr_tile_kernel(const LocalCorrArgs a) {
+__global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(const LocalCorrArgs a) {
   constexpr int P = 2 * R + 2, KW = 2 * R + 1, K = KW * KW;
   constexpr int NR = (P + 3) / 4;  // patch rows per wave
   constexpr int CC = LcDot<T>::CC;
@@ -219,21 +220,18 @@ __global__ __launch_bounds__(256, 2) void local_corr_tile_kernel(const LocalCorr
   int* qy0 = qx0 + 64;                                      // [64]
   float* qfx = reinterpret_cast<float*>(qy0 + 64);          // [64]
   float* qfy = qfx + 64;                                    // [64]
-  int* tinfo = reinterpret_cast<int*>(qfy + 64);            // bx0, by0, bw, bh, dequeued list index
+  int* tinfo = reinterpret_cast<int*>(qfy + 64);            // bx0, by0, bw, bh
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (a.W + LC_TQ - 1) / LC_TQ, tiles_y = (a.H + LC_TQ - 1) / LC_TQ;
   const int tpi = tiles_x * tiles_y;
   const long HW = (long)a.H * a.W;
   const int* tlist = a.ws + 4 + a.B * tpi;  // coherent tiles (local_corr_classify_kernel)
-  // persistent workgroups pull tiles from the list (one atomic per tile): a launch sized for the worst case costs
-  // nothing when most tiles went to the gather list
-  for (;;) {
-  __syncthreads();  // previous tile's readers of tinfo / the stage are done
-  if (tid == 0) tinfo[4] = atomicAdd(a.ws + 2, 1);
-  __syncthreads();
-  const int tidx = tinfo[4];
-  if (tidx >= a.ws[1]) break;
+  // One workgroup per listed tile; the launch covers every tile of the call and the surplus workgroups exit at once.
+  // (Persistent workgroups pulling tiles from the list were measured 30 % slower on coherent warps: the two workgroups
+  // of a CU then run their load and compute phases in lock-step instead of drifting apart like short-lived ones do.)
+  for (int tidx = blockIdx.x; tidx < a.ws[1]; tidx += gridDim.x) {
+  __syncthreads();  // previous tile's readers of tinfo / the stage are done (grid-stride repeat only)
   const int tile = tlist[tidx];
   const int b = tile / tpi;
   const int trem = tile - b * tpi;
@@ -294,23 +292,31 @@ __global__ __launch_bounds__(256, 2) void local_corr_tile_kernel(const LocalCorr
   constexpr bool PREFETCH = LcGeom<R>::PREFETCH;
   constexpr int NP = PREFETCH ? NPRE : 1;
   uint4 pre[NP];
-  const char* psrc[NP];  // per-piece source (chunk 0), nullptr = zero fill; advanced by the chunk offset
+  // per-piece source of chunk 0 as a 32-bit byte offset from its image base (one feature map of one image is far below
+  // 4 GB): bit k of `from_f0` selects the base, 0xffffffff = zero fill.  Half the registers of 64-bit pointers.
+  unsigned poff[NP];
+  unsigned from_f0 = 0;
+  const char* f1b = reinterpret_cast<const char*>(f1p);
+  const char* f0b = reinterpret_cast<const char*>(f0p);
 #pragma unroll
   for (int k = 0; k < (PREFETCH ? NPRE : 0); ++k) {
     const int i = tid + 256 * k;
     const int slotp = i >> 3, piece = i & 7;
-    const char* src = nullptr;
+    unsigned off = 0xffffffffu;
     if (slotp < (int)npx) {
       const int py = slotp / bw, px = slotp - py * bw;
-      src = reinterpret_cast<const char*>(f1p + ((long)(by0 + py) * a.W + (bx0 + px)) * a.ld1) + piece * 16;
+      off = (unsigned)((((long)(by0 + py) * a.W + (bx0 + px)) * a.ld1) * (long)sizeof(T) + piece * 16);
     } else if (slotp < nslots) {
       const int q = slotp - (int)npx;
       const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
-      if (gy < a.H && gx < a.W) src = reinterpret_cast<const char*>(f0p + ((long)gy * a.W + gx) * a.ld0) + piece * 16;
+      if (gy < a.H && gx < a.W) {
+        off = (unsigned)((((long)gy * a.W + gx) * a.ld0) * (long)sizeof(T) + piece * 16);
+        from_f0 |= 1u << k;
+      }
     }
-    psrc[k] = src;
+    poff[k] = off;
     pre[k] = make_uint4(0, 0, 0, 0);
-    if (src) pre[k] = *reinterpret_cast<const uint4*>(src);
+    if (off != 0xffffffffu) pre[k] = *reinterpret_cast<const uint4*>(((from_f0 >> k) & 1u ? f0b : f1b) + off);
   }
   for (int c0 = 0; c0 < a.C; c0 += CC) {
     if constexpr (PREFETCH) {
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void local_corr_tile_kernel(const LocalCorr
         const long coff = (long)(c0 + CC) * (long)sizeof(T);
 #pragma unroll
         for (int k = 0; k < NPRE; ++k)
-          if (psrc[k]) pre[k] = *reinterpret_cast<const uint4*>(psrc[k] + coff);
+          if (poff[k] != 0xffffffffu) pre[k] = *reinterpret_cast<const uint4*>(((from_f0 >> k) & 1u ? f0b : f1b) + poff[k] + coff);
       }
     }
     if (qvalid) {
@@ -428,8 +434,9 @@ __global__ __launch_bounds__(256) void local_corr_classify_kernel(const LocalCor
   }
 }
 
-// Per-query gathers for the pixels of the tiles on the gather list: work item = (list entry, round of 4 queries), one
-// query per wave; persistent workgroups pull items with one atomic each.
+// Per-query gathers for the pixels of the tiles on the gather list: persistent workgroups pull one TILE per atomic (a
+// single counter word saturates at ~90 dequeues / us on this chip - one atomic per 4 queries made the dequeue, not the
+// gathers, the bound) and serve its 64 queries in 16 rounds, one query per wave.
 template <int R, typename T, typename TOUT>
 __global__ __launch_bounds__(256) void local_corr_list_kernel(const LocalCorrArgs a) {
   extern __shared__ __attribute__((aligned(16))) float f0s[];  // [4 waves][C] + 1 int
@@ -437,25 +444,29 @@ __global__ __launch_bounds__(256) void local_corr_list_kernel(const LocalCorrArg
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles_x = (a.W + LC_TQ - 1) / LC_TQ, tiles_y = (a.H + LC_TQ - 1) / LC_TQ;
   const int tpi = tiles_x * tiles_y;
-  const int nitems = a.ws[0] * 16;
+  const int nitems = a.ws[0];
   float* myf0 = f0s + wave * a.C;
   for (;;) {
-    __syncthreads();  // previous item's readers of the f0 slices / item_s are done
+    __syncthreads();  // previous item's readers of item_s are done
     if (threadIdx.x == 0) *item_s = atomicAdd(a.ws + 3, 1);
     __syncthreads();
     const int item = *item_s;
     if (item >= nitems) break;
-    const int tile = a.ws[4 + (item >> 4)], rnd = item & 15;
+    const int tile = a.ws[4 + item];
     const int b = tile / tpi;
     const int trem = tile - b * tpi;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-    const int q = rnd * 4 + wave;
-    const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
-    const bool act = gy < a.H && gx < a.W;
-    const long pix = (long)b * a.H * a.W + (long)gy * a.W + gx;
-    lc_gather_stage_f0<R, T, TOUT>(a, pix, act, lane, myf0);
-    __syncthreads();
-    lc_gather_pixel<R, T, TOUT>(a, pix, act, lane, myf0);
+    for (int rnd = 0; rnd < (LC_TQ * LC_TQ) / 4; ++rnd) {
+      const int q = rnd * 4 + wave;
+      const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
+      const bool act = gy < a.H && gx < a.W;
+      const long pix = (long)b * a.H * a.W + (long)gy * a.W + gx;
+      // each wave stages and reads only ITS f0 slice, and a wave's LDS operations complete in order: no block barrier
+      lc_gather_stage_f0<R, T, TOUT>(a, pix, act, lane, myf0);
+      __builtin_amdgcn_wave_barrier();
+      lc_gather_pixel<R, T, TOUT>(a, pix, act, lane, myf0);
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
@@ -539,12 +550,9 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   }
   hipLaunchKernelGGL((local_corr_classify_kernel<R>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
   ROMA_LAUNCH_CHECK();
-  // persistent grids: what the chip can hold (LDS-limited for the tiled form), never more than there is work
-  const int per_cu = (160 * 1024) / (int)lds_tile;
-  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT>), dim3((unsigned)std::min(tiles, 256 * per_cu)), dim3(256), lds_tile,
-                     stream, a);
+  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT>), dim3((unsigned)tiles), dim3(256), lds_tile, stream, a);
   ROMA_LAUNCH_CHECK();
-  hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT>), dim3((unsigned)std::min(tiles * 16, 256 * 8)), dim3(256),
+  hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT>), dim3((unsigned)std::min(tiles, 256 * 8)), dim3(256),
                      (size_t)4 * a.C * sizeof(float) + 16, stream, a);
   ROMA_LAUNCH_CHECK();
   if (own_ws) ROMA_CHECK_HIP(hipFreeAsync(a.ws, stream));

@@ -318,13 +318,32 @@ int Model::pack_weights() {
     if (int rc = upload_f32(H(p + ".norm1.bias"), &o.ln1b)) return rc;
     if (int rc = upload_f32(H(p + ".norm2.weight"), &o.ln2w)) return rc;
     if (int rc = upload_f32(H(p + ".norm2.bias"), &o.ln2b)) return rc;
+    if (int rc = make_lin(H(p + ".attn.qkv.weight"), qkv_bias ? &H(p + ".attn.qkv.bias") : nullptr, 3072, 1024, &o.qkv)) return rc;
+    if (int rc = make_lin(H(p + ".mlp.fc1.weight"), &H(p + ".mlp.fc1.bias"), 4096, 1024, &o.fc1)) return rc;
+    if (ls && act_dt == DT_BF16) {
+      // LayerScale (layers/layer_scale.py:27-28) folded into the branch's last linear: x += g * (W a + b) = (g W) a + g b.
+      // In the throughput mode the product g W is rounded to bf16 once at pack time instead of the branch output being
+      // scaled in f32 before its bf16 rounding - the same 2^-9 class of rounding - and the GEMM epilogue needs no
+      // per-column scale vector (32 registers it does not have next to 128 accumulators).  The exact-f32 mode keeps the
+      // reference's order of operations.
+      auto fold = [&](const std::vector<float>& w, const std::vector<float>& b, const std::vector<float>& g, int N, int K,
+                      Lin* out) -> int {
+        std::vector<float> wf(w), bf(b);
+        for (int n = 0; n < N; ++n) {
+          for (int k = 0; k < K; ++k) wf[(size_t)n * K + k] *= g[n];
+          bf[n] *= g[n];
+        }
+        return make_lin(wf, &bf, N, K, out);
+      };
+      if (int rc = fold(H(p + ".attn.proj.weight"), H(p + ".attn.proj.bias"), H(p + ".ls1.gamma"), 1024, 1024, &o.proj)) return rc;
+      if (int rc = fold(H(p + ".mlp.fc2.weight"), H(p + ".mlp.fc2.bias"), H(p + ".ls2.gamma"), 1024, 4096, &o.fc2)) return rc;
+      return 0;
+    }
     if (ls) {
       if (int rc = upload_f32(H(p + ".ls1.gamma"), &o.ls1)) return rc;
       if (int rc = upload_f32(H(p + ".ls2.gamma"), &o.ls2)) return rc;
     }
-    if (int rc = make_lin(H(p + ".attn.qkv.weight"), qkv_bias ? &H(p + ".attn.qkv.bias") : nullptr, 3072, 1024, &o.qkv)) return rc;
     if (int rc = make_lin(H(p + ".attn.proj.weight"), &H(p + ".attn.proj.bias"), 1024, 1024, &o.proj)) return rc;
-    if (int rc = make_lin(H(p + ".mlp.fc1.weight"), &H(p + ".mlp.fc1.bias"), 4096, 1024, &o.fc1)) return rc;
     if (int rc = make_lin(H(p + ".mlp.fc2.weight"), &H(p + ".mlp.fc2.bias"), 1024, 4096, &o.fc2)) return rc;
     return 0;
   };
@@ -483,6 +502,86 @@ int Model::match(int B, const float* ima, const float* imb, const float* ima_hr,
     ROMA_REQUIRE(ima_hr && imb_hr, "roma_match: upsample_preds requires im_A_high_res and im_B_high_res");
   }
   ROMA_CHECK_HIP(hipSetDevice(cfg.device));
+  static const int env_graph = getenv("ROMA_GRAPH") ? atoi(getenv("ROMA_GRAPH")) : -1;
+  const int gm = env_graph >= 0 ? env_graph : graph_mode;
+  if (gm != 0 && !debug && !prof_enabled()) return match_graph(B, ima, imb, ima_hr, imb_hr, warp, cert, st);
+  return match_streams(B, ima, imb, ima_hr, imb_hr, warp, cert, st);
+}
+
+// ---------------------------------------------------------------- hipGraph replay of the whole schedule
+// match() is ~1 600 launches; at batch 8 the GPU is busy for ~110 ms and the host stays ahead, but a coarse-only single
+// pair is ~10 ms of kernels behind ~10 ms of hipLaunchKernel calls (host launch ~3.5 us each).  The schedule for a
+// given (batch, options) is static - same kernels, same arena addresses - so it is captured once from the caller's stream
+// (second call with that configuration; the first runs eagerly and warms function attributes / side streams) and replayed
+// with one hipGraphLaunch.  Caller buffers change from call to call, so the graph works on persistent staging copies of the
+// images and of the outputs (device-to-device copies on the same stream outside the graph: ~0.1 ms at batch 8).
+Model::GraphSlot::~GraphSlot() {
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
+}
+
+int Model::match_graph(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
+                       float* cert, hipStream_t st) {
+  const size_t im_lo = (size_t)3 * cfg.coarse_h * cfg.coarse_w, im_hi = (size_t)3 * cfg.upsample_h * cfg.upsample_w;
+  const int Ho = cfg.upsample_preds ? cfg.upsample_h : cfg.coarse_h, Wo = cfg.upsample_preds ? cfg.upsample_w : cfg.coarse_w;
+  const size_t px = (size_t)Ho * Wo * (cfg.symmetric ? 2 : 1);
+  if (!io_buf) {  // staging for the largest configuration of this handle
+    const size_t mb = (size_t)cfg.max_batch;
+    const size_t pxmax = (size_t)std::max(cfg.coarse_h * cfg.coarse_w, cfg.upsample_h * cfg.upsample_w) * 2;
+    io_off[0] = 0;
+    io_off[1] = io_off[0] + mb * im_lo;
+    io_off[2] = io_off[1] + mb * im_lo;
+    io_off[3] = io_off[2] + mb * im_hi;
+    io_off[4] = io_off[3] + mb * im_hi;          // warp
+    io_off[5] = io_off[4] + mb * pxmax * 4;      // certainty
+    const size_t total = io_off[5] + mb * pxmax;
+    ROMA_CHECK_HIP(hipMalloc((void**)&io_buf, total * sizeof(float)));
+    owned.push_back(io_buf);
+  }
+  float *s_a = io_buf + io_off[0], *s_b = io_buf + io_off[1], *s_ah = io_buf + io_off[2], *s_bh = io_buf + io_off[3];
+  float *s_w = io_buf + io_off[4], *s_c = io_buf + io_off[5];
+  ROMA_CHECK_HIP(hipMemcpyAsync(s_a, ima, B * im_lo * 4, hipMemcpyDeviceToDevice, st));
+  ROMA_CHECK_HIP(hipMemcpyAsync(s_b, imb, B * im_lo * 4, hipMemcpyDeviceToDevice, st));
+  const bool hr = cfg.upsample_preds != 0;
+  if (hr) {
+    ROMA_CHECK_HIP(hipMemcpyAsync(s_ah, ima_hr, B * im_hi * 4, hipMemcpyDeviceToDevice, st));
+    ROMA_CHECK_HIP(hipMemcpyAsync(s_bh, imb_hr, B * im_hi * 4, hipMemcpyDeviceToDevice, st));
+  }
+  char key[160];
+  snprintf(key, sizeof key, "B%d s%d u%d a%d r%d f%d n%d c%.9g", B, cfg.symmetric, cfg.upsample_preds, cfg.attenuate_cert,
+           (int)vit_bf16_residual, (int)fuse_refiner_blocks, n_streams, coarse_scale_factor);
+  GraphSlot& g = graphs[key];
+  int rc = 0;
+  if (g.exec) {
+    ROMA_CHECK_HIP(hipGraphLaunch(g.exec, st));
+  } else if (!g.warmed) {
+    rc = match_streams(B, s_a, s_b, hr ? s_ah : nullptr, hr ? s_bh : nullptr, s_w, s_c, st);
+    g.warmed = true;
+  } else {
+    ROMA_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    rc = match_streams(B, s_a, s_b, hr ? s_ah : nullptr, hr ? s_bh : nullptr, s_w, s_c, st);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(st, &graph);
+    if (rc == 0 && ce != hipSuccess) {
+      set_error(std::string("roma_match: hipStreamEndCapture: ") + hipGetErrorString(ce));
+      rc = ROMA_ERR_HIP;
+    }
+    if (rc != 0) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    g.graph = graph;
+    ROMA_CHECK_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+    ROMA_CHECK_HIP(hipGraphLaunch(g.exec, st));
+  }
+  if (rc) return rc;
+  ROMA_CHECK_HIP(hipMemcpyAsync(warp, s_w, (size_t)B * px * 4 * 4, hipMemcpyDeviceToDevice, st));
+  ROMA_CHECK_HIP(hipMemcpyAsync(cert, s_c, (size_t)B * px * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int Model::match_streams(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
+                         float* cert, hipStream_t st) {
   static const int env_streams = getenv("ROMA_STREAMS") ? atoi(getenv("ROMA_STREAMS")) : 0;
   static const bool serial_env = getenv("ROMA_STREAMS_SERIAL") && atoi(getenv("ROMA_STREAMS_SERIAL")) != 0;
   const int ns = debug ? 1 : std::min(std::min(env_streams > 0 ? env_streams : n_streams, (int)MAX_STREAMS), B);

@@ -104,6 +104,9 @@ class RegressionMatcher:
         # opt-in: batches of >= 2 pairs as two half-batches on two HIP streams (+5 % at batch 8).  Off by default: in
         # bf16 mode the overlapped sub-batch is not bit-reproducible yet (~1 bf16 ulp in a small patch in 1-5 % of runs)
         self.dual_stream = False
+        # opt-in: replay the kernel schedule of each (batch, options) configuration as a captured hipGraph from its
+        # third call on (one launch instead of ~1 600: matters for small batches, where match() is host-bound)
+        self.graph = False
         self._weights = weights
         self._dinov2_weights = dinov2_weights
         self._handle = None
@@ -231,7 +234,7 @@ class RegressionMatcher:
                              "use one matcher (one handle) per GPU")
         self._ensure_handle(call_hw)
         lib = _lib.load()
-        for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug", "vit_bf16_residual", "dual_stream"):
+        for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug", "vit_bf16_residual", "dual_stream", "graph"):
             _lib.check(lib.roma_set_option(self._handle, k.encode(), int(bool(getattr(self, k)))))
         _lib.check(lib.roma_set_option_f(self._handle, b"coarse_scale_factor", float(scale_factor)))
         B = a.shape[0]

@@ -1,6 +1,7 @@
 """Where does a GEMM tile's time go?  Both bf16 main loops (gemm8p / classic) on model shapes with the tuning bits of
 roma_tuning("gemm_dbg"): 1 = no global stores in the epilogue, 2 = minimal K loop (classic: 1 slab, gemm8p: 2 K tiles),
-256 = no epilogue at all (gemm8p only), 64 = no s_setprio, 128 = no wave-group stagger (gemm8p only).
+256 = no epilogue at all (gemm8p only), 128 = no wave-group stagger (gemm8p only), 512 = LDS-DMA issued in the load block
+instead of between the MFMAs (gemm8p, plain bf16 epilogue only).
 
     t(full) - t(bits 2)        ~ K-loop time        t(bits 2) ~ per-tile overhead (prologue + epilogue + launch)
     t(full) - t(bits 1)        ~ cost of the global stores
@@ -55,7 +56,7 @@ def shape(M, N, K, act=0):
     for kern, mode in (("classic", 0), ("gemm8p", 1)):
         lib.roma_tuning(b"gemm8p", mode)
         r = {}
-        for bits in (0, 1, 2, 3, 64) + ((128, 256, 258) if mode else ()):
+        for bits in (0, 1, 2, 3) + ((128, 256, 258, 512, 512 + 256) if mode else ()):
             lib.roma_tuning(b"gemm_dbg", bits)
             r[f"dbg{bits}_us"] = round(timed(call), 1)
         lib.roma_tuning(b"gemm_dbg", 0)
