@@ -74,6 +74,12 @@ long roma_debug_fetch(roma_handle_t h, const char* name, void* dst_host, long nb
  * f32, b = decoder batch - the output of cls_to_flow_refine (utils/utils.py:300-322), whose arg-max is discontinuous:
  * parity tests of the reduced-precision mode inject the oracle's coarse match and bound everything downstream. */
 int roma_debug_inject(roma_handle_t h, const char* name, const void* src_host, long nbytes);
+/* determinism trace (roma_set_option(h, "trace", 1)): every stage of the following roma_match calls XORs an
+ * order-independent 64-bit checksum of its output into a table, one table per sub-batch stream (slot 0 = the caller's
+ * stream).  Returns the number of entries of the last call (sums_host == NULL: count only); names_host receives the stage
+ * names, newline separated.  tools/stress_streams.py --trace uses it to name the FIRST stage that differs between runs. */
+long roma_debug_trace(roma_handle_t h, int slot, unsigned long long* sums_host, long max_entries, char* names_host,
+                      long names_bytes);
 int roma_destroy(roma_handle_t h);
 /* Per-launch HIP-event timing of the dominant kernels (bench.py roofline pass). roma_profile_report writes a JSON
  * object {kernel: {calls,total_ms,work,unit}} (work = algorithmic FLOPs or bytes); returns bytes needed when buf==NULL. */

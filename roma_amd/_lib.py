@@ -33,6 +33,7 @@ SIGNATURES = {
     "roma_set_option_f": (_i, [_vp, C.c_char_p, C.c_double]),
     "roma_match": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "roma_debug_fetch": (_l, [_vp, C.c_char_p, _vp, _l]),
+    "roma_debug_trace": (_l, [_vp, _i, _vp, _l, C.c_char_p, _l]),
     "roma_debug_inject": (_i, [_vp, C.c_char_p, _vp, _l]),
     "roma_destroy": (_i, [_vp]),
     "roma_tuning": (_i, [C.c_char_p, _i]),

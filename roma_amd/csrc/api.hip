@@ -1,4 +1,5 @@
 // extern "C" boundary of libroma_hip (declarations + reference citations: include/roma_hip.h)
+#include <algorithm>
 #include <mutex>
 #include <map>
 #include <vector>
@@ -90,6 +91,7 @@ int roma_set_option(roma_handle_t h, const char* key, int value) {
   else if (k == "vit_bf16_residual") h->m.vit_bf16_residual = value != 0;
   else if (k == "dual_stream") h->m.n_streams = value != 0 ? 2 : 1;
   else if (k == "graph") h->m.graph_mode = value != 0 ? 1 : 0;
+  else if (k == "trace") h->m.trace_on = value != 0;
   else if (k == "streams") {
     ROMA_REQUIRE(value >= 1 && value <= Model::MAX_STREAMS, "roma_set_option: streams must be 1..4");
     h->m.n_streams = value;
@@ -140,6 +142,28 @@ long roma_debug_fetch(roma_handle_t h, const char* name, void* dst_host, long nb
 int roma_debug_inject(roma_handle_t h, const char* name, const void* src_host, long nbytes) {
   ROMA_REQUIRE(h, "roma_debug_inject: null handle");
   return h->m.debug_inject(name, src_host, nbytes > 0 ? (size_t)nbytes : 0);
+}
+
+long roma_debug_trace(roma_handle_t h, int slot, unsigned long long* sums_host, long max_entries, char* names_host,
+                      long names_bytes) {
+  if (!h || slot < 0 || slot >= Model::MAX_STREAMS_DECL) return ROMA_ERR_ARG;
+  const long n = h->m.trace_n[slot];
+  if (!sums_host) return n;
+  if (max_entries < n || !h->m.trace_dev[slot]) {
+    set_error("roma_debug_trace: destination too small or tracing was never enabled");
+    return ROMA_ERR_ARG;
+  }
+  if (hipDeviceSynchronize() != hipSuccess) return ROMA_ERR_HIP;
+  if (hipMemcpy(sums_host, h->m.trace_dev[slot], (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+    return ROMA_ERR_HIP;
+  if (names_host && names_bytes > 0) {
+    std::string all;
+    for (long i = 0; i < n; ++i) all += h->m.trace_names[slot][(size_t)i] + "\n";
+    const size_t c = std::min<size_t>(all.size(), (size_t)names_bytes - 1);
+    memcpy(names_host, all.data(), c);
+    names_host[c] = 0;
+  }
+  return n;
 }
 
 int roma_destroy(roma_handle_t h) {

@@ -1,6 +1,7 @@
 // HBM-bound kernels of the RoMa match() path for gfx950 (see elementwise.h).
 // Conventions: channels-last activations, 16-byte (or 8-byte for bf16 quads) vector accesses,
 // one wave64 per row for row reductions, f32 math everywhere.
+#include <algorithm>
 #include "elementwise.h"
 #include <stdio.h>
 
@@ -1261,6 +1262,36 @@ int final_epilogue_launch(const FinalArgs& a, hipStream_t s) {
   const long total = (long)a.B * a.H * (a.symmetric ? 2 * a.W : a.W);
   dim3 grid((unsigned)std::min<long>((total + 255) / 256, 65536));
   hipLaunchKernelGGL(final_epilogue_kernel, grid, dim3(256), 0, s, a);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- determinism trace (debug)
+// Order-independent 64-bit checksum of a buffer: XOR over the words of mix(word, index).  Any single changed bit changes
+// the sum; the result does not depend on how threads are scheduled.  Used by Model::trace (option "trace") to find the
+// FIRST stage whose output differs between two runs of the same inputs.
+__global__ __launch_bounds__(256) void checksum_kernel(const uint32_t* p, long nwords, unsigned long long* out) {
+  unsigned long long h = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (long)gridDim.x * 256) {
+    unsigned long long x = ((unsigned long long)p[i] << 32) ^ (unsigned long long)(i * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    h ^= x;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)h, off), hi = __shfl_xor((unsigned)(h >> 32), off);
+    h ^= ((unsigned long long)hi << 32) | lo;
+  }
+  if ((threadIdx.x & 63) == 0 && h) atomicXor(out, h);
+}
+
+int checksum_launch(const void* p, size_t bytes, unsigned long long* out, hipStream_t s) {
+  const long nwords = (long)(bytes / 4);
+  if (nwords <= 0) return 0;
+  const unsigned grid = (unsigned)std::min<long>((nwords + 255) / 256, 1024);
+  hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(256), 0, s, static_cast<const uint32_t*>(p), nwords, out);
   ROMA_LAUNCH_CHECK();
   return 0;
 }

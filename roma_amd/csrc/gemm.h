@@ -51,6 +51,8 @@ struct GemmArgs {
 int gemm_launch(const GemmArgs& a, hipStream_t stream);
 // 8-phase 256 x 256 bf16 kernel (gemm8p.hip): 0 = launched, 1 = not its problem (gemm.hip runs it), < 0 = error
 int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream);
+// its 256 x 192 sibling (gemm6p.hip), called by gemm8p_try_launch once the common preconditions hold
+int gemm6p_try_launch(const GemmArgs& a, hipStream_t stream);
 extern int g_gemm_tuning[2];  // process-wide A/B switches (roma_tuning): [0] use gemm8p (-1 = env ROMA_GEMM8P, default on), [1] dbg bits
 
 }  // namespace roma

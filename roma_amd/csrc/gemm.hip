@@ -69,7 +69,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
   // ---- per-lane DMA descriptors: lane -> (row = 8q + lane/8, slot = lane%8), source chunk = slot ^ swizzle(row)
-  const int r8 = lane >> 3, slot = lane & 7;
   const char* a_src[NA];
   int a_chunk[NA], a_y[NA], a_x[NA];
   const char* w_src[NW];
@@ -80,6 +79,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
   {                                                                                                         \
     d_m0 = ((LTILE) / NT) * BM;                                                                             \
     d_n0 = (int)((LTILE) % NT) * BN;                                                                        \
+    int ln_ = lane;                                                                                         \
+    asm volatile("" : "+v"(ln_)); /* opaque: each setup is computed where it stands (see tile top) */         \
+    const int r8 = ln_ >> 3, slot = ln_ & 7;                                                                \
     _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                        \
       const int row = 8 * (wave * NA + j) + r8;                                                             \
       const int chunk = slot ^ ((row >> 1) & 7);                                                            \
@@ -169,7 +171,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
   ROMA_TILE_SETUP((long)xcd * per_xcd + li);
   ROMA_ISSUE_SLAB(0, 0);
   int bsel = 0;  // LDS buffer holding slab 0 of the current tile
-  for (;;) {
+  for (bool first_tile = true;; first_tile = false) {
+  if constexpr (NWAVES == 8) {
+    // The descriptors of this tile were built (and used for its slab 0) under the last MFMAs of the previous tile; they
+    // are rebuilt here instead of being kept: 4 x (NA + NW) registers live across the epilogue pushed its preloaded
+    // bias / scale / residual columns into scratch (the 256 x 192 tile went from 247 to 335 us on the stride-8 refiner
+    // GEMM).  ~40 integer instructions per tile.
+    if (!first_tile) ROMA_TILE_SETUP((long)xcd * per_xcd + li);
+  }
   const long m0 = d_m0;
   const int n0 = d_n0;
   const long li_next = li + wg_per_xcd;
@@ -313,6 +322,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
   }
 
   // ---------------------------------------------------------------- epilogue
+  // opaque lane id: every lane-dependent address of the epilogue variants is computed HERE, per tile.  With the plain
+  // `lane` hipcc hoists them all (every inlined variant's) to kernel entry and parks ~60 registers in scratch across the
+  // K loop - and reloads some inside it (tools/kernel_resources.py: 169 spilled registers on the 256 x 192 bf16 tile).
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int l31e = lane_e & 31, he = lane_e >> 5;
   TOUT* Cb = reinterpret_cast<TOUT*>(a.C) + (long)bz * a.sC;
   const float* Rb = a.res ? a.res + (long)bz * a.sR : nullptr;
   const bool vecC = ((a.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
       if (a.mode == EPI_QKV && a.qkv_pad && ((a.heads * a.hd) % (TN * 32)) == 0) {
         if constexpr (NWAVES != 8) __builtin_amdgcn_s_barrier();
         epi_staged_qkv<TM, TN>(acc, a, smem + (NWAVES == 8 ? 2 * BUF : 0) + wave * SLICE, m0 + (long)wm * TM * 32,
-                               n0 + wn * TN * 32, lane);
+                               n0 + wn * TN * 32, lane_e);
         if (!has_next) break;
         continue;  // next tile
       }
@@ -345,31 +360,31 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
       if constexpr (sizeof(TOUT) == 2) {
         bf16_t* Cbb = reinterpret_cast<bf16_t*>(Cb);
         if (a.act == ACT_GELU) {
-          if (full_tile) epi_staged_bf16<TM, TN, ACT_GELU, true>(acc, a, Cbb, ws, mw0, nw0, lane);
-          else epi_staged_bf16<TM, TN, ACT_GELU, false>(acc, a, Cbb, ws, mw0, nw0, lane);
+          if (full_tile) epi_staged_bf16<TM, TN, ACT_GELU, true>(acc, a, Cbb, ws, mw0, nw0, lane_e);
+          else epi_staged_bf16<TM, TN, ACT_GELU, false>(acc, a, Cbb, ws, mw0, nw0, lane_e);
         } else if (a.act == ACT_RELU) {
-          if (full_tile) epi_staged_bf16<TM, TN, ACT_RELU, true>(acc, a, Cbb, ws, mw0, nw0, lane);
-          else epi_staged_bf16<TM, TN, ACT_RELU, false>(acc, a, Cbb, ws, mw0, nw0, lane);
+          if (full_tile) epi_staged_bf16<TM, TN, ACT_RELU, true>(acc, a, Cbb, ws, mw0, nw0, lane_e);
+          else epi_staged_bf16<TM, TN, ACT_RELU, false>(acc, a, Cbb, ws, mw0, nw0, lane_e);
         } else if (a.res_bf16) {
           const bf16_t* Rbb = reinterpret_cast<const bf16_t*>(a.res_bf16) + (long)bz * a.sR;
           if (a.scale) {  // operator entry point only (the model folds LayerScale into the weights)
-            epi_staged_bf16<TM, TN, ACT_NONE, false, true, true>(acc, a, Cbb, ws, mw0, nw0, lane, Rbb);
+            epi_staged_bf16<TM, TN, ACT_NONE, false, true, true>(acc, a, Cbb, ws, mw0, nw0, lane_e, Rbb);
           } else {
-            if (full_tile) epi_staged_bf16<TM, TN, ACT_NONE, true, true>(acc, a, Cbb, ws, mw0, nw0, lane, Rbb);
-            else epi_staged_bf16<TM, TN, ACT_NONE, false, true>(acc, a, Cbb, ws, mw0, nw0, lane, Rbb);
+            if (full_tile) epi_staged_bf16<TM, TN, ACT_NONE, true, true>(acc, a, Cbb, ws, mw0, nw0, lane_e, Rbb);
+            else epi_staged_bf16<TM, TN, ACT_NONE, false, true>(acc, a, Cbb, ws, mw0, nw0, lane_e, Rbb);
           }
         } else {
-          if (full_tile) epi_staged_bf16<TM, TN, ACT_NONE, true>(acc, a, Cbb, ws, mw0, nw0, lane);
-          else epi_staged_bf16<TM, TN, ACT_NONE, false>(acc, a, Cbb, ws, mw0, nw0, lane);
+          if (full_tile) epi_staged_bf16<TM, TN, ACT_NONE, true>(acc, a, Cbb, ws, mw0, nw0, lane_e);
+          else epi_staged_bf16<TM, TN, ACT_NONE, false>(acc, a, Cbb, ws, mw0, nw0, lane_e);
         }
       } else {
         float* Cbf = reinterpret_cast<float*>(Cb);
         if (a.act == ACT_RELU) {
-          if (full_tile) epi_staged_f32<TM, TN, ACT_RELU, true>(acc, a, Cbf, Rb, ws, mw0, nw0, lane);
-          else epi_staged_f32<TM, TN, ACT_RELU, false>(acc, a, Cbf, Rb, ws, mw0, nw0, lane);
+          if (full_tile) epi_staged_f32<TM, TN, ACT_RELU, true>(acc, a, Cbf, Rb, ws, mw0, nw0, lane_e);
+          else epi_staged_f32<TM, TN, ACT_RELU, false>(acc, a, Cbf, Rb, ws, mw0, nw0, lane_e);
         } else {
-          if (full_tile) epi_staged_f32<TM, TN, ACT_NONE, true>(acc, a, Cbf, Rb, ws, mw0, nw0, lane);
-          else epi_staged_f32<TM, TN, ACT_NONE, false>(acc, a, Cbf, Rb, ws, mw0, nw0, lane);
+          if (full_tile) epi_staged_f32<TM, TN, ACT_NONE, true>(acc, a, Cbf, Rb, ws, mw0, nw0, lane_e);
+          else epi_staged_f32<TM, TN, ACT_NONE, false>(acc, a, Cbf, Rb, ws, mw0, nw0, lane_e);
         }
       }
       if (!has_next) break;
@@ -379,7 +394,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
 
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
-    const long m = m0 + (wm * TM + tm) * 32 + l31;
+    const long m = m0 + (wm * TM + tm) * 32 + l31e;
     if (m >= a.M) continue;
     float nxm = 0.f;
     if (a.mode == EPI_COSK) nxm = a.nx[(long)bz * a.sNx + m];
@@ -394,7 +409,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
     for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int n = n0 + (wn * TN + tn) * 32 + 8 * rg + 4 * h;
+        const int n = n0 + (wn * TN + tn) * 32 + 8 * rg + 4 * he;
         const int nvalid = a.N - n;
         if (nvalid <= 0) continue;
         f32x4 v;

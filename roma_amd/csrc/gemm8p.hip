@@ -219,10 +219,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
       acc[NH][(MH) * 2 + mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, BF[G]),    \
                                                                        __builtin_bit_cast(bf16x8_t, af[mt][G]), \
                                                                        acc[NH][(MH) * 2 + mt], 0, 0, 0);
-  // DMAMF phase: the two LDS-DMA pieces of the phase are issued BETWEEN the MFMAs (after the 2nd and the 4th of 8): an
-  // LDS-DMA instruction costs the issuing wave ~100-180 cycles in a block that also carries the fragment reads but ~60
-  // among bare MFMAs (MI355X_MICROARCH.md), and there its issue time hides under the matrix pipe instead of stretching
-  // the load block the partner group's MFMAs have to cover.
+  // DMAMF phase (experiment, off by default): the two LDS-DMA pieces of the phase are issued BETWEEN the MFMAs (after the
+  // 2nd and the 4th of 8) instead of in the load block.  The idea: an LDS-DMA instruction costs the issuing wave ~100-180
+  // cycles in a block that also carries the fragment reads but ~60 among bare MFMAs (MI355X_MICROARCH.md).  Measured: no
+  // gain at K = 1024 and a loss at long K / on the convolution - the matrix pipe is better off with an uninterrupted
+  // 8-MFMA burst than with a shorter partner load block.
 #define R8_PHASE_DM(WAIT, MH, NH, BF, ISS0, ISS1) \
   __builtin_amdgcn_sched_barrier(0);             \
   __builtin_amdgcn_s_barrier();                  \
@@ -263,6 +264,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
   const int step_m = (int)(wg_per_xcd / NT), step_n = (int)(wg_per_xcd % NT);
 
   // ---- prologue: K tile 0 complete, A0 / W0 of K tile 1 under way (nk >= 2 is guaranteed by the dispatcher)
+  if ((a.dbg & 16) && ((blockIdx.x >> 3) & 1) && nblk > gridDim.x) {
+    // experiment (dbg 16): persistent equal-sized tiles keep all CUs in lock-step - every epilogue of a round hits HBM in
+    // one 25-32 MB store burst while no MFMA runs.  Start every other workgroup half a tile late so that one half of the
+    // chip stores while the other half multiplies.
+    const long t0 = __builtin_readcyclecounter();
+    const long wait = (long)nk * 1900;
+    while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
   R8_TILE_SETUP(c_tm, c_tn)
   R8_ISSUE_A(0, 0, 0) R8_ISSUE_W(0, 0, 0) R8_ISSUE_W(1, 0, 0) R8_ISSUE_A(1, 0, 0)
   R8_ISSUE_A(0, 1, 1) R8_ISSUE_W(0, 1, 1)
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
 #undef R8_TILE_SETUP
 }
 
-template <typename TOUT, bool CONV, int EPI, bool DMAMF = true>
+template <typename TOUT, bool CONV, int EPI, bool DMAMF = false>
 static int launch8p(const GemmArgs& a, hipStream_t stream, const char* epi_name) {
   constexpr int BM = 256, BN = 256;
   const long nblk = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
@@ -458,6 +467,7 @@ int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
   if (a.N >= 384) {
     const long w256 = ((a.N + 255) / 256) * 256, w192 = ((a.N + 191) / 192) * 192;
     tile256 = !(w192 < w256);
+    if (!tile256) return gemm6p_try_launch(a, stream);  // 256 x 192 tiles (gemm6p.hip)
   } else if (a.N > 192 && a.N <= 256) {
     tile256 = true;
   }
@@ -480,7 +490,9 @@ int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
     }
     if (a.act == ACT_GELU) return launch8p<bf16_t, false, E8_GELU>(a, stream, "gelu");
     if (a.act == ACT_RELU) return launch8p<bf16_t, false, E8_RELU>(a, stream, "relu");
-    if (a.dbg & 512) return launch8p<bf16_t, false, E8_NONE, false>(a, stream, "none");  // A/B: DMA issued in the load block
+    // A/B switch: LDS-DMA issued between the MFMAs instead of in the load block.  Measured (profiles/r02_gemm_overhead.log):
+    // neutral at K = 1024, -4 % at K = 4096, -15 % on the 3x3 convolution (its per-piece select sits between the MFMAs)
+    if (a.dbg & 512) return launch8p<bf16_t, false, E8_NONE, true>(a, stream, "none");
     return launch8p<bf16_t, false, E8_NONE>(a, stream, "none");
   }
   if (a.out_dt == DT_F32) {

@@ -141,22 +141,26 @@ __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], con
   // the operator entry point, only together with the bf16 residual; gemm_launch routes other uses to the generic epilogue.
   EpiCols<TN, FULL, HAS_S> cols;
   cols.load(a, nw0, h);
+  // bf16 residual rows in a rolling buffer: piece i of block tm + 1 is requested the moment piece i of block tm has been
+  // consumed, so a request has the rest of the row pass plus the next staging pass to come back from L2 / HBM (a second
+  // buffer would cost 16-24 registers next to the accumulators: it spilled).  The lane that reads a 16-byte piece is the
+  // lane that later writes it, and blocks are disjoint rows: in-place is race free.
+  uint4 rres[RES ? NPC : 1];
+  auto load_res = [&](int tm, int i) {
+    const int c = lane + 64 * i;
+    const int row = c / CPR, ch = c - row * CPR;
+    const long m = mw0 + tm * 32 + row;
+    const int n = nw0 + ch * 8;
+    rres[i] = make_uint4(0, 0, 0, 0);
+    if (FULL || (m < a.M && n + 8 <= a.N)) rres[i] = *reinterpret_cast<const uint4*>(Rb + m * a.ldr + n);
+  };
+  if constexpr (RES) {
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) load_res(0, i);
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const long mw = mw0 + tm * 32;
-    // bf16 residual rows of this block: issued before the staging pass, consumed after it (same lane, same addresses)
-    uint4 rres[RES ? NPC : 1];
-    if constexpr (RES) {
-#pragma unroll
-      for (int i = 0; i < NPC; ++i) {
-        const int c = lane + 64 * i;
-        const int row = c / CPR, ch = c - row * CPR;
-        const long m = mw + row;
-        const int n = nw0 + ch * 8;
-        rres[i] = make_uint4(0, 0, 0, 0);
-        if (FULL || (m < a.M && n + 8 <= a.N)) rres[i] = *reinterpret_cast<const uint4*>(Rb + m * a.ldr + n);
-      }
-    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -192,6 +196,7 @@ __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], con
                                __uint_as_float(vp[j] & 0xffff0000u) + __uint_as_float(rp[j] & 0xffff0000u));
           v = make_uint4(o[0], o[1], o[2], o[3]);
         }
+        if (tm + 1 < TM) load_res(tm + 1, i);  // the register is free again: request the same piece of the next block
       }
       if (a.dbg & 1) continue;
       if (FULL) {

@@ -434,40 +434,30 @@ __global__ __launch_bounds__(256) void local_corr_classify_kernel(const LocalCor
   }
 }
 
-// Per-query gathers for the pixels of the tiles on the gather list: persistent workgroups pull one TILE per atomic (a
-// single counter word saturates at ~90 dequeues / us on this chip - one atomic per 4 queries made the dequeue, not the
-// gathers, the bound) and serve its 64 queries in 16 rounds, one query per wave.
+// Per-query gathers for the pixels of the tiles on the gather list: block = (list entry, round of 4 queries), one query per
+// wave.  The launch covers every tile of the call; blocks beyond the list exit at once.  (Persistent workgroups pulling
+// work with atomics were measured 1.6x slower: a single counter word saturates at ~90 dequeues / us, and pulling whole
+// tiles instead serialises 16 latency-bound rounds per workgroup.)
 template <int R, typename T, typename TOUT>
 __global__ __launch_bounds__(256) void local_corr_list_kernel(const LocalCorrArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float f0s[];  // [4 waves][C] + 1 int
-  int* item_s = reinterpret_cast<int*>(f0s + 4 * a.C);
+  extern __shared__ __attribute__((aligned(16))) float f0s[];  // [4 waves][C]
+  const int li = blockIdx.x >> 4, rnd = blockIdx.x & 15;
+  if (li >= a.ws[0]) return;
+  const int tile = a.ws[4 + li];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles_x = (a.W + LC_TQ - 1) / LC_TQ, tiles_y = (a.H + LC_TQ - 1) / LC_TQ;
   const int tpi = tiles_x * tiles_y;
-  const int nitems = a.ws[0];
+  const int b = tile / tpi;
+  const int trem = tile - b * tpi;
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int q = rnd * 4 + wave;
+  const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
+  const bool act = gy < a.H && gx < a.W;
+  const long pix = (long)b * a.H * a.W + (long)gy * a.W + gx;
   float* myf0 = f0s + wave * a.C;
-  for (;;) {
-    __syncthreads();  // previous item's readers of item_s are done
-    if (threadIdx.x == 0) *item_s = atomicAdd(a.ws + 3, 1);
-    __syncthreads();
-    const int item = *item_s;
-    if (item >= nitems) break;
-    const int tile = a.ws[4 + item];
-    const int b = tile / tpi;
-    const int trem = tile - b * tpi;
-    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-    for (int rnd = 0; rnd < (LC_TQ * LC_TQ) / 4; ++rnd) {
-      const int q = rnd * 4 + wave;
-      const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
-      const bool act = gy < a.H && gx < a.W;
-      const long pix = (long)b * a.H * a.W + (long)gy * a.W + gx;
-      // each wave stages and reads only ITS f0 slice, and a wave's LDS operations complete in order: no block barrier
-      lc_gather_stage_f0<R, T, TOUT>(a, pix, act, lane, myf0);
-      __builtin_amdgcn_wave_barrier();
-      lc_gather_pixel<R, T, TOUT>(a, pix, act, lane, myf0);
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
+  lc_gather_stage_f0<R, T, TOUT>(a, pix, act, lane, myf0);
+  __syncthreads();
+  lc_gather_pixel<R, T, TOUT>(a, pix, act, lane, myf0);
 }
 
 // General per-tap form: warp[B,HW,K,2] arbitrary coordinates (plugin signature).
@@ -552,8 +542,8 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   ROMA_LAUNCH_CHECK();
   hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT>), dim3((unsigned)tiles), dim3(256), lds_tile, stream, a);
   ROMA_LAUNCH_CHECK();
-  hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT>), dim3((unsigned)std::min(tiles, 256 * 8)), dim3(256),
-                     (size_t)4 * a.C * sizeof(float) + 16, stream, a);
+  hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
+                     stream, a);
   ROMA_LAUNCH_CHECK();
   if (own_ws) ROMA_CHECK_HIP(hipFreeAsync(a.ws, stream));
   return 0;

@@ -60,6 +60,7 @@ class Arena {
 
 class Model {
  public:
+  static constexpr int MAX_STREAMS_DECL = 4;
   roma_config_t cfg{};
   int act_dt = 0;  // DT_F32 / DT_BF16
   bool finalized = false;
@@ -69,6 +70,12 @@ class Model {
   // input are cast to amp_dtype); the decoder transformer keeps f32 (autocast leaves its residual f32).  Option
   // "vit_bf16_residual"; env ROMA_VIT_RES_F32=1 forces the f32 stream for A/B runs.
   bool vit_bf16_residual = true;
+  // option "trace": every stage of match() XORs a checksum of its output into a per-stream table (roma_debug_trace)
+  bool trace_on = false;
+  static constexpr int TRACE_MAX = 1024;
+  unsigned long long* trace_dev[MAX_STREAMS_DECL] = {nullptr};
+  std::vector<std::string> trace_names[MAX_STREAMS_DECL];
+  int trace_n[MAX_STREAMS_DECL] = {0};
   int graph_mode = 0;  // option "graph": replay match() as a captured hipGraph (model.hip match_graph)
   double coarse_scale_factor = 0.0;  // roma_set_option_f; 0 = sqrt(coarse_h * coarse_w / 560^2)
   std::map<std::string, HostTensor> host;
@@ -109,6 +116,8 @@ class Model {
     ~GraphSlot();
   };
   std::map<std::string, GraphSlot> graphs;  // one per (batch, options)
+  hipStream_t g_stream = nullptr;           // capture / replay stream (the caller's may be the un-capturable legacy stream)
+  hipEvent_t g_ev_in = nullptr, g_ev_out = nullptr;
   float* io_buf = nullptr;                  // staging copies of the images / outputs the graphs work on
   size_t io_off[6] = {0};
   std::vector<void*> owned;  // device allocations to free

@@ -31,6 +31,10 @@ Model::~Model() {
     if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
   }
   if (ev_fork) (void)hipEventDestroy(ev_fork);
+  graphs.clear();
+  if (g_stream) (void)hipStreamDestroy(g_stream);
+  if (g_ev_in) (void)hipEventDestroy(g_ev_in);
+  if (g_ev_out) (void)hipEventDestroy(g_ev_out);
   for (void* p : owned) (void)hipFree(p);
   for (auto& kv : dbg) (void)hipFree(kv.second.first);
   for (auto& kv : inject) (void)hipFree(kv.second.first);
@@ -514,7 +518,9 @@ int Model::match(int B, const float* ima, const float* imb, const float* ima_hr,
 // given (batch, options) is static - same kernels, same arena addresses - so it is captured once from the caller's stream
 // (second call with that configuration; the first runs eagerly and warms function attributes / side streams) and replayed
 // with one hipGraphLaunch.  Caller buffers change from call to call, so the graph works on persistent staging copies of the
-// images and of the outputs (device-to-device copies on the same stream outside the graph: ~0.1 ms at batch 8).
+// images and of the outputs (device-to-device copies on the caller's stream outside the graph: ~0.1 ms at batch 8).
+// Capture and replay run on a stream of the handle's own, fenced against the caller's stream with two events: the
+// caller's stream may be the legacy default stream (torch's default), which cannot be captured.
 Model::GraphSlot::~GraphSlot() {
   if (exec) (void)hipGraphExecDestroy(exec);
   if (graph) (void)hipGraphDestroy(graph);
@@ -551,17 +557,24 @@ int Model::match_graph(int B, const float* ima, const float* imb, const float* i
   snprintf(key, sizeof key, "B%d s%d u%d a%d r%d f%d n%d c%.9g", B, cfg.symmetric, cfg.upsample_preds, cfg.attenuate_cert,
            (int)vit_bf16_residual, (int)fuse_refiner_blocks, n_streams, coarse_scale_factor);
   GraphSlot& g = graphs[key];
+  if (!g_stream) {
+    ROMA_CHECK_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    ROMA_CHECK_HIP(hipEventCreateWithFlags(&g_ev_in, hipEventDisableTiming));
+    ROMA_CHECK_HIP(hipEventCreateWithFlags(&g_ev_out, hipEventDisableTiming));
+  }
+  ROMA_CHECK_HIP(hipEventRecord(g_ev_in, st));
+  ROMA_CHECK_HIP(hipStreamWaitEvent(g_stream, g_ev_in, 0));
   int rc = 0;
   if (g.exec) {
-    ROMA_CHECK_HIP(hipGraphLaunch(g.exec, st));
+    ROMA_CHECK_HIP(hipGraphLaunch(g.exec, g_stream));
   } else if (!g.warmed) {
-    rc = match_streams(B, s_a, s_b, hr ? s_ah : nullptr, hr ? s_bh : nullptr, s_w, s_c, st);
+    rc = match_streams(B, s_a, s_b, hr ? s_ah : nullptr, hr ? s_bh : nullptr, s_w, s_c, g_stream);
     g.warmed = true;
   } else {
-    ROMA_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-    rc = match_streams(B, s_a, s_b, hr ? s_ah : nullptr, hr ? s_bh : nullptr, s_w, s_c, st);
+    ROMA_CHECK_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeRelaxed));
+    rc = match_streams(B, s_a, s_b, hr ? s_ah : nullptr, hr ? s_bh : nullptr, s_w, s_c, g_stream);
     hipGraph_t graph = nullptr;
-    const hipError_t ce = hipStreamEndCapture(st, &graph);
+    const hipError_t ce = hipStreamEndCapture(g_stream, &graph);
     if (rc == 0 && ce != hipSuccess) {
       set_error(std::string("roma_match: hipStreamEndCapture: ") + hipGetErrorString(ce));
       rc = ROMA_ERR_HIP;
@@ -572,9 +585,11 @@ int Model::match_graph(int B, const float* ima, const float* imb, const float* i
     }
     g.graph = graph;
     ROMA_CHECK_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
-    ROMA_CHECK_HIP(hipGraphLaunch(g.exec, st));
+    ROMA_CHECK_HIP(hipGraphLaunch(g.exec, g_stream));
   }
   if (rc) return rc;
+  ROMA_CHECK_HIP(hipEventRecord(g_ev_out, g_stream));
+  ROMA_CHECK_HIP(hipStreamWaitEvent(st, g_ev_out, 0));
   ROMA_CHECK_HIP(hipMemcpyAsync(warp, s_w, (size_t)B * px * 4 * 4, hipMemcpyDeviceToDevice, st));
   ROMA_CHECK_HIP(hipMemcpyAsync(cert, s_c, (size_t)B * px * 4, hipMemcpyDeviceToDevice, st));
   return 0;
@@ -773,6 +788,25 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
   arena.reset();
   persist.reset();
   auto AL = [&](size_t elems, size_t es) { return arena.alloc(elems * es); };
+  // determinism trace: checksum of a stage's output, XORed into this sub-batch stream's table
+  const int tslot = (&arena == &this->arena) ? 0 : (int)(&arena - side_arena) + 1;
+  const bool tracing = trace_on && !dry;
+  if (tracing) {
+    if (!trace_dev[tslot]) {
+      ROMA_CHECK_HIP(hipMalloc((void**)&trace_dev[tslot], TRACE_MAX * sizeof(unsigned long long)));
+      owned.push_back(trace_dev[tslot]);
+    }
+    ROMA_CHECK_HIP(hipMemsetAsync(trace_dev[tslot], 0, TRACE_MAX * sizeof(unsigned long long), st));
+    trace_n[tslot] = 0;
+  }
+  auto CK = [&](const std::string& name, const void* p, size_t bytes) -> int {
+    if (!tracing) return 0;
+    const int k = trace_n[tslot]++;
+    if (k >= TRACE_MAX) return 0;
+    if ((int)trace_names[tslot].size() <= k) trace_names[tslot].push_back(name);
+    else trace_names[tslot][k] = name;
+    return checksum_launch(p, bytes, trace_dev[tslot] + k, st);
+  };
   auto off = [&](void* p, long elems) -> void* { return static_cast<char*>(p) + elems * (long)esz; };
 
   // ---- persistent, zero-initialised attention workspaces (pads must stay finite)
@@ -893,6 +927,8 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       if (int rc = conv(11, t0, feat[3], H / 8, W / 8)) return rc;
       arena.release(enc_mark);
     }
+    for (int l = 0; l < 4; ++l)
+      if (int rc = CK((up ? "p2_feat" : "p1_feat") + std::to_string(1 << l), feat[l], (size_t)nimg * fh[l] * fw[l] * fc[l] * esz)) return rc;
     if (debug && !dry && !up) {
       for (int l = 0; l < 4; ++l) {
         const std::string nm = "feat" + std::to_string(1 << l);
@@ -936,6 +972,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       for (int i = 0; i < nimg; ++i)  // drop the cls token: x_norm_patchtokens
         RUN(copy2d_launch(off(ln, ((long)i * Nd + 1) * 1024), 1024, act_dt, off(feat[4], (long)i * T * 1024), 1024, act_dt, T, 1024, st));
       arena.release(dmark);
+      if (int rc = CK("feat16", feat[4], (size_t)nimg * T * 1024 * esz)) return rc;
       if (debug && !dry)
         if (int rc = dbg_save("feat16", feat[4], (size_t)nimg * T * 1024 * esz, st)) return rc;
     }
@@ -970,6 +1007,8 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         g.M = (int)(nimg * hw); g.N = r.Cf; g.K = PROJ_CIN[si]; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = proj[si].b;
         RUN(gemm_launch(g, st));
       }
+      const std::string tp = std::string(up ? "p2_s" : "p1_s") + SCALES[si];
+      if (int rc = CK(tp + "_proj", pf, (size_t)nimg * hw * ldf * esz)) return rc;
       if (ins == 16) {
         if (debug && !dry)
           if (int rc = dbg_save("proj16", pf, (size_t)nimg * hw * ldf * esz, st)) return rc;
@@ -1000,7 +1039,10 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         }
         if (debug && !dry)
           if (int rc = dbg_save("logits16", logits, (size_t)rows_t * ldl * 4, st)) return rc;
+        if (int rc = CK(tp + "_tokens_gp", tokens, (size_t)rows_t * 1024 * 4)) return rc;
+        if (int rc = CK(tp + "_logits", logits, (size_t)rows_t * ldl * 4)) return rc;
         RUN(cls_to_flow_launch(logits, ldl, flow, cert, rows_t, st));
+        if (int rc = CK(tp + "_gm_flow", flow, (size_t)rows_t * 2 * 4)) return rc;
         ch = th; cw = tw;
         if (debug && !dry) {  // tests: the computed coarse match first (so the flips can be counted), then the override
           if (int rc = dbg_save("gm_flow16_own", flow, (size_t)rows_t * 2 * 4, st)) return rc;
@@ -1046,22 +1088,28 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
             if (int rc = dbg_save(nm.c_str(), d0, (size_t)M * r.Cp * esz, st)) return rc;
         }
         void *dcur = d0, *dalt = d1;
+        if (int rc = CK(tp + "_din", d0, (size_t)M * r.Cp * esz)) return rc;
         const bool fused = fuse_refiner_blocks && refiner_block_supported(r.Cp, act_dt);
         for (int b = 0; b < 9; ++b) {
           if (fused) {  // narrow scales: dw5x5 + 1x1 in one pass over HBM (refiner_block.hip)
             RUN(refiner_block_launch(dcur, dalt, r.dw_w[b], r.dw_b[b], r.pw[b].w, r.pw[b].ldw, r.pw[b].b, ndp, hs, ws,
                                      r.Cp, act_dt, st));
             std::swap(dcur, dalt);
+            if (int rc = CK(tp + "_blk" + std::to_string(b), dcur, (size_t)M * r.Cp * esz)) return rc;
             continue;
           }
           RUN(dwconv5x5_launch(dcur, dalt, r.dw_w[b], r.dw_b[b], ndp, hs, ws, r.Cp, act_dt, st));
+          if (int rc = CK(tp + "_dw" + std::to_string(b), dalt, (size_t)M * r.Cp * esz)) return rc;
           GemmArgs g;
           g.A = dalt; g.lda = r.Cp; g.W = r.pw[b].w; g.ldw = r.pw[b].ldw; g.C = dcur; g.ldc = r.Cp;
           g.M = (int)M; g.N = r.Cp; g.K = r.Cp; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = r.pw[b].b;
           RUN(gemm_launch(g, st));
+          if (int rc = CK(tp + "_blk" + std::to_string(b), dcur, (size_t)M * r.Cp * esz)) return rc;
         }
         const float sx = (float)ins / (4.0f * (float)W), sy = (float)ins / (4.0f * (float)H);
         RUN(refiner_out_launch(dcur, r.Cp, act_dt, r.out_w, r.out_b, flow, cert, M, r.Cp, sx, sy, st));
+        if (int rc = CK(tp + "_flow", flow, (size_t)M * 2 * 4)) return rc;
+        if (int rc = CK(tp + "_cert", cert, (size_t)M * 4)) return rc;
       }
       if (debug && !dry) {
         const std::string pfx = std::string("p") + (up ? "2" : "1");
@@ -1077,6 +1125,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         RUN(resize_bilinear_launch(cert, cert_alt, ndp, hs, ws, nh, nw, 1, st));
         std::swap(flow, flow_alt);
         std::swap(cert, cert_alt);
+        if (int rc = CK(tp + "_flow_up", flow, (size_t)ndp * nh * nw * 2 * 4)) return rc;
         ch = nh; cw = nw;
       }
     }
@@ -1098,6 +1147,8 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
   fa.warp = warp_out; fa.certainty = cert_out;
   fa.B = B; fa.H = Hfin; fa.W = Wfin; fa.h16 = th; fa.w16 = tw; fa.symmetric = cfg.symmetric;
   RUN(final_epilogue_launch(fa, st));
+  if (int rc = CK("final_warp", warp_out, (size_t)B * Hfin * Wfin * (cfg.symmetric ? 2 : 1) * 4 * 4)) return rc;
+  if (int rc = CK("final_cert", cert_out, (size_t)B * Hfin * Wfin * (cfg.symmetric ? 2 : 1) * 4)) return rc;
   return 0;
 }
 

@@ -107,6 +107,7 @@ class RegressionMatcher:
         # opt-in: replay the kernel schedule of each (batch, options) configuration as a captured hipGraph from its
         # third call on (one launch instead of ~1 600: matters for small batches, where match() is host-bound)
         self.graph = False
+        self.trace = False  # tests / tools only: per-stage output checksums (debug_trace)
         self._weights = weights
         self._dinov2_weights = dinov2_weights
         self._handle = None
@@ -234,7 +235,7 @@ class RegressionMatcher:
                              "use one matcher (one handle) per GPU")
         self._ensure_handle(call_hw)
         lib = _lib.load()
-        for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug", "vit_bf16_residual", "dual_stream", "graph"):
+        for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug", "vit_bf16_residual", "dual_stream", "graph", "trace"):
             _lib.check(lib.roma_set_option(self._handle, k.encode(), int(bool(getattr(self, k)))))
         _lib.check(lib.roma_set_option_f(self._handle, b"coarse_scale_factor", float(scale_factor)))
         B = a.shape[0]
@@ -265,6 +266,19 @@ class RegressionMatcher:
         if got < 0:
             raise _lib.RomaHipError(_lib.last_error())
         return buf
+
+    def debug_trace(self, slot: int = 0):
+        """(names, uint64 checksums) of the stages of the last match() on sub-batch stream `slot` (needs `self.trace`)."""
+        lib = _lib.load()
+        n = lib.roma_debug_trace(self._handle, slot, None, 0, None, 0)
+        if n <= 0:
+            return [], np.zeros(0, dtype=np.uint64)
+        sums = np.zeros(n, dtype=np.uint64)
+        names = C.create_string_buffer(64 * n + 16)
+        got = lib.roma_debug_trace(self._handle, slot, C.c_void_p(sums.ctypes.data), n, names, len(names))
+        if got < 0:
+            raise _lib.RomaHipError(_lib.last_error())
+        return names.value.decode().split("\n")[:n], sums
 
     def debug_inject(self, name: str, value: Optional[np.ndarray]):
         """Tests only (needs `self.debug`): override the named intermediate ("gm_flow16" [b,T,2], "gm_cert16" [b,T]) of

@@ -186,6 +186,12 @@ def test_conv3x3_implicit_gemm(lib, dt, B, H, W, Cin, Cout):
     (25600, 1408, 1408, 1, False),   # stride-16 refiner 1x1: half-empty last n-tile (1408 = 5.5 x 256), ReLU
     (16384, 1024, 512, 0, True),     # f32 output
     (70000, 512, 320, 0, False),     # many tiles per persistent workgroup, K = 5 tiles
+    # the 256 x 192 sibling (gemm6p.hip): 3 phases per K tile, 96-column wave tiles
+    (78400, 1152, 1152, 0, False),   # stride-8 refiner 1x1: 6 n-tiles, ragged last m-tile (78400 = 306.25 x 256), ~6 tiles per workgroup
+    (9000, 576, 576, 1, False),      # stride-4 refiner width, 3 n-tiles, ragged m, ReLU, fewer tiles than workgroups
+    (8200, 1096, 256, 0, False),     # ragged last n-tile (1096 = 5 x 192 + 136) and 8 rows in the last m-tile, shortest K
+    (16384, 576, 512, 0, True),      # f32 output
+    (100000, 384, 320, 1, False),    # many tiles per persistent workgroup, K = 5 tiles (odd: both LDS buffers start a tile)
 ])
 def test_gemm8p_matches_classic_and_reference(lib, M, N, K, act, out_f32):
     """Both main loops accumulate in the same k order, so the 8-phase kernel must reproduce the classic kernel BIT FOR

@@ -201,6 +201,11 @@ if __name__ == "__main__":
         dense(8192, 4096, 4096)                     # square-ish probe (guide's 4096-class reference point)
         dense(25616 - 16, 1024, 1024)               # exactly 100 m-tiles
         dense(300, 1024, 1024)                      # stays on the classic kernel (small M): sanity of the dispatcher
+    if which in ("all", "n192"):                    # the 256 x 192 sibling (gemm6p.hip): ConvRefiner 1x1 convolutions
+        dense(78400, 1152, 1152)                    # stride 8, 560 pass
+        dense(186624, 1152, 1152)                   # stride 8, 864 pass
+        dense(313600, 576, 576)                     # stride 4, 560 pass
+        dense(746496, 576, 576)                     # stride 4, 864 pass
     if which in ("all", "epi"):
         res_bf16(25616, 1024, 1024)
         res_bf16(25616, 1024, 4096)

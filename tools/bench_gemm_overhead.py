@@ -1,7 +1,8 @@
 """Where does a GEMM tile's time go?  Both bf16 main loops (gemm8p / classic) on model shapes with the tuning bits of
 roma_tuning("gemm_dbg"): 1 = no global stores in the epilogue, 2 = minimal K loop (classic: 1 slab, gemm8p: 2 K tiles),
-256 = no epilogue at all (gemm8p only), 128 = no wave-group stagger (gemm8p only), 512 = LDS-DMA issued in the load block
-instead of between the MFMAs (gemm8p, plain bf16 epilogue only).
+16 = every other workgroup starts half a tile late (de-synchronises the store bursts), 256 = no epilogue at all (gemm8p / gemm6p), 128 = no wave-group stagger (gemm8p / gemm6p), 512 = LDS-DMA issued between
+the MFMAs instead of in the load block (gemm8p, plain bf16 epilogue only).  Widths that tile better by 192 than by 256 run
+on gemm6p.hip when "gemm8p" is on.
 
     t(full) - t(bits 2)        ~ K-loop time        t(bits 2) ~ per-tile overhead (prologue + epilogue + launch)
     t(full) - t(bits 1)        ~ cost of the global stores
@@ -56,7 +57,7 @@ def shape(M, N, K, act=0):
     for kern, mode in (("classic", 0), ("gemm8p", 1)):
         lib.roma_tuning(b"gemm8p", mode)
         r = {}
-        for bits in (0, 1, 2, 3) + ((128, 256, 258, 512, 512 + 256) if mode else ()):
+        for bits in (0, 1, 2, 3) + ((16, 128, 256, 258, 512) if mode else ()):
             lib.roma_tuning(b"gemm_dbg", bits)
             r[f"dbg{bits}_us"] = round(timed(call), 1)
         lib.roma_tuning(b"gemm_dbg", 0)
@@ -75,5 +76,5 @@ if __name__ == "__main__":
     shape(25616, 4096, 1024, act=2)   # fc1 + GELU
     shape(25616, 1024, 4096)          # fc2
     shape(16384, 1024, 4096)          # one round, long K
-    shape(78400, 1152, 1152)          # stride-8 refiner 1x1 (256 x 192 classic tiles; not a gemm8p shape)
-    shape(313600, 576, 576)           # stride-4 refiner 1x1
+    shape(78400, 1152, 1152)          # stride-8 refiner 1x1 (256 x 192 tiles: classic vs gemm6p)
+    shape(313600, 576, 576)           # stride-4 refiner 1x1 (256 x 192 tiles: classic vs gemm6p)

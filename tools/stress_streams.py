@@ -20,6 +20,7 @@ ap.add_argument("--runs", type=int, default=400)
 ap.add_argument("--fuse", type=int, default=1)
 ap.add_argument("--amp", default="bf16")
 ap.add_argument("--res", type=int, nargs=2, default=[112, 168])
+ap.add_argument("--trace", action="store_true", help="per-stage checksums: name the first stage that deviates from the majority")
 args = ap.parse_args()
 
 lib = _lib.load()
@@ -38,10 +39,14 @@ w1b, c1b = m.match(inp["im_A"], inp["im_B"], **kw)
 torch.cuda.synchronize()
 single_repro = bool(torch.equal(w1, w1b) and torch.equal(c1, c1b))
 m.dual_stream = True
+m.trace = args.trace
 bad = []
+traces = []
 t0 = time.time()
 for i in range(args.runs):
     w, c = m.match(inp["im_A"], inp["im_B"], **kw)
+    if args.trace:
+        traces.append([m.debug_trace(s) for s in (0, 1)])
     ne = c != c1
     if bool(ne.any()) or not torch.equal(w, w1):
         per = []
@@ -56,3 +61,23 @@ for i in range(args.runs):
 print(f"amp={args.amp} fuse={args.fuse} pairs={NB} env={env}: single-stream reproducible={single_repro}; "
       f"mismatching dual-stream runs {len(bad)}/{args.runs} in {time.time() - t0:.1f}s; "
       f"(run, [(pair, npix, r0, r1, c0, c1, dcert, dwarp)]): {bad[:5]}", flush=True)
+
+if args.trace and traces:
+    import collections
+    for slot in (0, 1):
+        names = traces[0][slot][0]
+        sums = [tr[slot][1] for tr in traces]
+        n = min(len(s) for s in sums)
+        major = []
+        for k in range(n):
+            major.append(collections.Counter(int(s[k]) for s in sums).most_common(1)[0][0])
+        first = collections.Counter()
+        ndev = 0
+        for ri, s in enumerate(sums):
+            dev = [k for k in range(n) if int(s[k]) != major[k]]
+            if dev:
+                ndev += 1
+                first[names[dev[0]]] += 1
+                if ndev <= 4:  # the whole chain of the first few deviating runs: does the deviation propagate or heal?
+                    print(f"  slot {slot} run {ri}: {len(dev)} deviating stages: {[names[k] for k in dev[:12]]}", flush=True)
+        print(f"trace slot {slot}: {n} stages; runs deviating from the per-stage majority: {ndev}/{len(sums)}; first deviating stage: {dict(first)}", flush=True)
