@@ -49,6 +49,12 @@ def pmc_traffic(kernel):
     targs = targs.rstrip(">").split(",") if targs else []
     conv = {"bf16": "unsigned short", "f32": "float", "dense": "false", "conv3x3": "true"}
     want = "void roma::" + base + ("<" + ", ".join(conv.get(t, t) for t in targs) + ">" if targs else "")
+    if base == "gemm8p_kernel" and len(targs) == 4:    # profile scope <in,out,form,epilogue> -> <TOUT, CONV, EPI, DMAMF>
+        epi = {"none": 0, "relu": 1, "gelu": 2, "res_bf16": 3, "qkv": 4}[targs[3]]
+        want = f"void roma::gemm8p_kernel<{conv[targs[1]]}, {conv[targs[2]]}, {epi}, false>"
+    elif base == "gemm6p_kernel" and len(targs) == 4:  # -> <TOUT, ACT>
+        act = {"none": 0, "relu": 1}[targs[3]]
+        want = f"void roma::gemm6p_kernel<{conv[targs[1]]}, {act}>"
     for rel in PMC_SUMMARIES:
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):

@@ -148,14 +148,6 @@ __global__ __launch_bounds__(512, 2) void gemm6p_kernel(const GemmArgs a) {
 
   // ---- prologue = everything the steady-state stream has issued before P1 of its position 0: all of K tile 0 and
   // P3(-1)'s share of K tile 1; K tile 0 complete (nk >= 2 is guaranteed by the dispatcher)
-  if ((a.dbg & 16) && ((blockIdx.x >> 3) & 1) && nblk > gridDim.x) {
-    // experiment (dbg 16): persistent equal-sized tiles keep all CUs in lock-step - every epilogue of a round hits HBM in
-    // one 25-32 MB store burst while no MFMA runs.  Start every other workgroup half a tile late so that one half of the
-    // chip stores while the other half multiplies.
-    const long t0 = __builtin_readcyclecounter();
-    const long wait = (long)nk * 1450;
-    while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-  }
   R6_TILE_SETUP(c_tm, c_tn)
   R6_ISSUE_A(0, 0, 0) R6_ISSUE_A(1, 0, 0) R6_ISSUE_W(0, 0, 0) R6_ISSUE_A(2, 0, 0) R6_ISSUE_A(3, 0, 0)
   R6_ISSUE_W(1, 0, 0) R6_ISSUE_W(2, 0, 0)

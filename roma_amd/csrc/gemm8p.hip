@@ -264,14 +264,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
   const int step_m = (int)(wg_per_xcd / NT), step_n = (int)(wg_per_xcd % NT);
 
   // ---- prologue: K tile 0 complete, A0 / W0 of K tile 1 under way (nk >= 2 is guaranteed by the dispatcher)
-  if ((a.dbg & 16) && ((blockIdx.x >> 3) & 1) && nblk > gridDim.x) {
-    // experiment (dbg 16): persistent equal-sized tiles keep all CUs in lock-step - every epilogue of a round hits HBM in
-    // one 25-32 MB store burst while no MFMA runs.  Start every other workgroup half a tile late so that one half of the
-    // chip stores while the other half multiplies.
-    const long t0 = __builtin_readcyclecounter();
-    const long wait = (long)nk * 1900;
-    while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-  }
   R8_TILE_SETUP(c_tm, c_tn)
   R8_ISSUE_A(0, 0, 0) R8_ISSUE_W(0, 0, 0) R8_ISSUE_W(1, 0, 0) R8_ISSUE_A(1, 0, 0)
   R8_ISSUE_A(0, 1, 1) R8_ISSUE_W(0, 1, 1)
