@@ -394,43 +394,61 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
   }  // tile loop
 }
 
-// Tile classifier: one wave per 8 x 8 query tile computes the bounding rectangle of the tile's integer patches (clipped
-// to the image) and appends the tile to the coherent list (rectangle fits the LDS stage) or to the gather list.
-// ws: [0] gather count, [1] coherent count, [2] / [3] dequeue cursors, then the two lists (tiles ints each).
+// Tile classifier: one THREAD per 8 x 8 query tile computes the bounding rectangle of the tile's integer patches (clipped
+// to the image); the tile goes to the coherent list (rectangle fits the LDS stage) or to the gather list.
+// ws: [0] gather count, [1] coherent count, [2] / [3] unused, then the two lists (tiles ints each).
+// Appends are aggregated per wave (one atomicAdd per list and wave, positions by ballot rank), for two reasons measured
+// with one atomic per tile: (a) 11 664 atomics on one word took 100 us (a counter word sustains ~90 updates / us), 20x the
+// classification itself; (b) the lists came out in completion order, i.e. with the tiles of all images interleaved -
+// the gather kernel then walked 16 feature maps at once (80 MB, MALL resident) instead of one or two (L2 resident) and ran
+// 1.2-1.9x slower than the per-pixel kernel on the same queries.  Now a list is in tile order inside each group of 64.
 template <int R>
-__global__ __launch_bounds__(256) void local_corr_classify_kernel(const LocalCorrArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(64) void local_corr_classify_kernel(const LocalCorrArgs a) {
+  const int lane = threadIdx.x & 63;  // one wave per workgroup: 64 tiles, spread over as many CUs as there are groups
   const int tiles_x = (a.W + LC_TQ - 1) / LC_TQ, tiles_y = (a.H + LC_TQ - 1) / LC_TQ;
   const int tpi = tiles_x * tiles_y, tiles = a.B * tpi;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= tiles) return;
-  const int b = tile / tpi;
-  const int trem = tile - b * tpi;
-  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-  const int qy = ty * LC_TQ + (lane >> 3), qx = tx * LC_TQ + (lane & 7);
-  const bool qvalid = qy < a.H && qx < a.W;
-  int x0 = 0, y0 = 0;
-  float fx, fy;
-  if (qvalid) {
-    const long qpix = (long)b * a.H * a.W + (long)qy * a.W + qx;
-    unnormalize_floor(a.warp[qpix * 2 + 0], a.W, x0, fx);
-    unnormalize_floor(a.warp[qpix * 2 + 1], a.H, y0, fy);
-  }
-  int xlo = qvalid ? x0 : 0x3fffffff, xhi = qvalid ? x0 : -0x3fffffff;
-  int ylo = qvalid ? y0 : 0x3fffffff, yhi = qvalid ? y0 : -0x3fffffff;
+  const int tile = blockIdx.x * 64 + threadIdx.x;
+  const bool valid = tile < tiles;
+  bool coherent = false;
+  if (valid) {
+    const int b = tile / tpi;
+    const int trem = tile - b * tpi;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    int xlo = 0x3fffffff, xhi = -0x3fffffff, ylo = 0x3fffffff, yhi = -0x3fffffff;
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    xlo = min(xlo, __shfl_xor(xlo, off));
-    xhi = max(xhi, __shfl_xor(xhi, off));
-    ylo = min(ylo, __shfl_xor(ylo, off));
-    yhi = max(yhi, __shfl_xor(yhi, off));
-  }
-  if (lane == 0) {
+    for (int r = 0; r < LC_TQ; ++r) {
+      const int qy = ty * LC_TQ + r;
+      const float2* wrow = reinterpret_cast<const float2*>(a.warp) + (long)b * a.H * a.W + (long)min(qy, a.H - 1) * a.W;
+#pragma unroll
+      for (int c = 0; c < LC_TQ; ++c) {
+        const int qx = tx * LC_TQ + c;
+        const float2 wv = wrow[min(qx, a.W - 1)];  // clamped address, masked below: the 64 loads carry no branches
+        int x0, y0;
+        float fx, fy;
+        unnormalize_floor(wv.x, a.W, x0, fx);
+        unnormalize_floor(wv.y, a.H, y0, fy);
+        if (qy < a.H && qx < a.W) {
+          xlo = min(xlo, x0); xhi = max(xhi, x0);
+          ylo = min(ylo, y0); yhi = max(yhi, y0);
+        }
+      }
+    }
     const long bw = max(min(xhi + R + 1, a.W - 1) - max(xlo - R, 0) + 1, 0);
     const long bh = max(min(yhi + R + 1, a.H - 1) - max(ylo - R, 0) + 1, 0);
-    const bool coherent = bw * bh <= LcGeom<R>::PXMAX && !a.force_gather;
-    if (coherent) a.ws[4 + tiles + atomicAdd(a.ws + 1, 1)] = tile;
-    else a.ws[4 + atomicAdd(a.ws + 0, 1)] = tile;
+    coherent = bw * bh <= LcGeom<R>::PXMAX && !a.force_gather;
+  }
+  const unsigned long long mc = __ballot(valid && coherent), mg = __ballot(valid && !coherent);
+  int basec = 0, baseg = 0;
+  if (lane == 0) {
+    if (mc) basec = atomicAdd(a.ws + 1, __popcll(mc));
+    if (mg) baseg = atomicAdd(a.ws + 0, __popcll(mg));
+  }
+  basec = __shfl(basec, 0);
+  baseg = __shfl(baseg, 0);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (valid) {
+    if (coherent) a.ws[4 + tiles + basec + __popcll(mc & below)] = tile;
+    else a.ws[4 + baseg + __popcll(mg & below)] = tile;
   }
 }
 
@@ -538,7 +556,7 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((local_corr_classify_kernel<R>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((local_corr_classify_kernel<R>), dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, stream, a);
   ROMA_LAUNCH_CHECK();
   hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT>), dim3((unsigned)tiles), dim3(256), lds_tile, stream, a);
   ROMA_LAUNCH_CHECK();
