@@ -30,7 +30,11 @@ import subprocess
 import sys
 import time
 
-import torch
+# --graph 1 only: ROCm 7.2's pre-built AQL packets for graph kernel nodes fault on the second replay of match() under this
+# loop's launch timing (profiles/r02_graph_replay_fault.md); read by libamdhip64 when it is loaded, i.e. before torch
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -106,8 +110,8 @@ def main():
     ap.add_argument("--upsample", type=int, default=864)
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="sub-batch HIP streams per GPU (2 = stream split, see DESIGN.md)")
-    ap.add_argument("--graph", type=int, default=None, choices=[0, 1],
-                    help="replay match() as a captured hipGraph (default: 1 for --config coarse, 0 for the batch-8 metric)")
+    ap.add_argument("--graph", type=int, default=0, choices=[0, 1],
+                    help="replay match() as a captured hipGraph (opt-in; see DEBUG_CLR_GRAPH_PACKET_CAPTURE at the top)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -153,7 +157,7 @@ def main():
         model = roma_outdoor(device=dev, weights=sd, dinov2_weights=dsd, coarse_res=args.coarse, upsample_res=args.upsample,
                              amp_dtype=amp, symmetric=True, upsample_preds=full, max_batch=args.batch)
         model.dual_stream = args.streams == 2
-        model.graph = bool(args.graph if args.graph is not None else (not full))
+        model.graph = bool(args.graph)  # opt-in (see the note at the top of this file)
         inp = {k: v.to(dev) for k, v in synthetic.make_inputs(args.batch, args.coarse, args.upsample if full else None,
                                                               seed=1 + rank).items()}
     n_pairs = args.batch * world

@@ -113,7 +113,6 @@ class Model {
     bool warmed = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    hipEvent_t done = nullptr;  // end of the last replay (one launch of an exec in flight at a time)
     ~GraphSlot();
   };
   std::map<std::string, GraphSlot> graphs;  // one per (batch, options)

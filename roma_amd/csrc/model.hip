@@ -522,7 +522,6 @@ int Model::match(int B, const float* ima, const float* imb, const float* ima_hr,
 // Capture and replay run on a stream of the handle's own, fenced against the caller's stream with two events: the
 // caller's stream may be the legacy default stream (torch's default), which cannot be captured.
 Model::GraphSlot::~GraphSlot() {
-  if (done) (void)hipEventDestroy(done);
   if (exec) (void)hipGraphExecDestroy(exec);
   if (graph) (void)hipGraphDestroy(graph);
 }
@@ -566,14 +565,12 @@ int Model::match_graph(int B, const float* ima, const float* imb, const float* i
   ROMA_CHECK_HIP(hipEventRecord(g_ev_in, st));
   ROMA_CHECK_HIP(hipStreamWaitEvent(g_stream, g_ev_in, 0));
   int rc = 0;
-  // One launch of an executable graph in flight at a time: with the host running ahead (bench loop, no synchronisation
-  // between calls) a second hipGraphLaunch of the same hipGraphExec_t while the first was still executing ended in a GPU
-  // memory access fault on ROCm 7.2 (tools/debug_graph.py --nosync reproduces it; the same calls with a wait in between,
-  // or eager launches, are clean).  The host therefore waits for the previous replay of THIS graph before it launches the
-  // next one; it still runs ahead by the rest of the call (staging copies, output copies).
-  static const bool graph_nosync = getenv("ROMA_GRAPH_NOSYNC") && atoi(getenv("ROMA_GRAPH_NOSYNC")) != 0;
+  // ROCm 7.2 note: with the runtime's pre-built graph packets (DEBUG_CLR_GRAPH_PACKET_CAPTURE, on by default) the second
+  // or a later replay of this graph ends in a GPU memory access fault under some launch timings; with that feature off
+  // every replay is clean and bit-identical (profiles/r02_graph_replay_fault.md: bisection).  Nothing on this side changes
+  // it (one launch in flight at a time was tried), so the option stays opt-in and the callers that use it set that
+  // variable before the runtime is loaded.
   if (g.exec) {
-    if (g.done && !graph_nosync) ROMA_CHECK_HIP(hipEventSynchronize(g.done));
     ROMA_CHECK_HIP(hipGraphLaunch(g.exec, g_stream));
   } else if (!g.warmed) {
     rc = match_streams(B, s_a, s_b, hr ? s_ah : nullptr, hr ? s_bh : nullptr, s_w, s_c, g_stream);
@@ -596,10 +593,6 @@ int Model::match_graph(int B, const float* ima, const float* imb, const float* i
     ROMA_CHECK_HIP(hipGraphLaunch(g.exec, g_stream));
   }
   if (rc) return rc;
-  if (g.exec) {
-    if (!g.done) ROMA_CHECK_HIP(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
-    ROMA_CHECK_HIP(hipEventRecord(g.done, g_stream));
-  }
   ROMA_CHECK_HIP(hipEventRecord(g_ev_out, g_stream));
   ROMA_CHECK_HIP(hipStreamWaitEvent(st, g_ev_out, 0));
   ROMA_CHECK_HIP(hipMemcpyAsync(warp, s_w, (size_t)B * px * 4 * 4, hipMemcpyDeviceToDevice, st));

@@ -105,7 +105,9 @@ class RegressionMatcher:
         # bf16 mode the overlapped sub-batch is not bit-reproducible yet (~1 bf16 ulp in a small patch in 1-5 % of runs)
         self.dual_stream = False
         # opt-in: replay the kernel schedule of each (batch, options) configuration as a captured hipGraph from its
-        # third call on (one launch instead of ~1 600: matters for small batches, where match() is host-bound)
+        # third call on (one launch instead of ~1 600: matters for tiny problems, where match() is host-bound).  On
+        # ROCm 7.2 run the process with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (set before libamdhip64 / torch is loaded):
+        # the runtime's pre-built graph packets fault on a later replay (profiles/r02_graph_replay_fault.md)
         self.graph = False
         self.trace = False  # tests / tools only: per-stage output checksums (debug_trace)
         self._weights = weights
