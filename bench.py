@@ -108,8 +108,8 @@ def main():
                     help="full = 560 -> 864 upsample path (the metric); coarse = coarse-only 560 (BASELINE config 2)")
     ap.add_argument("--coarse", type=int, default=560)
     ap.add_argument("--upsample", type=int, default=864)
-    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
-                    help="sub-batch HIP streams per GPU (2 = stream split, see DESIGN.md)")
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
+                    help="sub-batch HIP streams per GPU (2 = the library default: two half-batches, DESIGN.md section 4)")
     ap.add_argument("--graph", type=int, default=0, choices=[0, 1],
                     help="replay match() as a captured hipGraph (opt-in; see DEBUG_CLR_GRAPH_PACKET_CAPTURE at the top)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -99,12 +99,13 @@ class Model {
   // Sub-batches on several HIP streams (option "streams" 1..4, "dual_stream" = 2 / 1; env ROMA_STREAMS overrides):
   // pairs are independent, so sub-batch i > 0 runs the same schedule out of its own arenas on side stream i and the
   // partially filled last rounds of one sub-batch's kernels (e.g. 404 GEMM tiles on 256 CUs) are filled by the
-  // others' work: +5 % at batch 8 with 2 streams (profiles/r01_v20_stream_split_ab.log).  OFF by default: in bf16
-  // mode the sub-batch on the caller's stream is not bit-reproducible under the overlap (1-5 % of runs differ by
-  // ~1 bf16 ulp in a 1 x 16 pixel patch of the finest refiner input; f32 mode 0 / 558) - see DESIGN.md.
+  // others' work: +7 % at batch 8 with 2 streams (profiles/r02_v10_bench_bf16.json vs r02_v6_bench_bf16.json).
+  // ON by default (2 streams) since round 2: results are bit-identical to the single-stream schedule (2 000 / 2 000 bf16
+  // stress runs in the GPU suite; the 1-5 % one-ulp deviations of round 1 went away with the GEMM epilogue rewrite,
+  // while the library of the commit before it still shows them on the same box - DESIGN.md section 4).
   // Side arenas / streams are created on first use from the sizes planned at roma_finalize.
   static constexpr int MAX_STREAMS = 4;
-  int n_streams = 1, streams_ready = 1;
+  int n_streams = 2, streams_ready = 1;
   size_t side_arena_bytes = 0, side_persist_bytes = 0;
   Arena side_arena[MAX_STREAMS - 1], side_persist[MAX_STREAMS - 1];
   hipStream_t side[MAX_STREAMS - 1] = {nullptr};

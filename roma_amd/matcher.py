@@ -101,9 +101,9 @@ class RegressionMatcher:
         # bf16 mode only: DINOv2's residual stream in bf16 like the reference's bf16 backbone (encoders.py casts the
         # backbone weights and input to amp_dtype); False keeps it in f32 (slower, slightly closer to the fp32 result)
         self.vit_bf16_residual = True
-        # opt-in: batches of >= 2 pairs as two half-batches on two HIP streams (+5 % at batch 8).  Off by default: in
-        # bf16 mode the overlapped sub-batch is not bit-reproducible yet (~1 bf16 ulp in a small patch in 1-5 % of runs)
-        self.dual_stream = False
+        # batches of >= 2 pairs run as two half-batches on two HIP streams (+7 % at batch 8; bit-identical to the
+        # single-stream schedule: tests/test_gpu_match.py::test_stream_split_*).  False = one stream, half the workspace
+        self.dual_stream = True
         # opt-in: replay the kernel schedule of each (batch, options) configuration as a captured hipGraph from its
         # third call on (one launch instead of ~1 600: matters for tiny problems, where match() is host-bound).  On
         # ROCm 7.2 run the process with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (set before libamdhip64 / torch is loaded):
