@@ -169,6 +169,12 @@ int roma_op_sample_warp_at(const float* warp, const float* cert, int H, int W, c
                            float* cert_a, void* stream);
 int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
                       int* match_b, void* ws_a, void* ws_b, void* stream);
+/* RegressionMatcher.visualize_warp (matcher.py:936-986): out[c,y,x] = certainty * grid_sample(image, warp) + (1 - certainty)
+ * (bilinear, zeros padding, align_corners=False; white background).  warp [H, W2, 4] f32 with W2 = 2W (symmetric: left
+ * half samples im_b at warp[..., 2:4], right half samples im_a at warp[..., 0:2], matcher.py:967-975) or W2 = W (im_a may
+ * be NULL); certainty [H, W2]; images [3, im_h, im_w] f32; out [3, H, W2] f32. */
+int roma_op_visualize_warp(const float* warp, const float* certainty, const float* im_a, const float* im_b, int H, int W,
+                           int symmetric, int im_h, int im_w, float* out, void* stream);
 /* conf_from_fb_consistency (matcher.py:672-699): out[b,y,x] = 1 if the backward flow sampled (bilinear, zeros padding,
  * align_corners=False) at the forward flow's target returns to within th_n of pixel (x,y)'s own normalised
  * coordinate, else 0.  flows DEVICE [B,H,W,2] f32, out [B,H,W] f32; th_n = 2*th / max(H,W). */

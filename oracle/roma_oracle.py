@@ -389,6 +389,20 @@ def match_keypoints(x_A, x_B, warp, certainty, max_dist=0.005, cert_th=0):
                          * (cert_A_to_B[:, None] > cert_th) * (D < max_dist), as_tuple=True)
 
 
+def visualize_warp(warp, certainty, im_A, im_B, symmetric=True):
+    """RegressionMatcher.visualize_warp - romatch/models/matcher.py:964-981 (tensor inputs): [3, H, W2] blend of the
+    warped images with the certainty over a white background."""
+    H, W2, _ = warp.shape
+    W = W2 // 2 if symmetric else W2
+    a_rgb = F.grid_sample(im_B[None], warp[:, :W, 2:][None], mode="bilinear", align_corners=False)[0]
+    if symmetric:
+        b_rgb = F.grid_sample(im_A[None], warp[:, W:, :2][None], mode="bilinear", align_corners=False)[0]
+        warp_im = torch.cat((a_rgb, b_rgb), dim=2)
+    else:
+        warp_im = a_rgb
+    return certainty * warp_im + (1 - certainty) * torch.ones((H, W2))
+
+
 def conf_from_fb_consistency(flow_forward, flow_backward, th=2):
     """RegressionMatcher.conf_from_fb_consistency - romatch/models/matcher.py:672-699 (batched [B,H,W,2] flows)."""
     H, W = flow_forward.shape[-3:-1]

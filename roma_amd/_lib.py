@@ -59,6 +59,7 @@ SIGNATURES = {
     "roma_op_sample_warp_at": (_i, [_vp, _vp, _i, _i, _vp, _l, _vp, _vp, _vp]),
     "roma_op_mutual_nn": (_i, [_vp, _l, _vp, _l, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "roma_op_fb_consistency": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp]),
+    "roma_op_visualize_warp": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "roma_op_maxpool2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "roma_op_conv3x3_c3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }

@@ -366,6 +366,10 @@ int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const fl
                           static_cast<unsigned long long*>(ws_b), S(stream));
 }
 
+int roma_op_visualize_warp(const float* warp, const float* certainty, const float* im_a, const float* im_b, int H, int W,
+                           int symmetric, int im_h, int im_w, float* out, void* stream) {
+  return visualize_warp_launch(warp, certainty, im_a, im_b, H, W, symmetric, im_h, im_w, out, S(stream));
+}
 int roma_op_fb_consistency(const float* flow_fwd, const float* flow_bwd, int B, int H, int W, float th_n, float* out,
                            void* stream) {
   return fb_consistency_launch(flow_fwd, flow_bwd, B, H, W, th_n, out, S(stream));

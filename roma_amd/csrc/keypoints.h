@@ -12,6 +12,9 @@ int sample_warp_at_launch(const float* warp, const float* cert, int H, int W, co
 int mutual_nn_launch(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
                      int* match_b, unsigned long long* ws_a, unsigned long long* ws_b, hipStream_t s);
 // conf_from_fb_consistency (matcher.py:672-699): flows [B,H,W,2] f32 -> in_th [B,H,W] f32 (0 / 1)
+// visualize_warp (matcher.py:936-986): warp [H,W2,4], certainty [H,W2], images [3,im_h,im_w] f32 -> out [3,H,W2]
+int visualize_warp_launch(const float* warp, const float* cert, const float* im_a, const float* im_b, int H, int W,
+                          int symmetric, int im_h, int im_w, float* out, hipStream_t s);
 int fb_consistency_launch(const float* flow_fwd, const float* flow_bwd, int B, int H, int W, float th_n, float* out,
                           hipStream_t s);
 }  // namespace roma

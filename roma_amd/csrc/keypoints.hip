@@ -170,4 +170,51 @@ int fb_consistency_launch(const float* flow_fwd, const float* flow_bwd, int B, i
   return 0;
 }
 
+// ------------------------------------------------------------------ visualize_warp (matcher.py:936-986)
+// out[c, y, x] = cert[y, x] * bilinear_zeropad(src(x)[c], grid(y, x)) + (1 - cert[y, x])     (white background)
+// left half (x < W): src = im_B sampled at warp[y, x, 2:4]; right half (symmetric only): src = im_A at warp[y, x, 0:2]
+__global__ __launch_bounds__(256) void visualize_warp_kernel(const float* __restrict__ warp, const float* __restrict__ cert,
+                                                             const float* __restrict__ im_a, const float* __restrict__ im_b,
+                                                             int H, int W, int W2, int hi, int wi, float* __restrict__ out) {
+  const long total = (long)H * W2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int x = (int)(idx % W2);
+  const bool right = x >= W;
+  const float* src = right ? im_a : im_b;
+  const float gx = warp[idx * 4 + (right ? 0 : 2)], gy = warp[idx * 4 + (right ? 1 : 3)];
+  float ix = ((gx + 1.f) * wi - 1.f) * 0.5f, iy = ((gy + 1.f) * hi - 1.f) * 0.5f;
+  ix = fminf(fmaxf(ix, -1.0e6f), 1.0e6f);
+  iy = fminf(fmaxf(iy, -1.0e6f), 1.0e6f);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float tx = ix - fx0, ty = iy - fy0;
+  const float wgt[4] = {(1.f - tx) * (1.f - ty), tx * (1.f - ty), (1.f - tx) * ty, tx * ty};
+  float rgb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
+    if (yy >= 0 && yy < hi && xx >= 0 && xx < wi) {
+      const long p = (long)yy * wi + xx;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb[c] += wgt[t] * src[(long)c * hi * wi + p];
+    }
+  }
+  const float ce = cert[idx];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[(long)c * total + idx] = ce * rgb[c] + (1.f - ce);
+}
+
+int visualize_warp_launch(const float* warp, const float* cert, const float* im_a, const float* im_b, int H, int W,
+                          int symmetric, int im_h, int im_w, float* out, hipStream_t s) {
+  ROMA_REQUIRE(warp && cert && im_b && out && H > 0 && W > 0 && im_h > 0 && im_w > 0, "visualize_warp: bad arguments");
+  ROMA_REQUIRE(!symmetric || im_a, "visualize_warp: symmetric warps need im_A as well");
+  const int W2 = symmetric ? 2 * W : W;
+  const long total = (long)H * W2;
+  hipLaunchKernelGGL(visualize_warp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, warp, cert, im_a, im_b, H, W,
+                     W2, im_h, im_w, out);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace roma

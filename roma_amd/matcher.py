@@ -375,6 +375,47 @@ class RegressionMatcher:
                                                           C.c_void_p(torch.cuda.current_stream(ff.device).cuda_stream)))
         return out if has_batch else out[0]
 
+    def visualize_warp(self, warp, certainty, im_A=None, im_B=None, im_A_path=None, im_B_path=None, device="cuda",
+                       symmetric=True, save_path=None, unnormalize=False):
+        """matcher.py:936-986: both images warped into each other and blended with the certainty over a white background
+        (one HIP kernel: bilinear grid_sample + blend).  Same arguments and return value ([3, H, W2] tensor) as the
+        reference; PIL / path inputs are resized to the warp's resolution on the host like there."""
+        from PIL import Image
+        dev = warp.device
+        if not warp.is_cuda:
+            raise _lib.RomaHipError("visualize_warp: warp / certainty must live on a HIP device; there is no CPU fallback")
+        H, W2, _ = warp.shape
+        W = W2 // 2 if symmetric else W2
+        if im_A is None:
+            im_A, im_B = Image.open(im_A_path).convert("RGB"), Image.open(im_B_path).convert("RGB")
+        if not isinstance(im_A, torch.Tensor):
+            im_A, im_B = im_A.resize((W, H)), im_B.resize((W, H))
+            x_B = (torch.tensor(np.array(im_B)) / 255).to(dev).permute(2, 0, 1)
+            x_A = (torch.tensor(np.array(im_A)) / 255).to(dev).permute(2, 0, 1) if symmetric else None
+        else:
+            x_A, x_B = (im_A if symmetric else None), im_B
+        x_B = x_B.detach().to(dev, torch.float32).contiguous()
+        x_A = x_A.detach().to(dev, torch.float32).contiguous() if x_A is not None else None
+        if x_A is not None and tuple(x_A.shape) != tuple(x_B.shape):
+            raise ValueError("visualize_warp: im_A and im_B must have the same shape")
+        w = warp.detach().to(torch.float32).contiguous()
+        c = certainty.detach().to(torch.float32).contiguous()
+        out = torch.empty((3, H, W2), device=dev, dtype=torch.float32)
+        P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().roma_op_visualize_warp(P(w), P(c), P(x_A), P(x_B), H, W, int(bool(symmetric)),
+                                                          int(x_B.shape[-2]), int(x_B.shape[-1]), P(out),
+                                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        if save_path is not None:
+            vis = out
+            if unnormalize:  # utils.tensor_to_pil(unnormalize=True): undo the ImageNet normalisation
+                mean = torch.tensor([0.485, 0.456, 0.406], device=dev)[:, None, None]
+                std = torch.tensor([0.229, 0.224, 0.225], device=dev)[:, None, None]
+                vis = vis * std + mean
+            arr = (vis.permute(1, 2, 0).clamp(0, 1).cpu().numpy() * 255).astype(np.uint8)
+            Image.fromarray(arr).save(save_path)
+        return out
+
     # ------------------------------------------------------------------ light post-processing helpers (torch)
     def to_pixel_coordinates(self, coords, H_A, W_A, H_B=None, W_B=None):
         """matcher.py:701-717."""

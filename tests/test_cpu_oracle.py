@@ -127,6 +127,17 @@ def test_oracle_match_keypoints_vs_reference_golden():
         assert np.array_equal(iA.numpy(), g["inds_A_" + name]) and np.array_equal(iB.numpy(), g["inds_B_" + name]), name
 
 
+def test_oracle_visualize_warp_vs_reference_golden():
+    """oracle.visualize_warp against RegressionMatcher.visualize_warp of the reference (matcher.py:936-986): symmetric
+    warp with tensor images, and the one-directional form with an image of another resolution."""
+    from oracle import roma_oracle as O
+    g = np.load(os.path.join(GOLDEN, "visualize_reference.npz"))
+    t = {k: torch.from_numpy(g[k]) for k in g.files}
+    W = t["im_A"].shape[-1]
+    assert torch.equal(O.visualize_warp(t["warp"], t["cert"], t["im_A"], t["im_B"], symmetric=True), t["vis_sym"])
+    assert torch.equal(O.visualize_warp(t["warp"][:, :W], t["cert"][:, :W], None, t["im_B2"], symmetric=False), t["vis_one"])
+
+
 def test_library_exports_every_declared_symbol(built_lib):
     """include/roma_hip.h <-> libroma_hip.so <-> ctypes table: same symbol set; no compute without a GPU."""
     from roma_amd import _lib

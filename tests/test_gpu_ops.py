@@ -612,6 +612,25 @@ def test_match_keypoints_vs_reference_golden():
     assert len(e[0]) == 0 and len(e[1]) == 0
 
 
+def test_visualize_warp_vs_reference_golden(tmp_path):
+    """RegressionMatcher.visualize_warp on the device (roma_op_visualize_warp: grid_sample + certainty blend in one kernel)
+    against the reference's own output (tests/golden/visualize_reference.npz): symmetric with tensor images, one
+    direction with an image of another resolution; plus the save_path route."""
+    from roma_amd import RegressionMatcher
+    g = np.load(os.path.join(GOLDEN, "visualize_reference.npz"))
+    t = {k: torch.from_numpy(g[k]).cuda() for k in g.files}
+    m = RegressionMatcher.__new__(RegressionMatcher)  # the method needs no model handle
+    W = t["im_A"].shape[-1]
+    vs = m.visualize_warp(t["warp"], t["cert"], im_A=t["im_A"], im_B=t["im_B"], symmetric=True)
+    assert vs.shape == t["vis_sym"].shape and float((vs - t["vis_sym"]).abs().max()) < 2e-6
+    p = str(tmp_path / "vis.png")
+    vo = m.visualize_warp(t["warp"][:, :W].contiguous(), t["cert"][:, :W].contiguous(), im_A=t["im_A"], im_B=t["im_B2"],
+                          symmetric=False, save_path=p)
+    assert float((vo - t["vis_one"]).abs().max()) < 2e-6 and os.path.getsize(p) > 0
+    with pytest.raises(Exception):
+        m.visualize_warp(t["warp"].cpu(), t["cert"].cpu(), im_A=t["im_A"], im_B=t["im_B"])
+
+
 def test_fb_consistency_vs_oracle():
     """conf_from_fb_consistency on the device vs the oracle restatement (matcher.py:672-699).  The output is a hard
     threshold: pixels whose round-trip error is within 1e-5 of the threshold are excluded from the comparison."""

@@ -80,7 +80,8 @@ def run(r, c, h, w, B, regime, dt):
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    for regime in ("coherent", "incoherent"):
+    regimes = tuple(sys.argv[1:]) or ("coherent", "incoherent")  # e.g. `bench_local_corr.py coherent` under rocprofv3 --pmc
+    for regime in regimes:
         for (r, c, h, w) in ((7, 512, 40, 40), (3, 512, 70, 70), (3, 512, 108, 108), (2, 256, 140, 140), (2, 256, 216, 216)):
             run(r, c, h, w, 16, regime, BF16)
     run(3, 512, 108, 108, 16, "coherent", F32)

@@ -13,6 +13,7 @@ fixtures are what travels to the GPU box.  Usage:
     python tools/make_goldens.py full8_indoor  # same geometry, seeds 2 / 3 (BASELINE config 5 "indoor")
     python tools/make_goldens.py kde           # romatch.utils.kde.kde on seeded match-like points
     python tools/make_goldens.py keypoints     # RegressionMatcher.match_keypoints on a seeded warp + keypoints
+    python tools/make_goldens.py vis           # RegressionMatcher.visualize_warp on a seeded warp + images
 """
 import json
 import os
@@ -260,6 +261,30 @@ def keypoints_golden():
     np.savez_compressed(os.path.join(GOLD, "keypoints_reference.npz"), **out)
 
 
+def vis_golden():
+    """Reference RegressionMatcher.visualize_warp (matcher.py:936-986) on a seeded smooth symmetric warp, tensor images
+    of the warp's resolution, and the non-symmetric form with images of a different resolution."""
+    install_stubs()
+    from romatch.models.matcher import RegressionMatcher
+    g = torch.Generator().manual_seed(23)
+    H, W = 48, 64
+    ys, xs = torch.meshgrid(torch.linspace(-1 + 1 / H, 1 - 1 / H, H), torch.linspace(-1 + 1 / W, 1 - 1 / W, W), indexing="ij")
+    grid = torch.stack((xs, ys), dim=-1)
+    tgt_ab = (grid * 0.9 + 0.15 * torch.sin(3 * grid.flip(-1)) + 0.12).float()   # leaves the image at one border (zeros padding)
+    tgt_ba = (grid * 1.05 - 0.1 * torch.cos(2 * grid)).float()
+    warp = torch.cat((torch.cat((grid, tgt_ab), dim=-1), torch.cat((tgt_ba, grid), dim=-1)), dim=1)  # [H, 2W, 4]
+    cert = torch.rand(H, 2 * W, generator=g)
+    im_A, im_B = torch.rand(3, H, W, generator=g), torch.rand(3, H, W, generator=g)
+    out = {"warp": warp.numpy(), "cert": cert.numpy(), "im_A": im_A.numpy(), "im_B": im_B.numpy()}
+    out["vis_sym"] = RegressionMatcher.visualize_warp(None, warp, cert, im_A=im_A, im_B=im_B, device="cpu", symmetric=True).numpy()
+    im_B2 = torch.rand(3, 30, 44, generator=g)
+    out["im_B2"] = im_B2.numpy()
+    out["vis_one"] = RegressionMatcher.visualize_warp(None, warp[:, :W], cert[:, :W], im_A=im_A, im_B=im_B2, device="cpu",
+                                                      symmetric=False).numpy()
+    np.savez_compressed(os.path.join(GOLD, "visualize_reference.npz"), **out)
+    print("visualize_reference.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     for what in sys.argv[1:]:
-        {"contract": contract, "ops": ops, "tiny": tiny, "small": small, "full": full, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden}[what]()
+        {"contract": contract, "ops": ops, "tiny": tiny, "small": small, "full": full, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden, "vis": vis_golden}[what]()
