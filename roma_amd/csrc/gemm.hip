@@ -561,6 +561,12 @@ int gemm_launch(const GemmArgs& a0, hipStream_t stream) {
   GemmArgs a = a0;
   static const int dbg_env = getenv("ROMA_GEMM_DBG") ? atoi(getenv("ROMA_GEMM_DBG")) : 0;
   a.dbg = g_gemm_tuning[1] >= 0 ? g_gemm_tuning[1] : dbg_env;
+  // Non-temporal output stores in the bf16 row writer (full tiles): the store acknowledgements are what the in-order
+  // vmcnt queue of the next tile's first counted waits sits behind, and streaming stores come back sooner: -4..-5 % on the
+  // K = 1024 / 1152 launches, neutral at K = 576 / 4096 (profiles/r02_v11_gemm_overhead.log, bit 1024).  ROMA_GEMM_NT=0 or
+  // gemm_dbg bit 2048 switch them off (A/B).
+  static const bool nt_env = !(getenv("ROMA_GEMM_NT") && atoi(getenv("ROMA_GEMM_NT")) == 0);
+  if (nt_env && !(a.dbg & 2048)) a.dbg |= 1024;
   const int ce = a.in_dt == DT_F32 ? 4 : 8;
   ROMA_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "gemm: empty problem");
   ROMA_REQUIRE(a.K % ce == 0, "gemm: K must be a multiple of the 16-byte chunk");

@@ -482,7 +482,7 @@ int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
     }
     if (a.act == ACT_GELU) return launch8p<bf16_t, false, E8_GELU>(a, stream, "gelu");
     if (a.act == ACT_RELU) return launch8p<bf16_t, false, E8_RELU>(a, stream, "relu");
-    // A/B switch: LDS-DMA issued between the MFMAs instead of in the load block.  Measured (profiles/r02_gemm_overhead.log):
+    // A/B switch: LDS-DMA issued between the MFMAs instead of in the load block.  Measured (tools/bench_gemm_overhead.py bit 512, profiles/r02_v11_gemm_overhead.log):
     // neutral at K = 1024, -4 % at K = 4096, -15 % on the 3x3 convolution (its per-piece select sits between the MFMAs)
     if (a.dbg & 512) return launch8p<bf16_t, false, E8_NONE, true>(a, stream, "none");
     return launch8p<bf16_t, false, E8_NONE>(a, stream, "none");

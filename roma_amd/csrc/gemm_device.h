@@ -200,7 +200,7 @@ __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], con
       }
       if (a.dbg & 1) continue;
       if (FULL) {
-        if (a.dbg & 1024) {  // experiment: streaming (non-temporal) stores - does the in-order vmcnt queue see them acked earlier?
+        if (a.dbg & 1024) {  // streaming (non-temporal) stores, the default (gemm_launch): acknowledged sooner in the vmcnt queue
           typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
           __builtin_nontemporal_store(u32x4n{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4n*>(dst));
         } else {

@@ -59,11 +59,14 @@ __device__ __forceinline__ void lc_gather_stage_f0(const LocalCorrArgs& a, long 
   const int b = (int)(pix / HW);
   const long p = pix - (long)b * HW;
   const T* f0p = reinterpret_cast<const T*>(a.f0) + ((long)b * HW + p) * a.ld0;
+  // 16-byte LDS accesses on purpose (myf0 is 16-byte aligned: C % 4 == 0): with scalar indexing hipcc emitted
+  // ds_write2_b32 / ds_read2_b32, which bank over 32 dwords - the channel slices s and s + 4 of the readers (32 bytes
+  // apart) then collide: LDS bank-conflict share 0.47-0.49 of this kernel (profiles/r02_v11_local_corr_sq.txt)
   for (int c = lane * CE; c < a.C; c += 64 * CE) {
     float v[CE];
     LcIO<T>::ld(f0p + c, v);
 #pragma unroll
-    for (int j = 0; j < CE; ++j) myf0[c + j] = v[j];
+    for (int j = 0; j < CE; j += 4) *reinterpret_cast<f32x4*>(myf0 + c + j) = f32x4{v[j], v[j + 1], v[j + 2], v[j + 3]};
   }
 }
 
@@ -95,13 +98,19 @@ __device__ __forceinline__ void lc_gather_pixel(const LocalCorrArgs& a, long pix
     float sum = 0.f;
     if (y >= 0 && y < a.H && xok) {
       const T* src = f1p + ((long)y * a.W + x) * a.ld1 + CE * s;
-      const float* fq = myf0 + CE * s;
+      const f32x4* fq = reinterpret_cast<const f32x4*>(myf0 + CE * s);  // ds_read_b128 (see lc_gather_stage_f0)
 #pragma unroll 4
       for (int i = 0; i < NI; ++i) {
         float v[CE];
         LcIO<T>::ld(src + (long)i * CE * S, v);
 #pragma unroll
-        for (int j = 0; j < CE; ++j) sum = fmaf(v[j], fq[i * CE * S + j], sum);
+        for (int j = 0; j < CE; j += 4) {
+          const f32x4 q = fq[(i * CE * S + j) >> 2];
+          sum = fmaf(v[j], q[0], sum);
+          sum = fmaf(v[j + 1], q[1], sum);
+          sum = fmaf(v[j + 2], q[2], sum);
+          sum = fmaf(v[j + 3], q[3], sum);
+        }
       }
     }
     D[r] = sum;
@@ -173,6 +182,17 @@ template <int R> struct LcGeom {
   static constexpr int NPRE = (NSLOT * 8 + 255) / 256;  // 16-byte pieces per thread per chunk
   static constexpr bool PREFETCH = R <= 3;              // larger windows: the accumulators need the registers
 };
+
+// Row pitch (in staged pixel slots) of the f1 rectangle.  Lanes are queries: a 16-lane LDS group covers 4 runs of 4
+// neighbouring queries on 4 tile rows - {row 0: cols 0-3}, {row 1: cols 4-7}, {row 2: cols 4-7}, {row 3: cols 0-3} - and
+// with the 144-byte slot pitch the bank group of a slot is (9 * slot) mod 16, so the four runs fall on distinct banks
+// exactly when the row pitch is 8 (mod 16).  With the natural pitch (the rectangle width, 15-17 at unit scale) the runs
+// overlap: bank-conflict share 0.53-0.59 of the kernel's LDS cycles (profiles/r02_v11_local_corr_sq.txt).  The padded
+// pitch is used when the padded rectangle still fits the stage; otherwise the natural one (slower, still correct).
+__device__ __host__ inline int lc_row_pitch(int bw, int bh, int pxmax) {
+  const int padded = ((bw + 7) / 16) * 16 + 8;  // smallest p >= bw with p % 16 == 8
+  return (long)padded * bh <= pxmax ? padded : bw;
+}
 
 template <typename T> struct LcDot;
 template <> struct LcDot<float> {  // 32 channels per 128-byte chunk
@@ -269,7 +289,8 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
   }
   __syncthreads();
   const int bx0 = tinfo[0], by0 = tinfo[1], bw = tinfo[2], bh = tinfo[3];
-  const long npx = (long)bw * bh;
+  const int bwp = lc_row_pitch(bw, bh, LC_PXMAX);  // slots per staged rectangle row (>= bw, see lc_row_pitch)
+  const long npx = (long)bwp * bh;
   const int simg = (b + a.f1_shift) % a.nimg;
   TOUT* outp = reinterpret_cast<TOUT*>(a.out);
 
@@ -304,8 +325,8 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
     const int slotp = i >> 3, piece = i & 7;
     unsigned off = 0xffffffffu;
     if (slotp < (int)npx) {
-      const int py = slotp / bw, px = slotp - py * bw;
-      off = (unsigned)((((long)(by0 + py) * a.W + (bx0 + px)) * a.ld1) * (long)sizeof(T) + piece * 16);
+      const int py = slotp / bwp, px = slotp - py * bwp;
+      if (px < bw) off = (unsigned)((((long)(by0 + py) * a.W + (bx0 + px)) * a.ld1) * (long)sizeof(T) + piece * 16);
     } else if (slotp < nslots) {
       const int q = slotp - (int)npx;
       const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
@@ -330,8 +351,8 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
         const int slotp = i >> 3, piece = i & 7;
         const char* src = nullptr;
         if (slotp < (int)npx) {
-          const int py = slotp / bw, px = slotp - py * bw;
-          src = reinterpret_cast<const char*>(f1p + ((long)(by0 + py) * a.W + (bx0 + px)) * a.ld1 + c0) + piece * 16;
+          const int py = slotp / bwp, px = slotp - py * bwp;
+          if (px < bw) src = reinterpret_cast<const char*>(f1p + ((long)(by0 + py) * a.W + (bx0 + px)) * a.ld1 + c0) + piece * 16;
         } else {
           const int q = slotp - (int)npx;
           const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
@@ -363,7 +384,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
 #pragma unroll
           for (int j = 0; j < P; ++j) {
             const int xx = my_x + j;
-            if (xx >= 0 && xx < bw) acc[ri][j] = LcDot<T>::dot(q, lds + (yy * bw + xx) * LC_PITCH, acc[ri][j]);
+            if (xx >= 0 && xx < bw) acc[ri][j] = LcDot<T>::dot(q, lds + (yy * bwp + xx) * LC_PITCH, acc[ri][j]);
           }
         }
       }

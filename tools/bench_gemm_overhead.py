@@ -1,6 +1,6 @@
 """Where does a GEMM tile's time go?  Both bf16 main loops (gemm8p / classic) on model shapes with the tuning bits of
 roma_tuning("gemm_dbg"): 1 = no global stores in the epilogue, 2 = minimal K loop (classic: 1 slab, gemm8p: 2 K tiles),
-1024 = non-temporal output stores (bf16 row writer, full tiles), 256 = no epilogue at all (gemm8p / gemm6p), 128 = no wave-group stagger (gemm8p / gemm6p), 512 = LDS-DMA issued between
+2048 = NO non-temporal output stores (they are the default: bf16 row writer, full tiles), 256 = no epilogue at all (gemm8p / gemm6p), 128 = no wave-group stagger (gemm8p / gemm6p), 512 = LDS-DMA issued between
 the MFMAs instead of in the load block (gemm8p, plain bf16 epilogue only).  Widths that tile better by 192 than by 256 run
 on gemm6p.hip when "gemm8p" is on.
 
@@ -57,7 +57,7 @@ def shape(M, N, K, act=0):
     for kern, mode in (("classic", 0), ("gemm8p", 1)):
         lib.roma_tuning(b"gemm8p", mode)
         r = {}
-        for bits in (0, 1, 2, 3) + ((128, 256, 258, 512, 1024) if mode else ()):
+        for bits in (0, 1, 2, 3) + ((128, 256, 258, 512, 2048) if mode else ()):
             lib.roma_tuning(b"gemm_dbg", bits)
             r[f"dbg{bits}_us"] = round(timed(call), 1)
         lib.roma_tuning(b"gemm_dbg", 0)
