@@ -372,7 +372,33 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
           if (poff[k] != 0xffffffffu) pre[k] = *reinterpret_cast<const uint4*>(((from_f0 >> k) & 1u ? f0b : f1b) + poff[k] + coff);
       }
     }
-    if (qvalid) {
+    if constexpr (sizeof(T) == 2 && R <= 3) {
+      // Branch-free per lane: a patch position outside the rectangle reads slot 0 (always staged) and its dot is discarded
+      // by a select.  With per-position `if`s every one of the 8 x 16-byte LDS reads of a dot sat in its own exec-masked
+      // block and was waited for on its own (149 s_waitcnt for 124 reads in the ISA): the kernel ran at LDS LATENCY,
+      // 5x below its LDS-bandwidth bound (SQ: 66 % of the wave cycles parked).  Queries outside the image have a zero f0
+      // row, so they need no guard either.  The only branch left is wave-uniform (r < P).
+      uint4 q[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) q[i] = *reinterpret_cast<const uint4*>(f0slot + 16 * i);
+#pragma unroll
+      for (int ri = 0; ri < NR; ++ri) {
+        const int r = wave + 4 * ri;  // wave-uniform
+        if (r < P) {
+          const int yy = my_y + r;
+          const bool rowok = yy >= 0 && yy < bh;
+          const int rowbase = rowok ? yy * bwp : 0;
+#pragma unroll
+          for (int j = 0; j < P; ++j) {
+            const int xx = my_x + j;
+            const bool ok = rowok && xx >= 0 && xx < bw;
+            const float t = LcDot<T>::dot(q, lds + (rowbase + (ok ? xx : 0)) * LC_PITCH, acc[ri][j]);
+            acc[ri][j] = ok ? t : acc[ri][j];
+          }
+        }
+      }
+    } else if (qvalid) {
+      // f32 operands / r = 7: the branch-free form needs more registers than there are (11-334 spilled); per-position guards
       uint4 q[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) q[i] = *reinterpret_cast<const uint4*>(f0slot + 16 * i);
@@ -481,8 +507,11 @@ template <int R, typename T, typename TOUT>
 __global__ __launch_bounds__(256) void local_corr_list_kernel(const LocalCorrArgs a) {
   extern __shared__ __attribute__((aligned(16))) float f0s[];  // [4 waves][C]
   const int li = blockIdx.x >> 4, rnd = blockIdx.x & 15;
-  if (li >= a.ws[0]) return;
+  // both scalar loads are issued before either is waited for (the list has one slot per tile of the call, so the second
+  // address is valid whatever the count is): one L2 round trip at the head of every workgroup instead of two dependent ones
+  const int nlist = a.ws[0];
   const int tile = a.ws[4 + li];
+  if (li >= nlist) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles_x = (a.W + LC_TQ - 1) / LC_TQ, tiles_y = (a.H + LC_TQ - 1) / LC_TQ;
   const int tpi = tiles_x * tiles_y;
@@ -579,7 +608,10 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   }
   hipLaunchKernelGGL((local_corr_classify_kernel<R>), dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, stream, a);
   ROMA_LAUNCH_CHECK();
-  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT>), dim3((unsigned)tiles), dim3(256), lds_tile, stream, a);
+  // (ROMA_LC_TILE_GRID caps the launch - the kernel strides over the list - for A/B runs of the surplus-workgroup cost)
+  static const int tile_grid_cap = getenv("ROMA_LC_TILE_GRID") ? atoi(getenv("ROMA_LC_TILE_GRID")) : 0;
+  const unsigned tile_grid = (unsigned)(tile_grid_cap > 0 ? std::min(tiles, tile_grid_cap) : tiles);
+  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT>), dim3(tile_grid), dim3(256), lds_tile, stream, a);
   ROMA_LAUNCH_CHECK();
   hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
                      stream, a);
