@@ -91,29 +91,32 @@ __device__ __forceinline__ void lc_gather_pixel(const LocalCorrArgs& a, long pix
   const T* f1p = reinterpret_cast<const T*>(a.f1) + (long)simg * HW * a.ld1;
   const int NI = a.C / (CE * S);
 
+  // Branch-free rows: a patch row / column outside the image reads a clamped (valid) address and its sum is discarded.
+  // With a per-row `if` the loads of one row could not be issued before the previous row's block had ended: 2 x P
+  // serialised L2 round trips per pixel, the kernel ran at memory LATENCY (5 waves per SIMD do not cover it).
+  const int xc = min(max(x, 0), a.W - 1);
+  const f32x4* fq = reinterpret_cast<const f32x4*>(myf0 + CE * s);  // ds_read_b128 (see lc_gather_stage_f0)
   float D[P];
 #pragma unroll
   for (int r = 0; r < P; ++r) {
     const int y = y0 - R + r;
+    const bool ok = y >= 0 && y < a.H && xok;
+    const T* src = f1p + ((long)min(max(y, 0), a.H - 1) * a.W + xc) * a.ld1 + CE * s;
     float sum = 0.f;
-    if (y >= 0 && y < a.H && xok) {
-      const T* src = f1p + ((long)y * a.W + x) * a.ld1 + CE * s;
-      const f32x4* fq = reinterpret_cast<const f32x4*>(myf0 + CE * s);  // ds_read_b128 (see lc_gather_stage_f0)
 #pragma unroll 4
-      for (int i = 0; i < NI; ++i) {
-        float v[CE];
-        LcIO<T>::ld(src + (long)i * CE * S, v);
+    for (int i = 0; i < NI; ++i) {
+      float v[CE];
+      LcIO<T>::ld(src + (long)i * CE * S, v);
 #pragma unroll
-        for (int j = 0; j < CE; j += 4) {
-          const f32x4 q = fq[(i * CE * S + j) >> 2];
-          sum = fmaf(v[j], q[0], sum);
-          sum = fmaf(v[j + 1], q[1], sum);
-          sum = fmaf(v[j + 2], q[2], sum);
-          sum = fmaf(v[j + 3], q[3], sum);
-        }
+      for (int j = 0; j < CE; j += 4) {
+        const f32x4 q = fq[(i * CE * S + j) >> 2];
+        sum = fmaf(v[j], q[0], sum);
+        sum = fmaf(v[j + 1], q[1], sum);
+        sum = fmaf(v[j + 2], q[2], sum);
+        sum = fmaf(v[j + 3], q[3], sum);
       }
     }
-    D[r] = sum;
+    D[r] = ok ? sum : 0.f;
   }
   // ---- reduce the S channel slices of each column, fetch the right-hand neighbour column
   float D1[P];
@@ -608,10 +611,8 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   }
   hipLaunchKernelGGL((local_corr_classify_kernel<R>), dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, stream, a);
   ROMA_LAUNCH_CHECK();
-  // (ROMA_LC_TILE_GRID caps the launch - the kernel strides over the list - for A/B runs of the surplus-workgroup cost)
-  static const int tile_grid_cap = getenv("ROMA_LC_TILE_GRID") ? atoi(getenv("ROMA_LC_TILE_GRID")) : 0;
-  const unsigned tile_grid = (unsigned)(tile_grid_cap > 0 ? std::min(tiles, tile_grid_cap) : tiles);
-  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT>), dim3(tile_grid), dim3(256), lds_tile, stream, a);
+  // (capping this launch at 1024 workgroups - the kernel strides over the list - changes nothing either way: measured)
+  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT>), dim3((unsigned)tiles), dim3(256), lds_tile, stream, a);
   ROMA_LAUNCH_CHECK();
   hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
                      stream, a);

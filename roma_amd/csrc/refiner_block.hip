@@ -358,8 +358,8 @@ __global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __r
         const int j = min(tid + 256 * it, n16 - 1);
         const int jp = j / (CP * 2 / 16), jc = j - jp * (CP * 2 / 16);  // piece -> (pixel, 16-byte column): un-pad
         const u32x4_t q = *(lds_u32x4*)(Ot + jp * Cf::OPIX + jc * 16);
-        if (dbg & 32) __builtin_nontemporal_store(q, reinterpret_cast<u32x4_t*>(orow + j * 8));  // experiment: streaming stores
-        else *reinterpret_cast<u32x4_t*>(orow + j * 8) = q;
+        *reinterpret_cast<u32x4_t*>(orow + j * 8) = q;  // (non-temporal stores: no change here - the counted waits already
+                                                         //  leave the stores of the last NR - 1 rows in flight)
       }
     }
     slot = slot + 1 == NR ? 0 : slot + 1;
