@@ -91,32 +91,32 @@ __device__ __forceinline__ void lc_gather_pixel(const LocalCorrArgs& a, long pix
   const T* f1p = reinterpret_cast<const T*>(a.f1) + (long)simg * HW * a.ld1;
   const int NI = a.C / (CE * S);
 
-  // Branch-free rows: a patch row / column outside the image reads a clamped (valid) address and its sum is discarded.
-  // With a per-row `if` the loads of one row could not be issued before the previous row's block had ended: 2 x P
-  // serialised L2 round trips per pixel, the kernel ran at memory LATENCY (5 waves per SIMD do not cover it).
-  const int xc = min(max(x, 0), a.W - 1);
+  // (A branch-free form of this loop - clamped addresses for out-of-image rows, sums discarded by a select - was measured
+  //  SLOWER on incoherent warps, 1.20 -> 1.57 ms at r = 2, 216 x 216: the gather is bound by L2 / fabric traffic there,
+  //  not by the serialisation of the rows, and the extra loads cost more than the overlap gains.)
   const f32x4* fq = reinterpret_cast<const f32x4*>(myf0 + CE * s);  // ds_read_b128 (see lc_gather_stage_f0)
   float D[P];
 #pragma unroll
   for (int r = 0; r < P; ++r) {
     const int y = y0 - R + r;
-    const bool ok = y >= 0 && y < a.H && xok;
-    const T* src = f1p + ((long)min(max(y, 0), a.H - 1) * a.W + xc) * a.ld1 + CE * s;
     float sum = 0.f;
+    if (y >= 0 && y < a.H && xok) {
+      const T* src = f1p + ((long)y * a.W + x) * a.ld1 + CE * s;
 #pragma unroll 4
-    for (int i = 0; i < NI; ++i) {
-      float v[CE];
-      LcIO<T>::ld(src + (long)i * CE * S, v);
+      for (int i = 0; i < NI; ++i) {
+        float v[CE];
+        LcIO<T>::ld(src + (long)i * CE * S, v);
 #pragma unroll
-      for (int j = 0; j < CE; j += 4) {
-        const f32x4 q = fq[(i * CE * S + j) >> 2];
-        sum = fmaf(v[j], q[0], sum);
-        sum = fmaf(v[j + 1], q[1], sum);
-        sum = fmaf(v[j + 2], q[2], sum);
-        sum = fmaf(v[j + 3], q[3], sum);
+        for (int j = 0; j < CE; j += 4) {
+          const f32x4 q = fq[(i * CE * S + j) >> 2];
+          sum = fmaf(v[j], q[0], sum);
+          sum = fmaf(v[j + 1], q[1], sum);
+          sum = fmaf(v[j + 2], q[2], sum);
+          sum = fmaf(v[j + 3], q[3], sum);
+        }
       }
     }
-    D[r] = ok ? sum : 0.f;
+    D[r] = sum;
   }
   // ---- reduce the S channel slices of each column, fetch the right-hand neighbour column
   float D1[P];
