@@ -169,6 +169,22 @@ int roma_op_sample_warp_at(const float* warp, const float* cert, int H, int W, c
                            float* cert_a, void* stream);
 int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
                       int* match_b, void* ws_a, void* ws_b, void* stream);
+/* ---- Tiny RoMa (romatch/models/tiny.py), matcher side; the XFeat backbone is the caller's (model_zoo/__init__.py:24-27).
+ * All tensors f32, channels-last unless noted.  corr_volume (tiny.py:182-196) = roma_op_gemm with A = feats of image B
+ * [H1*W1, C], W = feats of image A [H0*W0, C], alpha = 1/sqrt(C), batch = pairs: cv [B, H1*W1, H0*W0]. */
+int roma_op_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, void* stream);
+/* pos_embed, inference path (tiny.py:114-142 with exact_softmax = False): out [B, H0*W0, 2] = soft arg-max over the
+ * 4x-subsampled correlation column plus the arg-max position (H1, W1 multiples of 4). */
+int roma_op_tiny_pos_embed(const float* corr_volume, float* out, int B, int H1, int W1, int H0, int W0, void* stream);
+/* d[B,H,W,Cp] = cat(f0 [B,H,W,C], grid_sample(f1 [B,H1,W1,C], warp[..., 0:2]), warp[..., 0:2], zero pad)  (tiny.py:290-291,
+ * 298-299; bilinear, zeros padding, align_corners=False); warp has warp_channels >= 2 channels per pixel. */
+int roma_op_tiny_matcher_input(const float* f0, const float* f1, const float* warp, int warp_channels, float* d, int B, int H,
+                               int W, int H1, int W1, int C, int Cp, void* stream);
+/* out[p, 0:3] = base[p, 0:base_channels] (third channel 0 when base has 2) + delta[p, 0:3] * (sx, sy, 1)  (tiny.py:289-300) */
+int roma_op_tiny_update(const float* base, int base_channels, const float* delta, long ldd, float sx, float sy, float* out,
+                        long npix, void* stream);
+/* warp [B,H,W,4] = (grid, matches[..., 0:2]), certainty [B,H,W] = sigmoid(matches[..., 2])  (tiny.py:226-238) */
+int roma_op_tiny_final(const float* matches, float* warp, float* certainty, int B, int H, int W, void* stream);
 /* RegressionMatcher.visualize_warp (matcher.py:936-986): out[c,y,x] = certainty * grid_sample(image, warp) + (1 - certainty)
  * (bilinear, zeros padding, align_corners=False; white background).  warp [H, W2, 4] f32 with W2 = 2W (symmetric: left
  * half samples im_b at warp[..., 2:4], right half samples im_a at warp[..., 0:2], matcher.py:967-975) or W2 = W (im_a may

@@ -14,6 +14,7 @@
 #include "refiner_block.h"
 #include "kde.h"
 #include "keypoints.h"
+#include "tiny.h"
 
 namespace roma {
 static thread_local std::string g_err;
@@ -366,6 +367,24 @@ int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const fl
                           static_cast<unsigned long long*>(ws_b), S(stream));
 }
 
+// ---- Tiny RoMa matcher side (tiny.hip)
+int roma_op_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, void* stream) {
+  return nchw_to_nhwc_launch(in, out, B, C, H, W, S(stream));
+}
+int roma_op_tiny_pos_embed(const float* corr_volume, float* out, int B, int H1, int W1, int H0, int W0, void* stream) {
+  return tiny_pos_embed_launch(corr_volume, out, B, H1, W1, H0, W0, S(stream));
+}
+int roma_op_tiny_matcher_input(const float* f0, const float* f1, const float* warp, int warp_channels, float* d, int B, int H,
+                               int W, int H1, int W1, int C, int Cp, void* stream) {
+  return tiny_matcher_input_launch(f0, f1, warp, warp_channels, d, B, H, W, H1, W1, C, Cp, S(stream));
+}
+int roma_op_tiny_update(const float* base, int base_channels, const float* delta, long ldd, float sx, float sy, float* out,
+                        long npix, void* stream) {
+  return tiny_update_launch(base, base_channels, delta, ldd, sx, sy, out, npix, S(stream));
+}
+int roma_op_tiny_final(const float* matches, float* warp, float* certainty, int B, int H, int W, void* stream) {
+  return tiny_final_launch(matches, warp, certainty, B, H, W, S(stream));
+}
 int roma_op_visualize_warp(const float* warp, const float* certainty, const float* im_a, const float* im_b, int H, int W,
                            int symmetric, int im_h, int im_w, float* out, void* stream) {
   return visualize_warp_launch(warp, certainty, im_a, im_b, H, W, symmetric, im_h, im_w, out, S(stream));

@@ -174,3 +174,64 @@ def make_inputs(batch: int, coarse_res, upsample_res=None, seed: int = 1):
         out["im_A_high_res"] = rng.normal((batch, 3, uh, uw))
         out["im_B_high_res"] = rng.normal((batch, 3, uh, uw))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ Tiny RoMa
+class XFeatStandIn(torch.nn.Module):
+    """A caller-side stand-in for the XFeat backbone TinyRoMa uses (romatch/models/tiny.py:80-99; the real one is
+    `torch.hub.load("verlab/accelerated_features", "XFeat").net`, model_zoo/__init__.py:24-27 - not available offline).
+    Same interface and the same tensor contract: `norm`, `block1..5`, `skip1`, `block_fusion`;
+    x2 = block2(block1(x) + skip1(x)) is [B, 24, H/4, W/4], block_fusion(x3 + x4 + x5) is [B, 64, H/8, W/8].
+    Seeded weights (numpy PCG64).  TinyRoMa.__init__ deletes heatmap_head / keypoint_head / fine_matcher, so they exist."""
+
+    def __init__(self, seed: int = 0):
+        super().__init__()
+        nn = torch.nn
+        self.norm = nn.InstanceNorm2d(1)
+        self.skip1 = nn.Sequential(nn.AvgPool2d(4, stride=4), nn.Conv2d(1, 24, 1, stride=1, padding=0))
+        self.block1 = nn.Sequential(nn.Conv2d(1, 8, 3, stride=2, padding=1), nn.ReLU(), nn.Conv2d(8, 24, 3, stride=2, padding=1), nn.ReLU())
+        self.block2 = nn.Sequential(nn.Conv2d(24, 24, 3, padding=1), nn.ReLU())
+        self.block3 = nn.Sequential(nn.Conv2d(24, 64, 3, stride=2, padding=1), nn.ReLU())
+        self.block4 = nn.Sequential(nn.Conv2d(64, 64, 3, stride=2, padding=1), nn.ReLU())
+        self.block5 = nn.Sequential(nn.Conv2d(64, 64, 3, stride=2, padding=1), nn.ReLU())
+        self.block_fusion = nn.Sequential(nn.Conv2d(64, 64, 3, padding=1), nn.ReLU(), nn.Conv2d(64, 64, 1))
+        self.heatmap_head = nn.Identity()
+        self.keypoint_head = nn.Identity()
+        self.fine_matcher = nn.Identity()
+        rng = _Rng(9000 + seed)
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+                    m.weight.copy_(rng.normal(tuple(m.weight.shape), std=math.sqrt(2.0 / fan_in)))
+                    m.bias.copy_(rng.normal(tuple(m.bias.shape), std=0.1))
+        self.train(False)
+
+
+def make_tiny_state_dict(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """Matcher weights of TinyRoMa (tiny.py:49-62): 4 x BasicLayer (3x3 conv without bias, BatchNorm affine=False) + a 1x1
+    conv with bias, for the coarse (130 -> 256 -> 3) and the fine (50 -> 64 -> 3) matcher; same keys as the reference."""
+    rng = _Rng(9100 + seed)
+    sd = OrderedDict()
+    for name, cin, dim in (("coarse_matcher", 64 + 64 + 2, 256), ("fine_matcher", 24 + 24 + 2, 64)):
+        c = cin
+        for i in range(4):
+            sd[f"{name}.{i}.layer.0.weight"] = rng.normal((dim, c, 3, 3), std=math.sqrt(2.0 / (9 * c)))
+            sd[f"{name}.{i}.layer.1.running_mean"] = rng.normal((dim,), std=0.2)
+            sd[f"{name}.{i}.layer.1.running_var"] = rng.uniform((dim,), 0.5, 1.5)
+            sd[f"{name}.{i}.layer.1.num_batches_tracked"] = torch.tensor(100, dtype=torch.long)
+            c = dim
+        sd[f"{name}.4.weight"] = rng.normal((3, dim, 1, 1), std=0.3 * math.sqrt(1.0 / dim))
+        sd[f"{name}.4.bias"] = rng.normal((3,), std=0.05)
+    return sd
+
+
+def make_tiny_inputs(batch: int, h: int, w: int, seed: int = 1):
+    """Seeded image pairs in [0, 1] (what ToTensor() yields in TinyRoMa.match_from_path, tiny.py:199-203), smooth enough to
+    give structured correlation volumes."""
+    rng = _Rng(9200 + seed)
+    a = rng.uniform((batch, 3, h, w), 0.0, 1.0)
+    b = torch.roll(a, shifts=(h // 9, -(w // 11)), dims=(2, 3)) * 0.8 + 0.2 * rng.uniform((batch, 3, h, w), 0.0, 1.0)
+    k = torch.ones(1, 1, 5, 5) / 25.0
+    sm = lambda t: torch.nn.functional.conv2d(t.reshape(-1, 1, h, w), k, padding=2).reshape(batch, 3, h, w)  # noqa: E731
+    return {"im_A": sm(a).contiguous(), "im_B": sm(b).contiguous()}

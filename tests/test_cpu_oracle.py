@@ -127,6 +127,27 @@ def test_oracle_match_keypoints_vs_reference_golden():
         assert np.array_equal(iA.numpy(), g["inds_A_" + name]) and np.array_equal(iB.numpy(), g["inds_B_" + name]), name
 
 
+def test_tiny_oracle_vs_reference_golden():
+    """oracle.tiny_oracle (TinyRoMa inference, romatch/models/tiny.py) against the reference's own TinyRoMa run with the
+    seeded stand-in backbone (tests/golden/tiny_reference.npz): both correspondence levels from the stored features
+    (bit-exact) and match() end to end (BASELINE config 1: the reference's CPU-runnable case)."""
+    from oracle import tiny_oracle as T
+    from roma_amd import synthetic
+    g = np.load(os.path.join(GOLDEN, "tiny_reference.npz"))
+    sd, xf = synthetic.make_tiny_state_dict(0), synthetic.XFeatStandIn(0)
+    for tag in "ab":
+        a, b = torch.from_numpy(g[tag + "_im_A"]), torch.from_numpy(g[tag + "_im_B"])
+        n = a.shape[0]
+        ff, fc = torch.from_numpy(g[tag + "_feat_fine"]), torch.from_numpy(g[tag + "_feat_coarse"])
+        cor = T.forward_from_features(ff[:n], fc[:n], ff[n:], fc[n:], sd, (b.shape[-2] // 32) * 32, (b.shape[-1] // 32) * 32)
+        for lvl in (8, 4):
+            assert torch.equal(cor[lvl]["flow"], torch.from_numpy(g[f"{tag}_flow{lvl}"])), (tag, lvl)
+            assert torch.equal(cor[lvl]["certainty"], torch.from_numpy(g[f"{tag}_cert{lvl}"])), (tag, lvl)
+        w, c = T.match(a, b, xf, sd)
+        assert float((w - torch.from_numpy(g[tag + "_warp"])).abs().max()) < 1e-5
+        assert float((c - torch.from_numpy(g[tag + "_cert"])).abs().max()) < 1e-5
+
+
 def test_oracle_visualize_warp_vs_reference_golden():
     """oracle.visualize_warp against RegressionMatcher.visualize_warp of the reference (matcher.py:936-986): symmetric
     warp with tensor images, and the one-directional form with an image of another resolution."""

@@ -14,6 +14,7 @@ fixtures are what travels to the GPU box.  Usage:
     python tools/make_goldens.py kde           # romatch.utils.kde.kde on seeded match-like points
     python tools/make_goldens.py keypoints     # RegressionMatcher.match_keypoints on a seeded warp + keypoints
     python tools/make_goldens.py vis           # RegressionMatcher.visualize_warp on a seeded warp + images
+    python tools/make_goldens.py tinyroma      # TinyRoMa.match / forward with the seeded stand-in XFeat backbone
 """
 import json
 import os
@@ -261,6 +262,42 @@ def keypoints_golden():
     np.savez_compressed(os.path.join(GOLD, "keypoints_reference.npz"), **out)
 
 
+def tinyroma_golden():
+    """The reference's own TinyRoMa (romatch/models/tiny.py; tiny_roma_v1_model with exact_softmax=False, eval) on seeded
+    image pairs, with roma_amd.synthetic.XFeatStandIn in place of the un-vendored XFeat hub model and seeded matcher
+    weights.  Stored: inputs, the backbone features (so the device test can start from identical features), both
+    correspondence levels and match() outputs, for a 96 x 128 pair batch and a 100 x 150 pair (pre-processing resize)."""
+    install_stubs()
+    import types
+    if "torchvision.transforms" not in sys.modules:  # tiny.py imports ToTensor at module level
+        tv = sys.modules.get("torchvision") or types.ModuleType("torchvision")
+        tr = types.ModuleType("torchvision.transforms")
+        tr.ToTensor = lambda: (lambda im: torch.from_numpy(np.array(im)).permute(2, 0, 1).float() / 255)
+        tv.transforms = tr
+        sys.modules["torchvision"] = tv
+        sys.modules["torchvision.transforms"] = tr
+    from romatch.models.tiny import TinyRoMa
+    from roma_amd import synthetic
+    sd = synthetic.make_tiny_state_dict(0)
+    model = TinyRoMa(xfeat=synthetic.XFeatStandIn(0), freeze_xfeat=True, exact_softmax=False)
+    missing = model.load_state_dict(sd, strict=True)
+    model.train(False)
+    out = {}
+    for tag, (b, h, w) in (("a", (2, 96, 128)), ("b", (1, 100, 150))):
+        inp = synthetic.make_tiny_inputs(b, h, w, seed=3 if tag == "a" else 4)
+        with torch.inference_mode():
+            x = torch.cat([model.preprocess_tensor(inp["im_A"])[0], model.preprocess_tensor(inp["im_B"])[0]], dim=0)
+            fine, coarse = model.forward_single(x)
+            corr = model.forward({"im_A": inp["im_A"], "im_B": inp["im_B"]})
+            warp, cert = model.match(inp["im_A"], inp["im_B"], batched=True)
+        out.update({f"{tag}_im_A": np32(inp["im_A"]), f"{tag}_im_B": np32(inp["im_B"]), f"{tag}_feat_fine": np32(fine),
+                    f"{tag}_feat_coarse": np32(coarse), f"{tag}_flow8": np32(corr[8]["flow"]), f"{tag}_cert8": np32(corr[8]["certainty"]),
+                    f"{tag}_flow4": np32(corr[4]["flow"]), f"{tag}_cert4": np32(corr[4]["certainty"]), f"{tag}_warp": np32(warp),
+                    f"{tag}_cert": np32(cert)})
+    np.savez_compressed(os.path.join(GOLD, "tiny_reference.npz"), **out)
+    print("tiny_reference.npz", {k: v.shape for k, v in out.items()}, missing)
+
+
 def vis_golden():
     """Reference RegressionMatcher.visualize_warp (matcher.py:936-986) on a seeded smooth symmetric warp, tensor images
     of the warp's resolution, and the non-symmetric form with images of a different resolution."""
@@ -287,4 +324,4 @@ def vis_golden():
 
 if __name__ == "__main__":
     for what in sys.argv[1:]:
-        {"contract": contract, "ops": ops, "tiny": tiny, "small": small, "full": full, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden, "vis": vis_golden}[what]()
+        {"contract": contract, "ops": ops, "tiny": tiny, "small": small, "full": full, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden, "vis": vis_golden, "tinyroma": tinyroma_golden}[what]()
