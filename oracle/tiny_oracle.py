@@ -41,7 +41,15 @@ def corr_volume(feat0, feat1):
 
 def pos_embed(cv):
     """tiny.py:114-142, the inference branch (not training, exact_softmax False): low-resolution softmax plus the arg-max
-    entry.  Note tiny.py:134 concatenates the arg-max INDEX tensor, so the last logit is the index value itself."""
+    entry.  Note tiny.py:134 concatenates the arg-max INDEX tensor, so the last logit is the index value itself.
+
+    Batch semantics: tiny.py:137 multiplies P_lowres[:, -1] ([B, H0, W0]) with grid[best_match].permute(0, 3, 1, 2)
+    ([B, 2, H0, W0]) - the batch axis of P broadcasts against the CHANNEL axis of the grid, which is only well defined for
+    B = 1 (B = 2 silently mixes the two pairs, B >= 3 raises).  The reference's own callers pass single pairs
+    (match_from_path / PIL inputs, demo/demo_match_tiny.py); pairs are treated independently here, i.e. every pair gets the
+    reference's B = 1 result."""
+    if cv.shape[0] > 1:
+        return torch.cat([pos_embed(cv[b:b + 1]) for b in range(cv.shape[0])], dim=0)
     B, H1, W1, H0, W0 = cv.shape
     grid = torch.stack(torch.meshgrid(torch.linspace(-1 + 1 / W1, 1 - 1 / W1, W1), torch.linspace(-1 + 1 / H1, 1 - 1 / H1, H1),
                                       indexing="xy"), dim=-1).float().reshape(H1 * W1, 2)

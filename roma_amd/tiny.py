@@ -6,7 +6,11 @@ and it runs as the caller's torch module (tiny.py:80-99).  Everything after the 
 C ABI (include/roma_hip.h, csrc/tiny.hip): the all-pairs correlation volume on the MFMA GEMM, the soft arg-max position
 embedding, the two convolutional matchers (implicit-GEMM 3x3 convolutions with the BatchNorm folded in), the grid-sample
 warps and the final assembly.  fp32 throughout (the reference runs TinyRoMa in fp32).  No CPU fallback: tensors must live on
-a HIP device."""
+a HIP device.
+
+Batches: pairs are independent here, each gets the reference's single-pair (B = 1) result.  The reference's own batched
+pos_embed broadcasts the batch axis against the channel axis (tiny.py:137) - B = 2 silently mixes the pairs, B >= 3 raises -
+and its callers pass single pairs (match_from_path, demo/demo_match_tiny.py)."""
 from __future__ import annotations
 
 import ctypes as C

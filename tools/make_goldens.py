@@ -266,7 +266,9 @@ def tinyroma_golden():
     """The reference's own TinyRoMa (romatch/models/tiny.py; tiny_roma_v1_model with exact_softmax=False, eval) on seeded
     image pairs, with roma_amd.synthetic.XFeatStandIn in place of the un-vendored XFeat hub model and seeded matcher
     weights.  Stored: inputs, the backbone features (so the device test can start from identical features), both
-    correspondence levels and match() outputs, for a 96 x 128 pair batch and a 100 x 150 pair (pre-processing resize)."""
+    correspondence levels and match() outputs, for two 96 x 128 pairs and a 100 x 150 pair (pre-processing resize).
+    Every pair is run on its own (B = 1): tiny.py:137 broadcasts the batch axis of the arg-max probability against the
+    channel axis of the grid, so the reference's batched result is only well defined for B = 1 (see oracle/tiny_oracle.py)."""
     install_stubs()
     import types
     if "torchvision.transforms" not in sys.modules:  # tiny.py imports ToTensor at module level
@@ -285,15 +287,24 @@ def tinyroma_golden():
     out = {}
     for tag, (b, h, w) in (("a", (2, 96, 128)), ("b", (1, 100, 150))):
         inp = synthetic.make_tiny_inputs(b, h, w, seed=3 if tag == "a" else 4)
-        with torch.inference_mode():
-            x = torch.cat([model.preprocess_tensor(inp["im_A"])[0], model.preprocess_tensor(inp["im_B"])[0]], dim=0)
-            fine, coarse = model.forward_single(x)
-            corr = model.forward({"im_A": inp["im_A"], "im_B": inp["im_B"]})
-            warp, cert = model.match(inp["im_A"], inp["im_B"], batched=True)
-        out.update({f"{tag}_im_A": np32(inp["im_A"]), f"{tag}_im_B": np32(inp["im_B"]), f"{tag}_feat_fine": np32(fine),
-                    f"{tag}_feat_coarse": np32(coarse), f"{tag}_flow8": np32(corr[8]["flow"]), f"{tag}_cert8": np32(corr[8]["certainty"]),
-                    f"{tag}_flow4": np32(corr[4]["flow"]), f"{tag}_cert4": np32(corr[4]["certainty"]), f"{tag}_warp": np32(warp),
-                    f"{tag}_cert": np32(cert)})
+        per = {k: [] for k in ("fineA", "fineB", "coarseA", "coarseB", "flow8", "cert8", "flow4", "cert4", "warp", "cert")}
+        for p in range(b):
+            ia, ib = inp["im_A"][p:p + 1], inp["im_B"][p:p + 1]
+            with torch.inference_mode():
+                x = torch.cat([model.preprocess_tensor(ia)[0], model.preprocess_tensor(ib)[0]], dim=0)
+                fine, coarse = model.forward_single(x)
+                corr = model.forward({"im_A": ia, "im_B": ib})
+                warp, cert = model.match(ia, ib, batched=True)
+            for k, v in (("fineA", fine[:1]), ("fineB", fine[1:]), ("coarseA", coarse[:1]), ("coarseB", coarse[1:]),
+                         ("flow8", corr[8]["flow"]), ("cert8", corr[8]["certainty"]), ("flow4", corr[4]["flow"]),
+                         ("cert4", corr[4]["certainty"]), ("warp", warp), ("cert", cert)):
+                per[k].append(v.clone())
+        cat = {k: torch.cat(v, dim=0) for k, v in per.items()}
+        out.update({f"{tag}_im_A": np32(inp["im_A"]), f"{tag}_im_B": np32(inp["im_B"]),
+                    f"{tag}_feat_fine": np32(torch.cat((cat["fineA"], cat["fineB"]), dim=0)),          # [A pairs ..., B pairs ...]
+                    f"{tag}_feat_coarse": np32(torch.cat((cat["coarseA"], cat["coarseB"]), dim=0)),
+                    f"{tag}_flow8": np32(cat["flow8"]), f"{tag}_cert8": np32(cat["cert8"]), f"{tag}_flow4": np32(cat["flow4"]),
+                    f"{tag}_cert4": np32(cat["cert4"]), f"{tag}_warp": np32(cat["warp"]), f"{tag}_cert": np32(cat["cert"])})
     np.savez_compressed(os.path.join(GOLD, "tiny_reference.npz"), **out)
     print("tiny_reference.npz", {k: v.shape for k, v in out.items()}, missing)
 
