@@ -48,8 +48,8 @@ def test_tiny_match_end_to_end(built_lib, tag):
     dc = float((cert.cpu() - torch.from_numpy(g[tag + "_cert"])).abs().max())
     print(f"tiny match {tag}: max|dwarp| = {dw:.2e}, max|dcert| = {dc:.2e}")
     assert dw < TOL and dc < TOL
-    w1, c1 = m.match(a[:1], b[:1], batched=True)
-    assert torch.equal(w1, warp[:1]) and torch.equal(c1, cert[:1])  # pairs are independent
+    w1, c1 = m.match(a[:1], b[:1], batched=True)  # pairs are independent (the torch backbone may pick another conv algorithm
+    assert float((w1 - warp[:1]).abs().max()) < 1e-4 and float((c1 - cert[:1]).abs().max()) < 1e-4  # for another batch size)
 
 
 def test_tiny_rejects_cpu_and_missing_backbone(built_lib):
