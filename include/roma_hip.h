@@ -169,6 +169,13 @@ int roma_op_sample_warp_at(const float* warp, const float* cert, int H, int W, c
                            float* cert_a, void* stream);
 int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
                       int* match_b, void* ws_a, void* ws_b, void* stream);
+/* torch.multinomial(weights, k, replacement=False) of RegressionMatcher.sample (matcher.py:615-627): k distinct int64
+ * indices, drawn with probability proportional to the non-negative f32 weights [n] (exponential race + radix select, no
+ * sort; reproducible from `seed`; output order arbitrary).  At least k weights must be positive (the caller checks, as
+ * torch does).  workspace: device memory of roma_op_multinomial_workspace(n) bytes. */
+long roma_op_multinomial_workspace(long n);
+int roma_op_multinomial(const float* weights, long n, long k, unsigned long long seed, long long* out_indices, void* workspace,
+                        long workspace_bytes, void* stream);
 /* ---- Tiny RoMa (romatch/models/tiny.py), matcher side; the XFeat backbone is the caller's (model_zoo/__init__.py:24-27).
  * All tensors f32, channels-last unless noted.  corr_volume (tiny.py:182-196) = roma_op_gemm with A = feats of image B
  * [H1*W1, C], W = feats of image A [H0*W0, C], alpha = 1/sqrt(C), batch = pairs: cv [B, H1*W1, H0*W0]. */

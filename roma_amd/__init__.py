@@ -6,7 +6,8 @@ local-correlation operator.  Everything numerical runs in libroma_hip.so (hand-w
 from .matcher import RegressionMatcher, roma_indoor, roma_model, roma_outdoor  # noqa: F401
 from .local_correlation import local_corr, local_correlation  # noqa: F401
 from .kde import kde  # noqa: F401
+from .sampling import multinomial  # noqa: F401
 from .tiny import TinyRoMa, tiny_roma_v1_outdoor  # noqa: F401
 
 __all__ = ["RegressionMatcher", "roma_model", "roma_outdoor", "roma_indoor", "local_corr", "local_correlation", "kde",
-           "TinyRoMa", "tiny_roma_v1_outdoor"]
+           "multinomial", "TinyRoMa", "tiny_roma_v1_outdoor"]

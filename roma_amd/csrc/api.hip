@@ -15,6 +15,7 @@
 #include "kde.h"
 #include "keypoints.h"
 #include "tiny.h"
+#include "sampling.h"
 
 namespace roma {
 static thread_local std::string g_err;
@@ -367,6 +368,11 @@ int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const fl
                           static_cast<unsigned long long*>(ws_b), S(stream));
 }
 
+long roma_op_multinomial_workspace(long n) { return (long)multinomial_workspace_bytes(n); }
+int roma_op_multinomial(const float* weights, long n, long k, unsigned long long seed, long long* out_indices, void* workspace,
+                        long workspace_bytes, void* stream) {
+  return multinomial_launch(weights, n, k, seed, out_indices, workspace, (size_t)workspace_bytes, S(stream));
+}
 // ---- Tiny RoMa matcher side (tiny.hip)
 int roma_op_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, void* stream) {
   return nchw_to_nhwc_launch(in, out, B, C, H, W, S(stream));

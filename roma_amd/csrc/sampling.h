@@ -1,0 +1,13 @@
+// torch.multinomial(weights, k, replacement=False) on the device (matcher.py:615-627): see sampling.hip.
+#pragma once
+#include <algorithm>
+
+#include "common.h"
+
+namespace roma {
+size_t multinomial_workspace_bytes(long n);
+// out: k distinct indices (int64) drawn without replacement with probability proportional to weights (>= 0); the caller
+// guarantees at least k positive weights (checked by the Python wrapper like torch does).  ws: device workspace.
+int multinomial_launch(const float* weights, long n, long k, unsigned long long seed, long long* out, void* ws, size_t ws_bytes,
+                       hipStream_t s);
+}  // namespace roma

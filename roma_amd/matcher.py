@@ -298,23 +298,24 @@ class RegressionMatcher:
         """Certainty-weighted sampling of matches, optionally balanced by the inverse match density.
 
         Same control flow and attributes (`sample_mode`, `sample_thresh`) as the reference; the density is
-        `roma_amd.kde.kde` (HIP).  The two draws are `torch.multinomial` on the device tensors, as in the reference:
-        the result is stochastic, so parity with the reference is distributional."""
+        `roma_amd.kde.kde` (HIP) and the two draws without replacement are `roma_amd.sampling.multinomial` (HIP exponential
+        race + radix select).  The result is stochastic, so parity with the reference is distributional."""
         from .kde import kde
+        from .sampling import multinomial
         if "threshold" in self.sample_mode:
             upper_thresh = self.sample_thresh
             certainty = certainty.clone()
             certainty[certainty > upper_thresh] = 1
         matches, certainty = matches.reshape(-1, 4), certainty.reshape(-1)
         expansion_factor = 4 if "balanced" in self.sample_mode else 1
-        good_samples = torch.multinomial(certainty, num_samples=min(expansion_factor * num, len(certainty)), replacement=False)
+        good_samples = multinomial(certainty, min(expansion_factor * num, len(certainty)))
         good_matches, good_certainty = matches[good_samples], certainty[good_samples]
         if "balanced" not in self.sample_mode:
             return good_matches, good_certainty
         density = kde(good_matches, std=0.1)
         p = 1 / (density + 1)
         p[density < 10] = 1e-7  # at least 10 perfect neighbours, or around 100 ok ones (matcher.py:622-624)
-        balanced_samples = torch.multinomial(p, num_samples=min(num, len(good_certainty)), replacement=False)
+        balanced_samples = multinomial(p, min(num, len(good_certainty)))
         return good_matches[balanced_samples], good_certainty[balanced_samples]
 
     # ------------------------------------------------------------------ keypoint matching (matcher.py:732-773)

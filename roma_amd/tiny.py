@@ -22,6 +22,7 @@ import torch
 
 from . import _lib
 from .kde import kde
+from .sampling import multinomial
 
 F32 = 0
 
@@ -248,14 +249,14 @@ class TinyRoMa:
             certainty[certainty > self.sample_thresh] = 1
         matches, certainty = matches.reshape(-1, 4), certainty.reshape(-1)
         expansion_factor = 4 if "balanced" in self.sample_mode else 1
-        good = torch.multinomial(certainty, num_samples=min(expansion_factor * num, len(certainty)), replacement=False)
+        good = multinomial(certainty, min(expansion_factor * num, len(certainty)))
         good_matches, good_certainty = matches[good], certainty[good]
         if "balanced" not in self.sample_mode:
             return good_matches, good_certainty
         density = kde(good_matches, std=0.1, half=True, down=1)
         p = 1 / (density + 1)
         p[density < 10] = 1e-7
-        bal = torch.multinomial(p, num_samples=min(num, len(good_certainty)), replacement=False)
+        bal = multinomial(p, min(num, len(good_certainty)))
         return good_matches[bal], good_certainty[bal]
 
     def to_pixel_coordinates(self, coords, H_A, W_A, H_B=None, W_B=None):

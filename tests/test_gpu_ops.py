@@ -589,6 +589,43 @@ def test_sample_distribution_matches_oracle():
     assert vals <= {1.0, np.float32(0.01).item()}
 
 
+def test_multinomial_without_replacement():
+    """roma_amd.multinomial (exponential race + radix select) against the semantics of torch.multinomial(replacement=False):
+    k distinct indices, never a zero-weight entry while positive ones remain, exactly the positive set when k equals their
+    number, inclusion frequencies equal to torch's own (CPU) over many draws, reproducible from torch.manual_seed."""
+    from roma_amd import multinomial
+    g = torch.Generator().manual_seed(5)
+    n = 20000
+    w = torch.rand(n, generator=g) ** 3
+    w[::7] = 0.0
+    wd = w.cuda()
+    torch.manual_seed(123)
+    a = multinomial(wd, 3000)
+    assert a.dtype == torch.int64 and a.shape == (3000,) and len(torch.unique(a)) == 3000
+    assert bool((w[a.cpu()] > 0).all())
+    torch.manual_seed(123)
+    assert torch.equal(torch.sort(multinomial(wd, 3000)).values, torch.sort(a).values)
+    npos = int((w > 0).sum())
+    allpos = multinomial(wd, npos)
+    assert set(allpos.cpu().tolist()) == set(torch.nonzero(w > 0)[:, 0].tolist())
+    assert len(torch.unique(multinomial(wd, n))) == n  # k = n: a permutation (zero weights complete the sample)
+    # inclusion frequencies on a small problem: ours vs torch CPU vs each other (sequential draws without replacement)
+    ws = torch.tensor([8.0, 4.0, 2.0, 1.0, 1.0, 0.5, 0.25, 0.0])
+    cnt_ours, cnt_ref, reps = torch.zeros(8), torch.zeros(8), 4000
+    gen = torch.Generator().manual_seed(9)
+    wsd = ws.cuda()
+    for _ in range(reps):
+        cnt_ours[multinomial(wsd, 3, generator=gen).cpu()] += 1
+        cnt_ref[torch.multinomial(ws, 3, replacement=False, generator=gen)] += 1
+    fo, fr = cnt_ours / reps, cnt_ref / reps
+    assert fo[7] == 0 and float((fo - fr).abs().max()) < 0.03, (fo, fr)
+    # big-n distribution: mean weight of the chosen set tracks torch's
+    torch.manual_seed(7)
+    mo = float(w[multinomial(wd, 2000).cpu()].mean())
+    mr = float(w[torch.multinomial(w, 2000, replacement=False)].mean())
+    assert abs(mo - mr) < 0.03 * mr + 0.01, (mo, mr)
+
+
 def test_match_keypoints_vs_reference_golden():
     """RegressionMatcher.match_keypoints through roma_op_sample_warp_at + roma_op_mutual_nn: index-exact against the
     reference's own output (tests/golden/keypoints_reference.npz) for both parameter sets, plus the return variants."""
