@@ -214,6 +214,30 @@ def test_gemm8p_matches_classic_and_reference(lib, M, N, K, act, out_f32):
     assert torch.allclose(out[:2048].cpu().double(), ref, atol=2e-3 if out_f32 else 0.03, rtol=1e-4 if out_f32 else 1e-2)
 
 
+@pytest.mark.parametrize("M,N,K,act", [
+    (8192, 256, 256, 0),       # one n-tile, 8 K tiles of 32
+    (9000, 768, 1024, 2),      # ragged last m-tile, GELU
+    (25616, 1024, 1024, 0),    # DINOv2 proj shape, several tiles per workgroup
+    (70000, 512, 160, 1),      # K = 5 tiles (odd: every ring stage starts a tile), ReLU, many tiles per workgroup
+    (8300, 1000, 128, 0),      # shortest K (4 tiles = the ring depth), ragged m and n
+])
+def test_gemm4w_matches_classic(lib, M, N, K, act):
+    """The experimental four-wave kernel (gemm4w.hip: 128 x 128 wave tiles, accumulators in hard AGPRs, fragment reads and
+    LDS-DMA between the MFMAs, 4-stage ring of 32-deep K tiles; tuning value gemm8p = 2) accumulates in the same k order as
+    the classic loop: bit-identical results, repeated launches (timing-dependent hazards)."""
+    A, W, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, std=K ** -0.5).bfloat16(), rnd(N, seed=3)
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    try:
+        lib.roma_tuning(b"gemm8p", 0)
+        base = gemm(lib, Ad, Wd, bias=bd, act=act, dt_in=BF16, dt_out=BF16)
+        lib.roma_tuning(b"gemm8p", 2)
+        for _ in range(4):
+            out = gemm(lib, Ad, Wd, bias=bd, act=act, dt_in=BF16, dt_out=BF16)
+            assert torch.equal(out, base), float((out.float() - base.float()).abs().max())
+    finally:
+        lib.roma_tuning(b"gemm8p", -1)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 70, 70, 256, 512), (3, 56, 60, 128, 256), (2, 72, 70, 64, 256), (1, 108, 108, 512, 512)])
 def test_conv3x3_gemm8p_matches_classic_and_reference(lib, B, H, W, Cin, Cout):
     """3x3 implicit GEMM on the 8-phase kernel (per-tap validity masks, zero page): bitwise vs the classic kernel and
