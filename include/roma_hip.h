@@ -52,7 +52,7 @@ int roma_finalize(roma_handle_t h);
  *         "vit_bf16_residual" (bf16 mode only, default 1: DINOv2 residual stream in bf16 like the reference's bf16
  *         backbone, encoders.py; 0 = keep it in f32),
  *         "streams" (1..4, default 2) / "dual_stream" (1 = 2 streams, 0 = 1): run a batch of >= 2 pairs as sub-batches on
- *         several HIP streams (+7 % at batch 8 with 2; side workspaces are allocated on first use; results are
+ *         several HIP streams (+5 % at batch 8 with 2; side workspaces are allocated on first use; results are
  *         bit-identical to the single-stream schedule - DESIGN.md section 4),
  *         "graph" (default 0; 1 = capture the kernel schedule of each (batch, options) configuration into a hipGraph on
  *         its second call and replay it afterwards: one launch instead of ~1 600, for small batches where match() is

@@ -99,7 +99,7 @@ class Model {
   // Sub-batches on several HIP streams (option "streams" 1..4, "dual_stream" = 2 / 1; env ROMA_STREAMS overrides):
   // pairs are independent, so sub-batch i > 0 runs the same schedule out of its own arenas on side stream i and the
   // partially filled last rounds of one sub-batch's kernels (e.g. 404 GEMM tiles on 256 CUs) are filled by the
-  // others' work: +7 % at batch 8 with 2 streams (profiles/r02_v10_bench_bf16.json vs r02_v6_bench_bf16.json).
+  // others' work: +5 % at batch 8 with 2 streams (profiles/r02_final_bench_bf16.json vs r02_final_bench_bf16_1stream.json).
   // ON by default (2 streams) since round 2: results are bit-identical to the single-stream schedule (2 000 / 2 000 bf16
   // stress runs in the GPU suite; the 1-5 % one-ulp deviations of round 1 went away with the GEMM epilogue rewrite,
   // while the library of the commit before it still shows them on the same box - DESIGN.md section 4).

@@ -101,7 +101,7 @@ class RegressionMatcher:
         # bf16 mode only: DINOv2's residual stream in bf16 like the reference's bf16 backbone (encoders.py casts the
         # backbone weights and input to amp_dtype); False keeps it in f32 (slower, slightly closer to the fp32 result)
         self.vit_bf16_residual = True
-        # batches of >= 2 pairs run as two half-batches on two HIP streams (+7 % at batch 8; bit-identical to the
+        # batches of >= 2 pairs run as two half-batches on two HIP streams (+5 % at batch 8; bit-identical to the
         # single-stream schedule: tests/test_gpu_match.py::test_stream_split_*).  False = one stream, half the workspace
         self.dual_stream = True
         # opt-in: replay the kernel schedule of each (batch, options) configuration as a captured hipGraph from its
