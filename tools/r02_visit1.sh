@@ -9,12 +9,6 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 ( nproc; free -g | head -2; rocm-smi --showclocks 2>/dev/null | head -20 ) > "$OUT/host.txt" 2>&1
 
-echo "== stand-alone 8-phase draft"
-for shp in "25600 1024 1024" "25600 4096 1024" "25600 1024 4096" "8192 4096 4096"; do
-  timeout 90 ./tools/scratch/gemm8p_draft $shp 10 >> "$OUT/draft.log" 2>&1 || echo "draft $shp rc=$?" >> "$OUT/draft.log"
-done
-tail -16 "$OUT/draft.log"
-
 echo "== gemm op tests"
 timeout 420 python -m pytest tests/test_gpu_ops.py -q -x -k "gemm or conv3x3 or qkv" 2>&1 | tail -15 > "$OUT/pytest_gemm.log"; tail -6 "$OUT/pytest_gemm.log"
 
