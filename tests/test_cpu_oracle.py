@@ -127,6 +127,28 @@ def test_oracle_match_keypoints_vs_reference_golden():
         assert np.array_equal(iA.numpy(), g["inds_A_" + name]) and np.array_equal(iB.numpy(), g["inds_B_" + name]), name
 
 
+def test_accuracy_harness_metrics_on_synthetic_planes():
+    """tools/accuracy_harness.py (the reference's MegaDepth dense benchmark metric path, megadepth_dense_benchmark.py:18-45 +
+    utils.py:357-455) on synthetic planar scenes with exact ground truth: perfect matches score EPE ~ 0 / PCK = 1, matches
+    shifted by a known number of pixels land in the right PCK bucket, and the covisibility mask excludes what camera 2
+    cannot see."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import accuracy_harness as AH
+    data = AH.synthetic_planar_batch(2, 96, 128, seed=1)
+    gt = AH.ground_truth_matches(data)
+    gd, p1, p3, p5, prob = AH.geometric_dist(data["im_A_depth"], data["im_B_depth"], data["T_1to2"], data["K1"], data["K2"], gt)
+    assert float(gd.max()) < 1e-3 and float(p1) == 1.0 and 0.3 < float(prob.mean()) <= 1.0
+    off = gt.clone()
+    off[..., 2] += 2 * 2.0 / 128  # 2 pixels to the right in image B
+    gd, p1, p3, p5, _ = AH.geometric_dist(data["im_A_depth"], data["im_B_depth"], data["T_1to2"], data["K1"], data["K2"], off)
+    assert abs(float(gd.mean()) - 2.0) < 1e-3 and float(p1) == 0.0 and float(p3) == 1.0 and float(p5) == 1.0
+    # image B really is image A seen through the true mapping: sampling B at the GT coordinates reproduces A where visible
+    smp = torch.nn.functional.grid_sample(data["im_B"], gt[..., 2:], mode="bilinear", align_corners=False)
+    err = ((smp - data["im_A"]).abs().mean(dim=1) * prob).sum() / prob.sum()
+    assert float(err) < 0.05
+    assert set(AH.check_acceptance({k: v[0] for k, v in AH.ACCEPTANCE.items()}).values()) == {True}
+
+
 def test_tiny_oracle_vs_reference_golden():
     """oracle.tiny_oracle (TinyRoMa inference, romatch/models/tiny.py) against the reference's own TinyRoMa run with the
     seeded stand-in backbone (tests/golden/tiny_reference.npz): both correspondence levels from the stored features
