@@ -52,6 +52,20 @@ def test_tiny_match_end_to_end(built_lib, tag):
     assert float((w1 - warp[:1]).abs().max()) < 1e-4 and float((c1 - cert[:1]).abs().max()) < 1e-4  # for another batch size)
 
 
+def test_tiny_match_demo_size(built_lib):
+    """A 480 x 640 pair (the size class of the reference's demo assets, BASELINE config 1): 4 800 x 4 800 correlation volume
+    per pair on the MFMA GEMM; outputs against the reference's, 1/4 sub-sampled in the golden."""
+    from roma_amd import synthetic
+    g = np.load(os.path.join(GOLDEN, "tiny_reference.npz"))
+    m = _model()
+    inp = synthetic.make_tiny_inputs(1, 480, 640, seed=int(g["c_seed"][0]))
+    warp, cert = m.match(inp["im_A"].cuda(), inp["im_B"].cuda())
+    dw = float((warp[:, ::4, ::4].cpu() - torch.from_numpy(g["c_warp_sub"])).abs().max())
+    dc = float((cert[:, ::4, ::4].cpu() - torch.from_numpy(g["c_cert_sub"])).abs().max())
+    print(f"tiny match 480 x 640: max|dwarp| = {dw:.2e}, max|dcert| = {dc:.2e}")
+    assert dw < TOL and dc < TOL
+
+
 def test_tiny_rejects_cpu_and_missing_backbone(built_lib):
     from roma_amd import TinyRoMa, synthetic, tiny_roma_v1_outdoor
     with pytest.raises(Exception):

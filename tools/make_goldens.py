@@ -305,6 +305,11 @@ def tinyroma_golden():
                     f"{tag}_feat_coarse": np32(torch.cat((cat["coarseA"], cat["coarseB"]), dim=0)),
                     f"{tag}_flow8": np32(cat["flow8"]), f"{tag}_cert8": np32(cat["cert8"]), f"{tag}_flow4": np32(cat["flow4"]),
                     f"{tag}_cert4": np32(cat["cert4"]), f"{tag}_warp": np32(cat["warp"]), f"{tag}_cert": np32(cat["cert"])})
+    # a demo-sized pair (BASELINE config 1 runs 'assets/sacre_coeur_A/B', ~ 480 x 640): end to end only, outputs 1/4 sub-sampled
+    inp = synthetic.make_tiny_inputs(1, 480, 640, seed=5)
+    with torch.inference_mode():
+        warp, cert = model.match(inp["im_A"], inp["im_B"], batched=True)
+    out.update({"c_seed": np.array([5]), "c_warp_sub": np32(warp[:, ::4, ::4]), "c_cert_sub": np32(cert[:, ::4, ::4])})
     np.savez_compressed(os.path.join(GOLD, "tiny_reference.npz"), **out)
     print("tiny_reference.npz", {k: v.shape for k, v in out.items()}, missing)
 
