@@ -7,6 +7,7 @@
 
 #include "../../include/roma_hip.h"
 #include "attention.h"
+#include "conv64.h"
 #include "elementwise.h"
 #include "gemm.h"
 #include "local_corr.h"
@@ -179,6 +180,7 @@ int roma_tuning(const char* key, int value) {
   if (k == "gemm8p") g_gemm_tuning[0] = value;
   else if (k == "gemm_dbg") g_gemm_tuning[1] = value;
   else if (k == "lc_mode") g_lc_mode = value;
+  else if (k == "conv64") g_conv64_mode = value;
   else {
     set_error("roma_tuning: unknown key " + k);
     return ROMA_ERR_ARG;

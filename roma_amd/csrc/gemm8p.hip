@@ -444,8 +444,13 @@ static int launch8p(const GemmArgs& a, hipStream_t stream, const char* epi_name)
 // problem (the caller falls back to gemm.hip), 0 on success, < 0 on error.  `a` is the argument block AFTER
 // gemm_launch's own normalisation (qkv_pad / m_alg already applied).
 int gemm4w_try_launch(const GemmArgs& a, hipStream_t stream);  // gemm4w.hip (experimental; "gemm8p" tuning value 2)
+int conv64_try_launch(const GemmArgs& a, hipStream_t stream);  // conv64.hip (weight-stationary 3x3, Cin = 64)
 
 int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
+  if (a.conv_c == 64) {  // the two widest VGG layers have their own kernel
+    const int rc = conv64_try_launch(a, stream);
+    if (rc <= 0) return rc;
+  }
   static const int use_env = getenv("ROMA_GEMM8P") ? atoi(getenv("ROMA_GEMM8P")) : 1;
   const int use = g_gemm_tuning[0] >= 0 ? g_gemm_tuning[0] : use_env;
   if (!use) return 1;

@@ -263,6 +263,35 @@ def test_conv3x3_gemm8p_matches_classic_and_reference(lib, B, H, W, Cin, Cout):
     assert torch.allclose(outs[1].cpu().double(), ref, atol=3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("B,H,W,Cout", [(2, 9, 11, 64), (1, 16, 16, 128), (3, 56, 60, 64), (3, 56, 60, 128), (2, 131, 200, 64), (2, 70, 129, 128),
+                                        (1, 280, 280, 128), (1, 560, 560, 64)])
+def test_conv3x3_c64_weight_stationary(lib, B, H, W, Cout):
+    """conv64.hip (VGG conv1_2 / conv2_1: Cin 64, weights in registers, rows through a 4-slot LDS ring) against torch conv2d
+    and against the implicit GEMM it replaces: image borders, strips with a ragged last row block, x tiles hanging over the
+    right edge (store count of the vmcnt accounting), images shorter than one strip.  Both accumulate in f32 over the same
+    products; the order differs, so the two device paths agree to one bf16 rounding.  Run twice (timing-dependent races)."""
+    Cin = 64
+    x, w, b = rnd(B, Cin, H, W, seed=1).bfloat16(), rnd(Cout, Cin, 3, 3, seed=2, std=(9 * Cin) ** -0.5).bfloat16(), rnd(Cout, seed=3)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).permute(0, 2, 3, 1)
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().cuda()
+    bd = b.cuda()
+    outs = []
+    try:
+        for mode in (0, 1, 1):
+            lib.roma_tuning(b"conv64", mode)
+            out = torch.full((B, H, W, Cout), -7.0, device="cuda", dtype=torch.bfloat16)
+            ok(lib, lib.roma_op_conv3x3(P(xin), P(wp), P(bd), P(out), B, H, W, Cin, Cout, 1, BF16, None))
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        lib.roma_tuning(b"conv64", -1)
+    assert torch.equal(outs[1], outs[2])
+    assert torch.allclose(outs[1].cpu().double(), ref, atol=3e-2, rtol=3e-2)
+    d = (outs[1].float() - outs[0].float()).abs()
+    assert float((d / (outs[0].float().abs() + 1.0)).max()) <= 2.0 ** -7, float(d.max())
+
+
 def _attention_case(lib, B, heads, hd, N, dt):
     D = heads * hd
     tdt = torch.float32 if dt == F32 else torch.bfloat16
