@@ -14,8 +14,10 @@
 //   * per output row: wait for input row y + 1 (issued one row earlier), barrier, issue row y + 2 into the slot row y - 2
 //     left, then 9 taps x (8 fragment reads, wait, 8 MFMAs); the reads of tap t + 1 are issued right behind the MFMAs of
 //     tap t.  Ring reads are inline asm (hipcc would drain the DMA queue before any LDS read that may alias a DMA target).
-//   * LDS position (pixel p, chunk c) of a ring row holds source chunk c ^ (p & 7): the 32 pixels of a fragment read are
-//     128 bytes apart, the swizzle spreads them over all banks.
+//   * LDS position (pixel p, chunk c) of a ring row holds source chunk c ^ ((p >> 1) & 7).  Pixels are 128 bytes apart, so
+//     two of them share a 256-byte bank row; a ds_read_b128 lane group is 16 lanes whose pixels are distinct mod 16
+//     (MI355X_MICROARCH.md, LDS table), and (p & 1, c ^ ((p >> 1) & 7)) gives those 16 pixels 16 different 16-byte slots.
+//     (The first version swizzled by p & 7: 8 classes for 16 lanes, every read 2-way conflicted - 720 -> see DESIGN.md.)
 //   * output: bias + ReLU + bf16 pack in registers, 8-byte stores (4 channels of one pixel per lane).
 #include "conv64.h"
 
@@ -28,8 +30,7 @@
 
 namespace roma {
 
-static __device__ __attribute__((aligned(256))) unsigned int g_c64_zero[64];   // zero source of out-of-image pixels
-static __device__ __attribute__((aligned(256))) unsigned int g_c64_dump[128];  // where lanes right of the image store
+static __device__ __attribute__((aligned(256))) unsigned int g_c64_dump[256];  // where lanes right of the image store
 
 int g_conv64_mode = -1;
 
@@ -45,25 +46,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const bf16_t* __res
   constexpr int NPIECE = ((TW + 2) * 128 + 1023) / 1024;  // 1 KiB DMA pieces per ring row (17 ; 9)
   constexpr int RSTRIDE = NPIECE * 1024;
   constexpr int KW = (NPIECE + 3) / 4;  // pieces of the busiest wave (5 ; 3)
-  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];  // [4][RSTRIDE]
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];  // [4][RSTRIDE], then the bias
 
-  const long lb = blockIdx.x;
-  if (lb >= nblocks) return;
-  const int xt = (int)(lb % nxt);
-  long r = lb / nxt;
-  const int yt = (H + SY - 1) / SY;
-  const int ys = (int)(r % yt) * SY;
-  const int b = (int)(r / yt);
-  const int x0 = xt * TW;
-  const int sy = min(SY, H - ys);
-
+  if ((int)blockIdx.x >= nblocks) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cg = wave % NCG, pg = wave / NCG;
   const int l31 = lane & 31, h = lane >> 5;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned ring0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)ring);
 
   // ---- this wave's weights: W[32 cg + l31][k = 16 ks + 8 h .. + 8), ks = tap * 4 + g  -> 36 x 16 bytes per lane
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   u32x4 wreg[36];
   {
     const bf16_t* wp = w + (long)(32 * cg + l31) * 576 + 8 * h;
@@ -73,50 +66,90 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const bf16_t* __res
   // bias lives in LDS behind the ring (registers are for W): channels 32 cg + 8 rg + 4 h + [0, 4) are read per output row
   float* bias_s = reinterpret_cast<float*>(ring + 4 * RSTRIDE);
   if (tid < COUT) bias_s[tid] = bias[tid];
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the ordinary loads are retired before the first DMA is counted
 
-  // ---- DMA of one input row (image row yy, may be outside the image) into ring slot `slot`: pieces wave, wave + 4, ...
-  const char* zsrc = reinterpret_cast<const char*>(g_c64_zero);
-  const bf16_t* inb = in + (long)b * H * W * 64;
-  const int dl_p = lane >> 3, dl_slot = lane & 7;  // lane -> (pixel of the piece, 16-byte slot)
-#define C64_ISSUE_ROW(YY, SLOT)                                                                                \
-  {                                                                                                            \
-    const int yy_ = (YY);                                                                                      \
-    const bool rok_ = yy_ >= 0 && yy_ < H;                                                                     \
-    _Pragma("unroll") for (int j = 0; j < KW; ++j) {                                                           \
-      const int q_ = wave + 4 * j;                                                                             \
-      if (q_ < NPIECE) {                                                                                       \
-        const int p_ = q_ * 8 + dl_p;           /* ring pixel 0 .. TW + 1 (beyond: padding of the last piece) */ \
-        const int x_ = x0 - 1 + p_;                                                                            \
-        const int c_ = dl_slot ^ (p_ & 7);                                                                     \
-        const bool ok_ = rok_ && p_ < TW + 2 && x_ >= 0 && x_ < W;                                             \
-        const char* s_ = ok_ ? reinterpret_cast<const char*>(inb + ((long)yy_ * W + x_) * 64 + c_ * 8) : zsrc + dl_slot * 16; \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s_,                    \
-                                         (__attribute__((address_space(3))) void*)(ring + (SLOT) * RSTRIDE + q_ * 1024), 16, 0, 0); \
-      }                                                                                                        \
-    }                                                                                                          \
-  }
-
-  // ---- fragment read offsets inside a ring row: pixel p = 64 pg + l31 + dx (+ 32 tm), chunk 2 g + h
-  const unsigned ring0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)ring);
-  // offset of chunk (2 g + h) ^ (p & 7) = (chunk h ^ (p & 7)) with bits 5-6 flipped by g: one register per dx
+  // ---- fragment read offsets inside a ring row: pixel p = 64 pg + l31 + dx (+ 32 tm), chunk 2 g + h.
+  // offset of chunk (2 g + h) ^ s(p) = (chunk h ^ s(p)) with bits 5-6 flipped by g: one register per dx
   unsigned rdo[3];
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) {
     const int p = 64 * pg + l31 + dx;
-    rdo[dx] = ring0 + (unsigned)(p * 128 + ((h ^ (p & 7)) << 4));
+    rdo[dx] = ring0 + (unsigned)(p * 128 + ((h ^ ((p >> 1) & 7)) << 4));
   }
-  u32x4 fa[2][4];  // [tm][g] fragments of the current tap
-#define C64_READ_TAP(SLOTOFF, DX)                                                                             \
-  _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                             \
-    const unsigned ad_ = (rdo[DX] + (SLOTOFF)) ^ (unsigned)(g << 5);                                           \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0][g]) : "v"(ad_));                                           \
-    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fa[1][g]) : "v"(ad_));                              \
+
+  // ---- persistent over strips (SY rows x TW pixels of one image): the weights are fetched once per workgroup
+  for (int lb = blockIdx.x; lb < nblocks; lb += gridDim.x) {
+  const int xt = lb % nxt;
+  const int r = lb / nxt;
+  const int yt = (H + SY - 1) / SY;
+  const int ys = (r % yt) * SY;
+  const int b = r / yt;
+  const int x0 = xt * TW;
+  const int sy = min(SY, H - ys);
+  if (lb != (int)blockIdx.x) __builtin_amdgcn_s_barrier();  // every wave is past the last ring read of the strip before
+
+  // ---- DMA geometry, fixed for the strip: piece q = wave + 4 j of a ring row, lane -> (pixel q * 8 + lane / 8, 16-byte
+  // slot lane % 8).  Lanes whose pixel is outside the image (left / right halo at the image border, padding behind the last
+  // pixel) are switched off in every DMA; their ring positions are zeroed once, here, in all four slots.
+  const bf16_t* inb = in + (long)b * H * W * 64;
+  unsigned voff[KW];  // byte offset of the lane's source chunk inside an image row
+  bool okx[KW];
+  {
+    const int dl_p = lane >> 3, dl_slot = lane & 7;
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < KW; ++j) {
+      const int q = wave + 4 * j;
+      const int p = q * 8 + dl_p;  // ring pixel 0 .. TW + 1 (beyond: padding of the last piece)
+      const int x = x0 - 1 + p;
+      const int c = dl_slot ^ ((p >> 1) & 7);
+      okx[j] = q < NPIECE && p < TW + 2 && x >= 0 && x < W;
+      voff[j] = okx[j] ? (unsigned)(x * 128 + c * 16) : 0u;
+      if (q < NPIECE && !okx[j]) {
+        int ln = lane;  // opaque: the address is computed here, not hoisted to kernel entry and parked in scratch
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+          asm volatile("ds_write_b128 %0, %1" ::"v"(ring0 + sl * RSTRIDE + q * 1024 + ln * 16), "v"(z4) : "memory");
+      }
+    }
   }
-#define C64_WAIT_FRAGS()                                                                                       \
-  asm volatile("s_waitcnt lgkmcnt(0)"                                                                          \
-               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]), "+v"(fa[1][1]), \
-                 "+v"(fa[1][2]), "+v"(fa[1][3])::"memory")
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the ordinary loads are retired before the first DMA is counted
+
+  // one input row (image row YY, may be outside the image: zeros) into ring slot SLOT
+#define C64_ISSUE_ROW(YY, SLOT)                                                                                \
+  {                                                                                                            \
+    const int yy_ = (YY);                                                                                      \
+    if (yy_ >= 0 && yy_ < H) {                                                                                 \
+      const char* rowp_ = reinterpret_cast<const char*>(inb + (long)yy_ * W * 64);                            \
+      _Pragma("unroll") for (int j = 0; j < KW; ++j) {                                                         \
+        const int q_ = wave + 4 * j;                                                                           \
+        if (q_ < NPIECE) {                                                                                     \
+          if (okx[j])                                                                                          \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp_ + voff[j]), \
+                                             (__attribute__((address_space(3))) void*)(ring + (SLOT) * RSTRIDE + q_ * 1024), 16, 0, 0); \
+        }                                                                                                      \
+      }                                                                                                        \
+    } else { /* rows above / below the image (first and last strip only) */                                    \
+      const u32x4 z4_ = {0u, 0u, 0u, 0u};                                                                      \
+      int ln_ = lane;                                                                                          \
+      asm volatile("" : "+v"(ln_));                                                                            \
+      _Pragma("unroll") for (int j = 0; j < KW; ++j) {                                                         \
+        const int q_ = wave + 4 * j;                                                                           \
+        if (q_ < NPIECE)                                                                                       \
+          asm volatile("ds_write_b128 %0, %1" ::"v"(ring0 + (SLOT) * RSTRIDE + q_ * 1024 + ln_ * 16), "v"(z4_) : "memory"); \
+      }                                                                                                        \
+    }                                                                                                          \
+  }
+
+  u32x4 fa[2][4];  // [tm][g] fragments: group g of the current tap until its MFMAs are issued, then of the next tap
+#define C64_READ_G(SLOTOFF, DX, G)                                                                            \
+  {                                                                                                           \
+    const unsigned ad_ = (rdo[DX] + (SLOTOFF)) ^ (unsigned)((G) << 5);                                         \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0][G]) : "v"(ad_));                                           \
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fa[1][G]) : "v"(ad_));                              \
+  }
+  // the two reads of group G are the oldest of the eight in flight (six younger ones: the rest of this tap, the head of the next)
+#define C64_WAIT_G(G, N) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[0][G]), "+v"(fa[1][G]) : "n"(N) : "memory")
 
   // ---- prologue: input rows ys - 1, ys, ys + 1 (ring slot = (row - ys + 1) & 3)
   C64_ISSUE_ROW(ys - 1, 0)
@@ -125,72 +158,92 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const bf16_t* __res
 
   bf16_t* outb = out + (long)b * H * W * COUT;
   for (int o = 0; o < sy; ++o) {
-    // input row ys + o + 1 (the last of this output row's three) was issued one iteration ago, behind it only the 8
+    // input row ys + o + 1 (the last of this output row's three) was issued one iteration ago, behind it only the 4
     // output stores of that iteration; first iteration: everything the prologue issued
     if (o == 0) {
-      C64_WAIT_VM(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     } else {
-      C64_WAIT_VM(8);
+      C64_WAIT_VM(4);
     }
     __builtin_amdgcn_s_barrier();
     C64_ISSUE_ROW(ys + o + 2, (o + 3) & 3)  // into the slot of input row ys + o - 2: every wave is past its last read
+    if (o == 0) {  // later rows: the first half of tap 0 was requested behind the last tap of the row before
+      C64_READ_G(0, 0, 0)
+      C64_READ_G(0, 0, 1)
+    }
+    C64_READ_G((o & 3) * RSTRIDE, 0, 2)
+    C64_READ_G((o & 3) * RSTRIDE, 0, 3)
 
     f32x16 acc[2];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[tm][e] = 0.f;
-    {
-      const unsigned s0 = ((o + 0) & 3) * RSTRIDE;
-      C64_READ_TAP(s0, 0)
-    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      C64_WAIT_FRAGS();
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 4; ++g) {
+        // younger reads in flight behind group g's two: 6 (rest of this tap + head of the next), except for the very last
+        // group of the row, behind which only the half tap of the next row was requested (4).  Where fewer are in flight
+        // (row start) the wait merely asks for more than it needs.
+        if (t == 8 && g == 3) {
+          C64_WAIT_G(g, 4);
+        } else {
+          C64_WAIT_G(g, 6);
+        }
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
           acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[t * 4 + g]),
                                                             __builtin_bit_cast(bf16x8_t, fa[tm][g]), acc[tm], 0, 0, 0);
-      // the next tap's reads overwrite fa behind the ISSUED MFMAs (operands are read at issue, LDS data returns >= 64 cycles later)
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < 9) {
-        const unsigned sn = ((o + (t + 1) / 3) & 3) * RSTRIDE;
-        C64_READ_TAP(sn, (t + 1) % 3)
+        // group g of the next tap overwrites fa[.][g] behind the ISSUED MFMAs (operands are read at issue, LDS data comes
+        // back >= 64 cycles later); behind the last tap: tap 0 of the next output row, whose ring row is already resident.
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < 9) {
+          C64_READ_G(((o + (t + 1) / 3) & 3) * RSTRIDE, (t + 1) % 3, g)
+        } else if (g < 2) {  // (the other half after the epilogue: 16 registers it needs)
+          C64_READ_G(((o + 1) & 3) * RSTRIDE, 0, g)
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 
-    // ---- bias + ReLU + bf16, 8-byte stores: lane = (pixel l31 of block tm, channels 8 rg + 4 h + [0, 4))
+    // ---- bias + ReLU + bf16.  A lane holds channels 8 rg + 4 h + [0, 4) of pixel l31; v_permlane32_swap pairs the two
+    // halves of a wave so that lane (l31, h) ends up with the 8 consecutive channels 16 P + 8 h + [0, 8): 16-byte stores,
+    // 32 contiguous bytes per pixel and instruction.  Exactly 4 store instructions per wave and row, whatever the lanes'
+    // validity (the vmcnt above counts on it): lanes right of the image store into a dump buffer.
     const int y = ys + o;
-    f32x4 bv[4];
-    {
-      const unsigned ba = ring0 + 4 * RSTRIDE + (32 * cg + 4 * h) * 4;
-      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
-                   "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]), "=&v"(bv[3])
-                   : "v"(ba)
-                   : "memory");
-    }
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      const int x = x0 + 64 * pg + 32 * tm + l31;
-      bf16_t* op = outb + ((long)y * W + x) * COUT + 32 * cg + 4 * h;
+    for (int P = 0; P < 2; ++P) {
+      f32x4 bv0, bv1;
+      {
+        const unsigned ba = ring0 + 4 * RSTRIDE + (32 * cg + 16 * P + 4 * h) * 4;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(bv0), "=&v"(bv1)
+                     : "v"(ba)
+                     : "memory");
+      }
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        uint2 pk;
-        pk.x = pack_bf16x2(fmaxf(acc[tm][4 * rg + 0] + bv[rg][0], 0.f), fmaxf(acc[tm][4 * rg + 1] + bv[rg][1], 0.f));
-        pk.y = pack_bf16x2(fmaxf(acc[tm][4 * rg + 2] + bv[rg][2], 0.f), fmaxf(acc[tm][4 * rg + 3] + bv[rg][3], 0.f));
-        // exactly 8 store instructions per wave and row, whatever the lanes' validity (the vmcnt above counts on it):
-        // lanes right of the image store into a dump buffer
-        uint2* dst = x < W ? reinterpret_cast<uint2*>(op + 8 * rg) : reinterpret_cast<uint2*>(g_c64_dump) + lane;
-        *dst = pk;
+      for (int tm = 0; tm < 2; ++tm) {
+        const int x = x0 + 64 * pg + 32 * tm + l31;
+        const unsigned a0 = pack_bf16x2(fmaxf(acc[tm][8 * P + 0] + bv0[0], 0.f), fmaxf(acc[tm][8 * P + 1] + bv0[1], 0.f));
+        const unsigned a1 = pack_bf16x2(fmaxf(acc[tm][8 * P + 2] + bv0[2], 0.f), fmaxf(acc[tm][8 * P + 3] + bv0[3], 0.f));
+        const unsigned b0 = pack_bf16x2(fmaxf(acc[tm][8 * P + 4] + bv1[0], 0.f), fmaxf(acc[tm][8 * P + 5] + bv1[1], 0.f));
+        const unsigned b1 = pack_bf16x2(fmaxf(acc[tm][8 * P + 6] + bv1[2], 0.f), fmaxf(acc[tm][8 * P + 7] + bv1[3], 0.f));
+        // swap(a, b): lanes 32-63 of a <-> lanes 0-31 of b.  h = 0 keeps its rg = 2P data and receives the partner's
+        // rg = 2P (channels + 4); h = 1 receives the partner's rg = 2P + 1 and keeps its own.
+        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        const u32x4 st = {s0[0], s1[0], s0[1], s1[1]};
+        bf16_t* op = outb + ((long)y * W + x) * COUT + 32 * cg + 16 * P + 8 * h;
+        u32x4* dst = x < W ? reinterpret_cast<u32x4*>(op) : reinterpret_cast<u32x4*>(g_c64_dump) + lane;
+        *dst = st;  // (a non-temporal hint here DOUBLES the kernel's time: the 32-byte pieces then reach HBM unmerged)
       }
     }
   }
-  C64_WAIT_VM(0);  // trailing DMA must not outlive the workgroup's LDS
-#undef C64_WAIT_FRAGS
-#undef C64_READ_TAP
+  C64_WAIT_VM(0);  // trailing DMA (rows below the strip) must neither outlive the workgroup's LDS nor land in the next strip
+  }  // strips
+#undef C64_WAIT_G
+#undef C64_READ_G
 #undef C64_ISSUE_ROW
 }
 
@@ -207,8 +260,24 @@ int conv64_try_launch(const GemmArgs& a, hipStream_t stream) {
   if (hw <= 0 || a.M % hw != 0) return 1;
   const int B = (int)(a.M / hw);
   const int TW = a.N == 64 ? 128 : 64;
-  const int SY = H >= 128 ? 32 : 16;
+  static const int sy_env = getenv("ROMA_CONV64_SY") ? atoi(getenv("ROMA_CONV64_SY")) : 0;
   const int nxt = (W + TW - 1) / TW;
+  // strip height: 512 persistent workgroups take the strips round-robin, so the launch lasts rounds x (SY + ~3 rows of ring
+  // prologue); pick the split of H that minimises it (432 rows, 112 columns of strips: 9 strips of 48 rows fill 1.97 rounds,
+  // where 14 strips of 32 would leave the fourth round 6 % full)
+  int SY = sy_env;
+  if (SY <= 0) {
+    long best = -1;
+    for (int yt = 1; yt <= std::max(1, H / 12); ++yt) {
+      const int sy = (H + yt - 1) / yt;
+      const long n = (long)B * nxt * ((H + sy - 1) / sy);
+      const long cost = ((n + 511) / 512) * (sy + 3);
+      if (best < 0 || cost < best) {
+        best = cost;
+        SY = sy;
+      }
+    }
+  }
   const long nb = (long)B * ((H + SY - 1) / SY) * nxt;
   if (nb <= 0 || nb >= (1l << 30)) return 1;
   char pname[64];
@@ -226,10 +295,11 @@ int conv64_try_launch(const GemmArgs& a, hipStream_t stream) {
     ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 9 * 1024 + 512));
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
+  const long gx = std::min<long>(nb, 512);  // two workgroups per CU, persistent over the strips
   if (a.N == 64) {
-    hipLaunchKernelGGL(conv3x3_c64_kernel<64>, dim3((unsigned)nb), dim3(256), lds, stream, in, w, a.bias, out, B, H, W, SY, nxt, (int)nb);
+    hipLaunchKernelGGL(conv3x3_c64_kernel<64>, dim3((unsigned)gx), dim3(256), lds, stream, in, w, a.bias, out, B, H, W, SY, nxt, (int)nb);
   } else {
-    hipLaunchKernelGGL(conv3x3_c64_kernel<128>, dim3((unsigned)nb), dim3(256), lds, stream, in, w, a.bias, out, B, H, W, SY, nxt, (int)nb);
+    hipLaunchKernelGGL(conv3x3_c64_kernel<128>, dim3((unsigned)gx), dim3(256), lds, stream, in, w, a.bias, out, B, H, W, SY, nxt, (int)nb);
   }
   ROMA_LAUNCH_CHECK();
   return 0;

@@ -295,11 +295,13 @@ def test_hot_gemm_kernels_do_not_spill(built_lib):
     below rejects scratch traffic between the MFMAs)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources
-    objs = {f: os.path.join(ROOT, "roma_amd", "csrc", "build", f) for f in ("gemm8p.o", "gemm6p.o")}
+    objs = {f: os.path.join(ROOT, "roma_amd", "csrc", "build", f) for f in ("gemm8p.o", "gemm6p.o", "conv64.o")}
     if not all(os.path.exists(o) for o in objs.values()):
         pytest.skip("object files not present (library shipped pre-built)")
     k6 = kernel_resources.kernels(objs["gemm6p.o"])
     assert len(k6) >= 4 and all(k["spill"] == 0 and k["scratch"] == 0 for k in k6), k6
+    k64 = kernel_resources.kernels(objs["conv64.o"])  # 144 weight registers + 64 for accumulators and fragments: 250 of 256
+    assert len(k64) == 2 and all(k["spill"] == 0 and k["scratch"] == 0 for k in k64), k64
     k8 = [k for k in kernel_resources.kernels(objs["gemm8p.o"]) if k["name"].startswith("gemm8p_kernel<bf16")]
     assert len(k8) >= 6
     for k in k8:
@@ -312,10 +314,10 @@ def test_isa_audit_no_touch_of_registers_with_asm_lds_reads_in_flight(built_lib)
     not track; the construct is only correct if nothing touches those registers before our s_waitcnt (the round-1 f32
     "carried k-group" miscompile: compiler-made v_mov copies of in-flight registers, profiles/r02_f32_carry_isa_excerpt.txt).
     tools/audit_asm_reads.py checks that in the ISA of the objects the library is linked from - on every build."""
-    objs = [os.path.join(ROOT, "roma_amd", "csrc", "build", f) for f in ("gemm.o", "gemm8p.o", "gemm6p.o", "gemm4w.o")]
+    objs = [os.path.join(ROOT, "roma_amd", "csrc", "build", f) for f in ("gemm.o", "gemm8p.o", "gemm6p.o", "gemm4w.o", "conv64.o")]
     if not all(os.path.exists(o) for o in objs):
         pytest.skip("object files not present (library shipped pre-built)")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_reads.py")] + objs, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and "AUDIT OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
-    assert out.stdout.count("clean") >= 57  # 45 gemm.hip + the gemm8p / gemm6p / gemm4w instantiations were actually inspected
+    assert out.stdout.count("clean") >= 59  # 45 gemm.hip + the gemm8p / gemm6p / gemm4w / conv64 instantiations were actually inspected
