@@ -247,31 +247,257 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const bf16_t* __res
 #undef C64_ISSUE_ROW
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Cin = 128, Cout = 128 (VGG conv2_2).  The weights are 288 KiB: exactly the 8 x 144 weight registers of EIGHT waves, so a
+// workgroup is 512 threads, wave = (channel quarter cg, Cin half kh), and each wave multiplies its 32 output channels by
+// its 64 input channels over all 9 taps (the same 72 MFMAs per output row as above).  The two kh waves of a quarter hold
+// partial sums of the same 32 x 64 outputs: each writes the pixel block the OTHER finishes (tm = 1 - kh) into an LDS
+// exchange buffer after its last tap; the row's barrier (the one the ring needs anyway) publishes it, and behind the
+// barrier each wave adds its partner's block to its own (tm = kh), applies bias + ReLU and stores - i.e. the epilogue of
+// row o runs at the top of row o + 1 and needs no barrier of its own.  The exchange buffers alternate with the row parity
+// (a wave two taps ahead must not overwrite what its partner has not read).
+// Ring: 4 slots x 66 pixels x 256 B; a pixel is one 256-byte bank row, position (p, c) holds source chunk c ^ (p & 15).
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void conv3x3_c128_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ w,
+                                                              const float* __restrict__ bias, bf16_t* __restrict__ out, int B,
+                                                              int H, int W, int SY, int nxt, int nblocks) {
+  constexpr int COUT = 128, TW = 64;
+  constexpr int NPIECE = ((TW + 2) * 256 + 1023) / 1024;  // 17
+  constexpr int RSTRIDE = NPIECE * 1024;
+  constexpr int KW = (NPIECE + 7) / 8;  // 3
+  constexpr int XCH = 4 * RSTRIDE;      // exchange buffers: [parity][wave][4 KiB]
+  constexpr int BIAS = XCH + 2 * 8 * 4096;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+  if ((int)blockIdx.x >= nblocks) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = wave & 3, kh = wave >> 2;
+  const int l31 = lane & 31, h = lane >> 5;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned ring0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)ring);
+
+  // W[32 cg + l31][k = tap * 128 + 64 kh + 16 g + 8 h .. + 8)
+  u32x4 wreg[36];
+  {
+    const bf16_t* wp = w + (long)(32 * cg + l31) * 1152 + 64 * kh + 8 * h;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) wreg[t * 4 + g] = *reinterpret_cast<const u32x4*>(wp + 128 * t + 16 * g);
+  }
+  float* bias_s = reinterpret_cast<float*>(ring + BIAS);
+  if (tid < COUT) bias_s[tid] = bias[tid];
+
+  unsigned rdo[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int p = l31 + dx;
+    rdo[dx] = ring0 + (unsigned)(p * 256 + (((8 * kh + h) ^ (p & 15)) << 4));
+  }
+  // exchange addresses: lane-contiguous 16-byte pieces, 4 per lane (j * 1 KiB apart)
+  const unsigned xw = ring0 + XCH + (unsigned)((cg + 4 * (1 - kh)) * 4096 + lane * 16);  // what the partner will finish
+  const unsigned xr = ring0 + XCH + (unsigned)((cg + 4 * kh) * 4096 + lane * 16);        // what the partner left for this wave
+
+  for (int lb = blockIdx.x; lb < nblocks; lb += gridDim.x) {
+  const int xt = lb % nxt;
+  const int r = lb / nxt;
+  const int yt = (H + SY - 1) / SY;
+  const int ys = (r % yt) * SY;
+  const int b = r / yt;
+  const int x0 = xt * TW;
+  const int sy = min(SY, H - ys);
+  if (lb != (int)blockIdx.x) __builtin_amdgcn_s_barrier();
+
+  const bf16_t* inb = in + (long)b * H * W * 128;
+  unsigned voff[KW];
+  bool okx[KW];
+  {
+    const int dl_p = lane >> 4, dl_slot = lane & 15;
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < KW; ++j) {
+      const int q = wave + 8 * j;
+      const int p = q * 4 + dl_p;
+      const int x = x0 - 1 + p;
+      const int c = dl_slot ^ (p & 15);
+      okx[j] = q < NPIECE && p < TW + 2 && x >= 0 && x < W;
+      voff[j] = okx[j] ? (unsigned)(x * 256 + c * 16) : 0u;
+      if (q < NPIECE && !okx[j]) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+          asm volatile("ds_write_b128 %0, %1" ::"v"(ring0 + sl * RSTRIDE + q * 1024 + ln * 16), "v"(z4) : "memory");
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+#define C128_ISSUE_ROW(YY, SLOT)                                                                               \
+  {                                                                                                            \
+    const int yy_ = (YY);                                                                                      \
+    if (yy_ >= 0 && yy_ < H) {                                                                                 \
+      const char* rowp_ = reinterpret_cast<const char*>(inb + (long)yy_ * W * 128);                           \
+      _Pragma("unroll") for (int j = 0; j < KW; ++j) {                                                         \
+        const int q_ = wave + 8 * j;                                                                           \
+        if (q_ < NPIECE) {                                                                                     \
+          if (okx[j])                                                                                          \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp_ + voff[j]), \
+                                             (__attribute__((address_space(3))) void*)(ring + (SLOT) * RSTRIDE + q_ * 1024), 16, 0, 0); \
+        }                                                                                                      \
+      }                                                                                                        \
+    } else {                                                                                                   \
+      const u32x4 z4_ = {0u, 0u, 0u, 0u};                                                                      \
+      int ln_ = lane;                                                                                          \
+      asm volatile("" : "+v"(ln_));                                                                            \
+      _Pragma("unroll") for (int j = 0; j < KW; ++j) {                                                         \
+        const int q_ = wave + 8 * j;                                                                           \
+        if (q_ < NPIECE)                                                                                       \
+          asm volatile("ds_write_b128 %0, %1" ::"v"(ring0 + (SLOT) * RSTRIDE + q_ * 1024 + ln_ * 16), "v"(z4_) : "memory"); \
+      }                                                                                                        \
+    }                                                                                                          \
+  }
+
+  u32x4 fa[2][4];
+#define C128_READ_G(SLOTOFF, DX, G)                                                                           \
+  {                                                                                                           \
+    const unsigned ad_ = (rdo[DX] + (SLOTOFF)) ^ (unsigned)((G) << 5);                                         \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0][G]) : "v"(ad_));                                           \
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fa[1][G]) : "v"(ad_));                              \
+  }
+#define C128_WAIT_G(G, N) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[0][G]), "+v"(fa[1][G]) : "n"(N) : "memory")
+
+  // finish output row Y from this wave's block ACC and the partner's partial sums in exchange buffer PAR
+  bf16_t* outb = out + (long)b * H * W * COUT;
+#define C128_EPILOGUE(ACC, Y, PAR)                                                                            \
+  {                                                                                                           \
+    f32x4 pp_[4];                                                                                             \
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t" \
+                 "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"                                    \
+                 : "=&v"(pp_[0]), "=&v"(pp_[1]), "=&v"(pp_[2]), "=&v"(pp_[3])                                 \
+                 : "v"(xr + (unsigned)(PAR) * 32768u)                                                         \
+                 : "memory");                                                                                 \
+    const int x_ = x0 + 32 * kh + l31;                                                                        \
+    _Pragma("unroll") for (int P = 0; P < 2; ++P) {                                                           \
+      f32x4 bv0_, bv1_;                                                                                       \
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)"            \
+                   : "=&v"(bv0_), "=&v"(bv1_)                                                                 \
+                   : "v"(ring0 + BIAS + (32 * cg + 16 * P + 4 * h) * 4)                                       \
+                   : "memory");                                                                               \
+      const f32x4 p0_ = pp_[2 * P], p1_ = pp_[2 * P + 1];                                                     \
+      const unsigned a0_ = pack_bf16x2(fmaxf(ACC[8 * P + 0] + p0_[0] + bv0_[0], 0.f), fmaxf(ACC[8 * P + 1] + p0_[1] + bv0_[1], 0.f)); \
+      const unsigned a1_ = pack_bf16x2(fmaxf(ACC[8 * P + 2] + p0_[2] + bv0_[2], 0.f), fmaxf(ACC[8 * P + 3] + p0_[3] + bv0_[3], 0.f)); \
+      const unsigned b0_ = pack_bf16x2(fmaxf(ACC[8 * P + 4] + p1_[0] + bv1_[0], 0.f), fmaxf(ACC[8 * P + 5] + p1_[1] + bv1_[1], 0.f)); \
+      const unsigned b1_ = pack_bf16x2(fmaxf(ACC[8 * P + 6] + p1_[2] + bv1_[2], 0.f), fmaxf(ACC[8 * P + 7] + p1_[3] + bv1_[3], 0.f)); \
+      const auto s0_ = __builtin_amdgcn_permlane32_swap(a0_, b0_, false, false);                              \
+      const auto s1_ = __builtin_amdgcn_permlane32_swap(a1_, b1_, false, false);                              \
+      const u32x4 st_ = {s0_[0], s1_[0], s0_[1], s1_[1]};                                                     \
+      bf16_t* op_ = outb + ((long)(Y) * W + x_) * COUT + 32 * cg + 16 * P + 8 * h;                            \
+      u32x4* dst_ = x_ < W ? reinterpret_cast<u32x4*>(op_) : reinterpret_cast<u32x4*>(g_c64_dump) + lane;     \
+      *dst_ = st_;                                                                                            \
+    }                                                                                                         \
+  }
+  // hand the block the partner finishes to the exchange buffer of parity PAR
+#define C128_PUBLISH(ACC, PAR)                                                                                \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
+    const f32x4 v_ = {ACC[4 * j + 0], ACC[4 * j + 1], ACC[4 * j + 2], ACC[4 * j + 3]};                        \
+    asm volatile("ds_write_b128 %0, %1" ::"v"(xw + (unsigned)(PAR) * 32768u + j * 1024), "v"(v_) : "memory"); \
+  }
+
+  C128_ISSUE_ROW(ys - 1, 0)
+  C128_ISSUE_ROW(ys, 1)
+  C128_ISSUE_ROW(ys + 1, 2)
+
+  f32x16 acc[2];
+  for (int o = 0; o < sy; ++o) {
+    // the row DMA issued one iteration ago is the youngest memory operation of this wave (the stores of the epilogue
+    // went out before it); the LDS writes of the exchange are retired before the barrier publishes them
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (o > 0) {
+      if (kh == 0) C128_EPILOGUE(acc[0], ys + o - 1, (o - 1) & 1)
+      else C128_EPILOGUE(acc[1], ys + o - 1, (o - 1) & 1)
+    }
+    C128_ISSUE_ROW(ys + o + 2, (o + 3) & 3)
+    if (o == 0) {
+      C128_READ_G(0, 0, 0)
+      C128_READ_G(0, 0, 1)
+    }
+    C128_READ_G((o & 3) * RSTRIDE, 0, 2)
+    C128_READ_G((o & 3) * RSTRIDE, 0, 3)
+
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[tm][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (t == 8 && g == 3) {
+          C128_WAIT_G(g, 4);
+        } else {
+          C128_WAIT_G(g, 6);
+        }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[t * 4 + g]),
+                                                            __builtin_bit_cast(bf16x8_t, fa[tm][g]), acc[tm], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < 9) {
+          C128_READ_G(((o + (t + 1) / 3) & 3) * RSTRIDE, (t + 1) % 3, g)
+        } else if (g < 2) {
+          C128_READ_G(((o + 1) & 3) * RSTRIDE, 0, g)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (kh == 0) C128_PUBLISH(acc[1], o & 1)
+    else C128_PUBLISH(acc[0], o & 1)
+  }
+  // last row of the strip
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (kh == 0) C128_EPILOGUE(acc[0], ys + sy - 1, (sy - 1) & 1)
+  else C128_EPILOGUE(acc[1], ys + sy - 1, (sy - 1) & 1)
+  C64_WAIT_VM(0);
+  }  // strips
+#undef C128_PUBLISH
+#undef C128_EPILOGUE
+#undef C128_WAIT_G
+#undef C128_READ_G
+#undef C128_ISSUE_ROW
+}
+
 // 0 = launched, 1 = not this kernel's problem
 int conv64_try_launch(const GemmArgs& a, hipStream_t stream) {
-  static const int use_env = getenv("ROMA_CONV64") ? atoi(getenv("ROMA_CONV64")) : 1;
-  if (!(g_conv64_mode >= 0 ? g_conv64_mode : use_env)) return 1;
-  if (a.conv_c != 64 || a.in_dt != DT_BF16 || a.out_dt != DT_BF16 || a.act != ACT_RELU || !a.bias) return 1;
-  if ((a.N != 64 && a.N != 128) || a.ldc != a.N || a.ldw != 576 || a.batch != 1 || a.mode != EPI_STD || a.scale || a.res ||
-      a.res_bf16 || a.alpha != 1.0f)
+  static const int use_env = getenv("ROMA_CONV64") ? atoi(getenv("ROMA_CONV64")) : 3;
+  const int use = g_conv64_mode >= 0 ? g_conv64_mode : use_env;  // bit 0: Cin = 64 kernels, bit 1: the Cin = 128 kernel
+  const bool c128 = a.conv_c == 128;
+  if (!(use & (c128 ? 2 : 1))) return 1;
+  if ((a.conv_c != 64 && !c128) || a.in_dt != DT_BF16 || a.out_dt != DT_BF16 || a.act != ACT_RELU || !a.bias) return 1;
+  if (c128 ? a.N != 128 : (a.N != 64 && a.N != 128)) return 1;
+  if (a.ldc != a.N || a.ldw != 9 * a.conv_c || a.batch != 1 || a.mode != EPI_STD || a.scale || a.res || a.res_bf16 || a.alpha != 1.0f)
     return 1;
   const int H = a.conv_h, W = a.conv_w;
   const long hw = (long)H * W;
   if (hw <= 0 || a.M % hw != 0) return 1;
   const int B = (int)(a.M / hw);
-  const int TW = a.N == 64 ? 128 : 64;
+  const int TW = (!c128 && a.N == 64) ? 128 : 64;
+  const int slots = c128 ? 256 : 512;  // persistent workgroups: one (8 waves) or two (4 waves) per CU
   static const int sy_env = getenv("ROMA_CONV64_SY") ? atoi(getenv("ROMA_CONV64_SY")) : 0;
   const int nxt = (W + TW - 1) / TW;
-  // strip height: 512 persistent workgroups take the strips round-robin, so the launch lasts rounds x (SY + ~3 rows of ring
-  // prologue); pick the split of H that minimises it (432 rows, 112 columns of strips: 9 strips of 48 rows fill 1.97 rounds,
-  // where 14 strips of 32 would leave the fourth round 6 % full)
+  // strip height: the persistent workgroups take the strips round-robin, so the launch lasts rounds x (SY + ~3 rows of ring
+  // prologue); pick the split of H that minimises it (432 rows, 112 columns of strips: 9 strips of 48 rows fill 1.97 rounds
+  // of 512, where 14 strips of 32 would leave the fourth round 6 % full)
   int SY = sy_env;
   if (SY <= 0) {
     long best = -1;
     for (int yt = 1; yt <= std::max(1, H / 12); ++yt) {
       const int sy = (H + yt - 1) / yt;
       const long n = (long)B * nxt * ((H + sy - 1) / sy);
-      const long cost = ((n + 511) / 512) * (sy + 3);
+      const long cost = ((n + slots - 1) / slots) * (sy + 3);
       if (best < 0 || cost < best) {
         best = cost;
         SY = sy;
@@ -281,25 +507,29 @@ int conv64_try_launch(const GemmArgs& a, hipStream_t stream) {
   const long nb = (long)B * ((H + SY - 1) / SY) * nxt;
   if (nb <= 0 || nb >= (1l << 30)) return 1;
   char pname[64];
-  snprintf(pname, sizeof pname, "conv3x3_c64_kernel<%d>", a.N);
-  ProfScope ps(pname, 2.0 * (double)a.M * a.N * 576.0, "flop", stream);
+  snprintf(pname, sizeof pname, c128 ? "conv3x3_c128_kernel<%d>" : "conv3x3_c64_kernel<%d>", a.N);
+  ProfScope ps(pname, 2.0 * (double)a.M * a.N * 9.0 * a.conv_c, "flop", stream);
   const bf16_t* in = reinterpret_cast<const bf16_t*>(a.A);
   const bf16_t* w = reinterpret_cast<const bf16_t*>(a.W);
   bf16_t* out = reinterpret_cast<bf16_t*>(a.C);
-  const size_t lds = (size_t)4 * ((((TW + 2) * 128 + 1023) / 1024) * 1024) + 512;  // ring + bias
+  constexpr int LDS64 = 4 * 17 * 1024 + 512, LDS64N128 = 4 * 9 * 1024 + 512;  // ring + bias
+  constexpr int LDS128 = 4 * 17 * 1024 + 2 * 8 * 4096 + 512;                   // ring + exchange + bias
   static bool attr_set[64] = {false};
   int dev = 0;
   ROMA_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 17 * 1024 + 512));
-    ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 9 * 1024 + 512));
+    ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS64));
+    ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS64N128));
+    ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c128_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS128));
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  const long gx = std::min<long>(nb, 512);  // two workgroups per CU, persistent over the strips
-  if (a.N == 64) {
-    hipLaunchKernelGGL(conv3x3_c64_kernel<64>, dim3((unsigned)gx), dim3(256), lds, stream, in, w, a.bias, out, B, H, W, SY, nxt, (int)nb);
+  const long gx = std::min<long>(nb, slots);
+  if (c128) {
+    hipLaunchKernelGGL(conv3x3_c128_kernel<0>, dim3((unsigned)gx), dim3(512), LDS128, stream, in, w, a.bias, out, B, H, W, SY, nxt, (int)nb);
+  } else if (a.N == 64) {
+    hipLaunchKernelGGL(conv3x3_c64_kernel<64>, dim3((unsigned)gx), dim3(256), LDS64, stream, in, w, a.bias, out, B, H, W, SY, nxt, (int)nb);
   } else {
-    hipLaunchKernelGGL(conv3x3_c64_kernel<128>, dim3((unsigned)gx), dim3(256), lds, stream, in, w, a.bias, out, B, H, W, SY, nxt, (int)nb);
+    hipLaunchKernelGGL(conv3x3_c64_kernel<128>, dim3((unsigned)gx), dim3(256), LDS64N128, stream, in, w, a.bias, out, B, H, W, SY, nxt, (int)nb);
   }
   ROMA_LAUNCH_CHECK();
   return 0;

@@ -447,7 +447,7 @@ int gemm4w_try_launch(const GemmArgs& a, hipStream_t stream);  // gemm4w.hip (ex
 int conv64_try_launch(const GemmArgs& a, hipStream_t stream);  // conv64.hip (weight-stationary 3x3, Cin = 64)
 
 int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
-  if (a.conv_c == 64) {  // the two widest VGG layers have their own kernel
+  if (a.conv_c == 64 || a.conv_c == 128) {  // the three widest VGG layers have their own kernels (conv64.hip)
     const int rc = conv64_try_launch(a, stream);
     if (rc <= 0) return rc;
   }

@@ -263,14 +263,16 @@ def test_conv3x3_gemm8p_matches_classic_and_reference(lib, B, H, W, Cin, Cout):
     assert torch.allclose(outs[1].cpu().double(), ref, atol=3e-2, rtol=3e-2)
 
 
-@pytest.mark.parametrize("B,H,W,Cout", [(2, 9, 11, 64), (1, 16, 16, 128), (3, 56, 60, 64), (3, 56, 60, 128), (2, 131, 200, 64), (2, 70, 129, 128),
-                                        (1, 280, 280, 128), (1, 560, 560, 64)])
-def test_conv3x3_c64_weight_stationary(lib, B, H, W, Cout):
-    """conv64.hip (VGG conv1_2 / conv2_1: Cin 64, weights in registers, rows through a 4-slot LDS ring) against torch conv2d
-    and against the implicit GEMM it replaces: image borders, strips with a ragged last row block, x tiles hanging over the
-    right edge (store count of the vmcnt accounting), images shorter than one strip.  Both accumulate in f32 over the same
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 11, 64, 64), (1, 16, 16, 64, 128), (3, 56, 60, 64, 64), (3, 56, 60, 64, 128),
+                                            (2, 131, 200, 64, 64), (2, 70, 129, 64, 128), (1, 280, 280, 64, 128), (1, 560, 560, 64, 64),
+                                            (2, 9, 11, 128, 128), (3, 56, 60, 128, 128), (2, 70, 129, 128, 128), (9, 140, 131, 128, 128),
+                                            (1, 432, 432, 128, 128)])
+def test_conv3x3_weight_stationary(lib, B, H, W, Cin, Cout):
+    """conv64.hip (VGG conv1_2 / conv2_1 / conv2_2: weights in registers, rows through a 4-slot LDS ring; Cin 128: partial sums of
+    the two Cin halves exchanged through LDS) against torch conv2d and against the implicit GEMM it replaces: image borders,
+    strips with a ragged last row block, x tiles hanging over the right edge (store count of the vmcnt accounting), images
+    shorter than one strip, several strips per persistent workgroup (9 x 140 x 131).  Both accumulate in f32 over the same
     products; the order differs, so the two device paths agree to one bf16 rounding.  Run twice (timing-dependent races)."""
-    Cin = 64
     x, w, b = rnd(B, Cin, H, W, seed=1).bfloat16(), rnd(Cout, Cin, 3, 3, seed=2, std=(9 * Cin) ** -0.5).bfloat16(), rnd(Cout, seed=3)
     ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).permute(0, 2, 3, 1)
     xin = x.permute(0, 2, 3, 1).contiguous().cuda()
@@ -278,7 +280,7 @@ def test_conv3x3_c64_weight_stationary(lib, B, H, W, Cout):
     bd = b.cuda()
     outs = []
     try:
-        for mode in (0, 1, 1):
+        for mode in (0, 3, 3):
             lib.roma_tuning(b"conv64", mode)
             out = torch.full((B, H, W, Cout), -7.0, device="cuda", dtype=torch.bfloat16)
             ok(lib, lib.roma_op_conv3x3(P(xin), P(wp), P(bd), P(out), B, H, W, Cin, Cout, 1, BF16, None))
