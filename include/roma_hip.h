@@ -206,6 +206,10 @@ int roma_op_fb_consistency(const float* flow_fwd, const float* flow_bwd, int B, 
 int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream);
 int roma_op_conv3x3_c3(const float* img, const float* w, const float* bias, void* out, int B, int H, int W, int dt_out,
                        void* stream);
+/* First VGG19-BN layer of the bf16 path (encoders.py:17-27, features[0..2] with the BatchNorm folded): img DEVICE f32
+ * [B,3,H,W] -> out DEVICE bf16 [B,H,W,64] = ReLU(conv3x3(bf16(img), w, pad 1) + bias), products exact, f32 accumulate.
+ * w DEVICE bf16 [64][32] with column k = ci*9 + ky*3 + kx (columns 27..31 zero), bias DEVICE f32 [64]. */
+int roma_op_conv3x3_c3_bf16(const float* img, const void* w, const float* bias, void* out, int B, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

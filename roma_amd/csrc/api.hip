@@ -406,6 +406,10 @@ int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, in
   return maxpool2x2_launch(in, out, B, H, W, C, DT(dt), S(stream));
 }
 
+int roma_op_conv3x3_c3_bf16(const float* img, const void* w, const float* bias, void* out, int B, int H, int W, void* stream) {
+  return conv3x3_c3_bf16_launch(img, w, bias, out, B, H, W, S(stream));
+}
+
 int roma_op_conv3x3_c3(const float* img, const float* w, const float* bias, void* out, int B, int H, int W, int dt_out,
                        void* stream) {
   return conv3x3_c3_launch(img, w, bias, out, B, H, W, DT(dt_out), S(stream));

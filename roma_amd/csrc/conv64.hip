@@ -470,9 +470,141 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c128_kernel(const bf16_t* __re
 #undef C128_ISSUE_ROW
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// First VGG layer (Cin = 3, Cout = 64, encoders.py:17-27 / vgg19_bn features[0]) in bf16 mode, straight from the f32 NCHW image:
+// replaces im2col (K = 27 -> 32, 64 B / pixel written and read back) + a 256 x 64 GEMM tile pass.  HBM-bound: 12 B / pixel
+// in, 128 B / pixel out.  A wave owns 32 consecutive pixels of an image row and walks RY rows down; the 27 taps of a pixel
+// are split over the two lanes that share it in the MFMA operand layout (lane (l31, h) supplies k = 16 h + [0, 16) of
+// k = ci * 9 + ky * 3 + kx, k >= 27 zero - a permutation of the MFMA's K index applied to both operands, so the weight
+// fragment of lane (l31, h), k-step ks is the contiguous 16 bytes W[cout][16 h + 8 ks ...)).  Tap offsets are lane constants
+// (two compile-time candidates per slot, selected by h); a row whose 34 x 3 window lies inside the image takes 16 plain
+// loads (coalesced over the 32 pixels), any other row the guarded form.  8 packs, 4 MFMAs (2 channel blocks x 2 k-steps),
+// bias + ReLU, and the 32 x 128 B of the row go through a per-wave LDS transpose so that every store instruction writes
+// whole 128-byte lines (8 lanes per pixel) instead of 32-byte pieces of 32 lines.
+__global__ __launch_bounds__(256, 4) void conv3x3_c3_bf16_kernel(const float* __restrict__ img, const bf16_t* __restrict__ w,
+                                                                 const float* __restrict__ bias, bf16_t* __restrict__ out, int B,
+                                                                 int H, int W, int RY, int nxt, long ntiles) {
+  __shared__ __attribute__((aligned(16))) float bias_s[64];
+  __shared__ __attribute__((aligned(1024))) unsigned char stage[4][4096];  // per wave: [32 pixels][8 chunks of 16 B], chunk ^ (px & 7)
+  if (threadIdx.x < 64) bias_s[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long t = (long)blockIdx.x * 4 + wave;  // (image, row block, 32-pixel column tile)
+  if (t >= ntiles) return;
+  const int xt = (int)(t % nxt);
+  const long r = t / nxt;
+  const int nyb = (H + RY - 1) / RY;
+  const int y0 = (int)(r % nyb) * RY;
+  const int b = (int)(r / nyb);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int x = xt * 32 + l31;
+  const int HW = H * W;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  u32x4 wf[2][2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wf[cb][ks] = *reinterpret_cast<const u32x4*>(w + (32 * cb + l31) * 32 + 16 * h + 8 * ks);
+
+  // lane constants: offset of tap s (relative to the pixel, in floats) and the validity bits it needs
+  // (bit ky: input row y + ky - 1 inside the image, bit 3 + kx: column x + kx - 1 inside; 64: never)
+  int toff[16], tsel[16];
+#pragma unroll
+  for (int s_ = 0; s_ < 16; ++s_) {
+    const int k0 = s_, k1 = 16 + s_;  // h = 0 / h = 1
+    const int o0 = (k0 / 9) * HW + ((k0 % 9) / 3 - 1) * W + (k0 % 3 - 1);
+    const int o1 = k1 < 27 ? (k1 / 9) * HW + ((k1 % 9) / 3 - 1) * W + (k1 % 3 - 1) : 0;
+    const int m0 = (1 << ((k0 % 9) / 3)) | (8 << (k0 % 3));
+    const int m1 = k1 < 27 ? ((1 << ((k1 % 9) / 3)) | (8 << (k1 % 3))) : 64;
+    toff[s_] = h ? o1 : o0;
+    tsel[s_] = h ? m1 : m0;
+  }
+  const int colbits = ((x >= 1 && x - 1 < W) ? 8 : 0) | (x < W ? 16 : 0) | (x + 1 < W ? 32 : 0);
+  const bool cols_in = xt * 32 >= 1 && xt * 32 + 33 <= W;  // the whole 34-pixel window of the tile (wave-uniform)
+  const float* p0 = img + (long)b * 3 * HW;
+  bf16_t* outb = out + (long)b * HW * 64;
+  const unsigned st0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)stage[wave]);
+  const int ny = min(RY, H - y0);
+  for (int o = 0; o < ny; ++o) {
+    const int y = y0 + o;
+    const int base = y * W + x;
+    float v[16];
+    if (cols_in && y >= 1 && y + 1 < H) {
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) v[s_] = p0[base + toff[s_]];
+      if (h) {  // k = 27 .. 31 of the second half do not exist
+#pragma unroll
+        for (int s_ = 11; s_ < 16; ++s_) v[s_] = 0.f;
+      }
+    } else {
+      const int okbits = colbits | (y >= 1 ? 1 : 0) | 2 | (y + 1 < H ? 4 : 0);
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) {
+        const bool ok = (okbits & tsel[s_]) == tsel[s_];
+        const float ld = p0[ok ? base + toff[s_] : 0];
+        v[s_] = ok ? ld : 0.f;
+      }
+    }
+    u32x4 fr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fr[ks][j] = pack_bf16x2(v[8 * ks + 2 * j], v[8 * ks + 2 * j + 1]);
+    f32x16 acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[cb][ks]),
+                                                          __builtin_bit_cast(bf16x8_t, fr[ks]), acc[cb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int P = 0; P < 2; ++P) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + 32 * cb + 16 * P + 4 * h);  // channels 32 cb + 8 rg + 4 h + [0, 4)
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_s + 32 * cb + 16 * P + 8 + 4 * h);
+        const unsigned a0 = pack_bf16x2(fmaxf(acc[cb][8 * P + 0] + b0[0], 0.f), fmaxf(acc[cb][8 * P + 1] + b0[1], 0.f));
+        const unsigned a1 = pack_bf16x2(fmaxf(acc[cb][8 * P + 2] + b0[2], 0.f), fmaxf(acc[cb][8 * P + 3] + b0[3], 0.f));
+        const unsigned c0 = pack_bf16x2(fmaxf(acc[cb][8 * P + 4] + b1[0], 0.f), fmaxf(acc[cb][8 * P + 5] + b1[1], 0.f));
+        const unsigned c1 = pack_bf16x2(fmaxf(acc[cb][8 * P + 6] + b1[2], 0.f), fmaxf(acc[cb][8 * P + 7] + b1[3], 0.f));
+        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1, false, false);
+        const u32x4 st = {s0[0], s1[0], s0[1], s1[1]};  // channels 32 cb + 16 P + 8 h + [0, 8) of pixel l31: chunk 4 cb + 2 P + h
+        const int c = 4 * cb + 2 * P + h;
+        *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(st0 + l31 * 128 + ((c ^ (l31 & 7)) << 4)) = st;
+      }
+    // the wave's LDS operations execute in order: the transposed reads below see the writes above
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4 st = *reinterpret_cast<__attribute__((address_space(3))) const u32x4*>(st0 + i * 1024 + lane * 16);
+      const int px = i * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (px & 7);
+      if (xt * 32 + px < W) *reinterpret_cast<u32x4*>(outb + ((long)y * W + xt * 32 + px) * 64 + c * 8) = st;
+    }
+  }
+}
+
+int conv3x3_c3_bf16_launch(const float* img, const void* w, const float* bias, void* out, int B, int H, int W, hipStream_t stream) {
+  ROMA_REQUIRE(img && w && bias && out && B > 0 && H > 0 && W > 0, "conv3x3_c3_bf16: bad arguments");
+  ROMA_REQUIRE((long)3 * H * W < (1l << 23), "conv3x3_c3_bf16: image too large for the packed tap offsets");
+  const int RY = 8;
+  const int nxt = (W + 31) / 32;
+  const long ntiles = (long)B * ((H + RY - 1) / RY) * nxt;
+  ProfScope ps("conv3x3_c3_bf16_kernel", (double)B * H * W * (12.0 + 128.0), "byte", stream);
+  hipLaunchKernelGGL(conv3x3_c3_bf16_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, stream, img,
+                     reinterpret_cast<const bf16_t*>(w), bias, reinterpret_cast<bf16_t*>(out), B, H, W, RY, nxt, ntiles);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
 // 0 = launched, 1 = not this kernel's problem
 int conv64_try_launch(const GemmArgs& a, hipStream_t stream) {
-  static const int use_env = getenv("ROMA_CONV64") ? atoi(getenv("ROMA_CONV64")) : 3;
+  static const int use_env = getenv("ROMA_CONV64") ? atoi(getenv("ROMA_CONV64")) : 7;
   const int use = g_conv64_mode >= 0 ? g_conv64_mode : use_env;  // bit 0: Cin = 64 kernels, bit 1: the Cin = 128 kernel
   const bool c128 = a.conv_c == 128;
   if (!(use & (c128 ? 2 : 1))) return 1;

@@ -9,6 +9,7 @@
 #include <set>
 
 #include "attention.h"
+#include "conv64.h"
 #include "elementwise.h"
 #include "gemm.h"
 #include "local_corr.h"
@@ -898,8 +899,13 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       const size_t enc_mark = arena.mark();
       void* t0 = AL((size_t)nimg * H * W * 64, esz);
       void* t1 = AL((size_t)nimg * (H / 2) * (W / 2) * 64, esz);
-      {  // first layer (Cin = 3): im2col to K = 32, then the same MFMA GEMM as every other layer
-        void* col1 = AL((size_t)nimg * H * W * 32, esz);
+      static const int c64_env = getenv("ROMA_CONV64") ? atoi(getenv("ROMA_CONV64")) : 7;
+      void* col1 = AL((size_t)nimg * H * W * 32, esz);  // (planned whichever form runs: the switch may change between calls)
+      if (act_dt == DT_BF16 && ((g_conv64_mode >= 0 ? g_conv64_mode : c64_env) & 4)) {
+        // first layer (Cin = 3), bf16: fused kernel straight from the f32 image (conv64.hip)
+        RUN(conv3x3_c3_bf16_launch(imA, vgg[0].w, vgg[0].b, t0, B, H, W, st));
+        RUN(conv3x3_c3_bf16_launch(imB, vgg[0].w, vgg[0].b, off(t0, (long)B * H * W * 64), B, H, W, st));
+      } else {  // im2col to K = 32, then the same MFMA GEMM as every other layer
         RUN(im2col3x3_c3_launch(imA, col1, B, H, W, act_dt, st));
         RUN(im2col3x3_c3_launch(imB, off(col1, (long)B * H * W * 32), B, H, W, act_dt, st));
         GemmArgs g;

@@ -570,6 +570,26 @@ def test_maxpool_and_first_conv(lib):
 
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 16, 24), (1, 9, 33), (3, 37, 70), (1, 560, 560), (2, 100, 864)])
+def test_first_conv_bf16_fused(lib, B, H, W):
+    """conv64.hip conv3x3_c3_bf16: the first VGG layer of the bf16 path straight from the f32 image (27 taps split over the two
+    lanes of an MFMA column, K index permuted on both operands).  Against conv2d on the bf16-rounded operands in f64: the
+    products are exact, the sum is f32, the output one bf16 rounding - and bit-for-bit against the im2col + GEMM pair it
+    replaces is NOT required (the K order inside the MFMA differs), so that pair is held to the same reference instead.
+    Image borders, ragged last column tile (W % 32 != 0), ragged last row block (H % 8 != 0)."""
+    img, w, b = rnd(B, 3, H, W, seed=1), rnd(64, 3, 3, 3, seed=2, std=0.3), rnd(64, seed=3)
+    imq, wq = img.bfloat16(), w.bfloat16()
+    ref = F.relu(F.conv2d(imq.double(), wq.double(), b.double(), padding=1)).permute(0, 2, 3, 1)
+    wp = torch.zeros(64, 32, dtype=torch.bfloat16)
+    wp[:, :27] = wq.reshape(64, 27)  # k = ci*9 + ky*3 + kx
+    out = torch.full((B, H, W, 64), -3.0, device="cuda", dtype=torch.bfloat16)
+    for _ in range(2):
+        ok(lib, lib.roma_op_conv3x3_c3_bf16(P(img.cuda()), P(wp.cuda()), P(b.cuda()), P(out), B, H, W, None))
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs()
+    assert float((err / (ref.abs() + 1.0)).max()) <= 2.0 ** -8 + 1e-6, float(err.max())
+
+
 # ------------------------------------------------------------------ sampling: KDE + RegressionMatcher.sample (SURVEY 8f rank 1)
 def test_kde_vs_reference_golden_and_oracle():
     import roma_amd

@@ -43,5 +43,28 @@ def main():
         lib.roma_tuning(b"conv64", -1)
 
 
+def first_layer(lib):
+    torch.manual_seed(0)
+    for (B, H, W) in [(8, 560, 560), (8, 864, 864)]:
+        img = torch.randn(B, 3, H, W, device="cuda")
+        w = torch.zeros(64, 32, device="cuda", dtype=torch.bfloat16)
+        w[:, :27] = (torch.randn(64, 27, device="cuda") / 5).bfloat16()
+        b = torch.randn(64, device="cuda")
+        out = torch.empty(B, H, W, 64, device="cuda", dtype=torch.bfloat16)
+        for _ in range(3):
+            lib.roma_op_conv3x3_c3_bf16(P(img), P(w), P(b), P(out), B, H, W, None)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 20
+        e0.record()
+        for _ in range(n):
+            lib.roma_op_conv3x3_c3_bf16(P(img), P(w), P(b), P(out), B, H, W, None)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        print(f"first layer B{B} {H}x{W}: {us:9.1f} us  {B * H * W * 140 / us / 1e6:6.2f} TB/s algorithmic", flush=True)
+
+
 if __name__ == "__main__":
+    first_layer(_lib.load())
     main()
