@@ -408,35 +408,42 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(float* A, long ld, long s
     const int row = idx >> 4, c4 = idx & 15;
     *reinterpret_cast<f32x4*>(&L[row * S + c4 * 4]) = *reinterpret_cast<const f32x4*>(Ab + (long)row * ld + c4 * 4);
   }
-  for (int j = 0; j < 64; ++j) {
-    const float d = sqrtf(L[j * S + j]);
-    const float lij = (i == j) ? d : L[i * S + j] / d;
-    L[i * S + j] = lij;   // rows < j: harmless garbage in the strictly upper part
-    LT[j * S + i] = lij;  // column j of the factor, contiguous
-    // a_ic -= l_ij * l_cj for c > j.  All 16 column groups every time (selects, no trip-count dependent loop): the
-    // 48 LDS operations of a step are independent and pipeline, instead of ~150 cycles of latency per group.
 #pragma unroll
-    for (int c = 0; c < 64; c += 4) {
-      f32x4 a = *reinterpret_cast<const f32x4*>(&L[i * S + c]);
-      const f32x4 lc = *reinterpret_cast<const f32x4*>(&LT[j * S + c]);  // same address in every lane: broadcast
+  for (int jb = 0; jb < 4; ++jb) {  // columns in four bands: a band's steps touch column groups >= 16 jb only
+    for (int j = 16 * jb; j < 16 * jb + 16; ++j) {
+      const float d = sqrtf(L[j * S + j]);
+      const float lij = (i == j) ? d : L[i * S + j] / d;
+      L[i * S + j] = lij;   // rows < j: harmless garbage in the strictly upper part
+      LT[j * S + i] = lij;  // column j of the factor, contiguous
+      // a_ic -= l_ij * l_cj for c > j.  Every column group of the band's range every time (selects, no trip count that
+      // depends on j): the LDS operations of a step are independent and pipeline, instead of ~150 cycles of latency per
+      // group; the compile-time band start drops the 37 % of the groups that lie wholly left of column j.
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = (c + u > j) ? a[u] - lij * lc[u] : a[u];
-      *reinterpret_cast<f32x4*>(&L[i * S + c]) = a;
+      for (int c = 16 * jb; c < 64; c += 4) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(&L[i * S + c]);
+        const f32x4 lc = *reinterpret_cast<const f32x4*>(&LT[j * S + c]);  // same address in every lane: broadcast
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = (c + u > j) ? a[u] - lij * lc[u] : a[u];
+        *reinterpret_cast<f32x4*>(&L[i * S + c]) = a;
+      }
     }
   }
   // inverse: lane c solves L x = e_c by forward substitution; x lives in XT[c][.].  Four interleaved partial sums
   // (t mod 4) keep the dependent-FMA chain at 16 instead of 64 per row.
   const int c = i;
-  for (int r = 0; r < 64; ++r) {
-    f32x4 part = {(r == c) ? 1.f : 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 64; t += 4) {
-      const f32x4 lr = *reinterpret_cast<const f32x4*>(&L[r * S + t]);   // broadcast
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(&XT[c * S + t]);
+  for (int rb = 0; rb < 4; ++rb) {  // rows in four bands: row r only needs the unknowns t < r, i.e. groups < 16 (rb + 1)
+    for (int r = 16 * rb; r < 16 * rb + 16; ++r) {
+      f32x4 part = {(r == c) ? 1.f : 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < 4; ++u) part[u] = (t + u < r) ? part[u] - lr[u] * xv[u] : part[u];
+      for (int t = 0; t < 16 * (rb + 1); t += 4) {
+        const f32x4 lr = *reinterpret_cast<const f32x4*>(&L[r * S + t]);   // broadcast
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(&XT[c * S + t]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) part[u] = (t + u < r) ? part[u] - lr[u] * xv[u] : part[u];
+      }
+      XT[c * S + r] = ((part[0] + part[1]) + (part[2] + part[3])) / L[r * S + r];
     }
-    XT[c * S + r] = ((part[0] + part[1]) + (part[2] + part[3])) / L[r * S + r];
   }
   float* Li = Linv + ((long)blockIdx.x * nblk + k) * 4096;
   float* LiT = LinvT + ((long)blockIdx.x * nblk + k) * 4096;
