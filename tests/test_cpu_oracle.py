@@ -300,8 +300,8 @@ def test_hot_gemm_kernels_do_not_spill(built_lib):
         pytest.skip("object files not present (library shipped pre-built)")
     k6 = kernel_resources.kernels(objs["gemm6p.o"])
     assert len(k6) >= 4 and all(k["spill"] == 0 and k["scratch"] == 0 for k in k6), k6
-    k64 = kernel_resources.kernels(objs["conv64.o"])  # 144 weight registers + 64 for accumulators and fragments: 250 of 256
-    assert len(k64) == 2 and all(k["spill"] == 0 and k["scratch"] == 0 for k in k64), k64
+    k64 = kernel_resources.kernels(objs["conv64.o"])  # 144 weight registers + 64 for accumulators and fragments: 242-256 of 256
+    assert len(k64) == 4 and all(k["spill"] == 0 and k["scratch"] == 0 for k in k64), k64
     k8 = [k for k in kernel_resources.kernels(objs["gemm8p.o"]) if k["name"].startswith("gemm8p_kernel<bf16")]
     assert len(k8) >= 6
     for k in k8:
