@@ -527,11 +527,14 @@ def test_dwconv5x5(lib, dt, B, H, W, Cp):
     assert torch.allclose(out.cpu().double(), ref, atol=tol, rtol=tol)
 
 
+@pytest.mark.parametrize("mode", [1, 0])
 @pytest.mark.parametrize("Cp,B,H,W", [(24, 2, 13, 10), (24, 1, 75, 301), (24, 1, 290, 150), (144, 2, 13, 10), (144, 1, 41, 59),
-                                      (144, 1, 262, 31)])
-def test_refiner_block_fused(lib, Cp, B, H, W):
+                                      (144, 1, 262, 31), (144, 5, 70, 280), (24, 3, 3, 200), (144, 2, 1, 30)])
+def test_refiner_block_fused(lib, Cp, B, H, W, mode):
     """Fused dw5x5+BN+ReLU+1x1 (refiner_block.hip) vs torch f64 on the same bf16-rounded operands: ragged strips,
-    x tiles and pixel blocks, both strip heights (H >= 256 selects 36-row strips)."""
+    x tiles and pixel blocks, both strip heights (H >= 256 selects 36-row strips), strips shorter than the pipeline depth.
+    mode 1 = the wave-specialised eight-wave kernel (experimental), 0 = the four-wave kernel (default); same arithmetic in the same order,
+    so the two must agree bit for bit (checked below), and each is run twice (timing-dependent races)."""
     x = rnd(B, Cp, H, W, seed=1).to(torch.bfloat16)
     w, b = rnd(Cp, 1, 5, 5, seed=2, std=0.2), rnd(Cp, seed=3)
     pw = rnd(Cp, Cp, seed=4, std=Cp ** -0.5).to(torch.bfloat16)
@@ -540,9 +543,19 @@ def test_refiner_block_fused(lib, Cp, B, H, W):
     ref = (F.conv2d(mid.double(), pw.double()[:, :, None, None], pb.double())).permute(0, 2, 3, 1)
     out = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=torch.bfloat16)
     wp = w.reshape(Cp, 25).T.contiguous().cuda()
-    ok(lib, lib.roma_op_refiner_block(P(x.permute(0, 2, 3, 1).contiguous().cuda()), P(out), P(wp), P(b.cuda()), P(pw.cuda()),
-                                      P(pb.cuda()), B, H, W, Cp, BF16, None))
-    torch.cuda.synchronize()
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    outs = []
+    try:
+        for m in (mode, mode, 1 - mode):
+            lib.roma_tuning(b"refiner_block", m)
+            out = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=torch.bfloat16)
+            ok(lib, lib.roma_op_refiner_block(P(xin), P(out), P(wp), P(b.cuda()), P(pw.cuda()), P(pb.cuda()), B, H, W, Cp, BF16, None))
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        lib.roma_tuning(b"refiner_block", -1)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    out = outs[0]
     got = out.cpu().double()
     assert torch.isfinite(got).all()
     # bf16 output rounding (2^-8 relative) + the occasional 1-ulp flip of the bf16 intermediate
