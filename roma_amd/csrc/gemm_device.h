@@ -68,7 +68,7 @@ __device__ __forceinline__ void epi_consume(uint4 v) { asm volatile("" ::"v"(v.x
 // columns of every 8-column group for ALL its rows, so they are loaded ONCE per tile, back to back, before the
 // accumulators are touched: one vmcnt wait per tile.  (Loading them where they are used - inside the (tm, tn, rg) loops -
 // made hipcc emit `global_load ; s_waitcnt vmcnt(0) ; use` 32..64 times per tile, each a serialised L2 round trip that
-// also drains the LDS-DMA queue: ~9 us of the ~12 us epilogue of a 256 x 256 tile, profiles/r02_gemm_overhead.log.)
+// also drains the LDS-DMA queue: ~9 us of the ~12 us epilogue of a 256 x 256 tile, profiles/r02_v11_gemm_overhead.log.)
 template <int TN, bool FULL, bool HAS_S>
 struct EpiCols {
   f32x4 b[TN][4], s[HAS_S ? TN : 1][4];
