@@ -204,6 +204,11 @@ int roma_op_visualize_warp(const float* warp, const float* certainty, const floa
 int roma_op_fb_consistency(const float* flow_fwd, const float* flow_bwd, int B, int H, int W, float th_n, float* out,
                            void* stream);
 int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream);
+/* ConvRefiner out_conv fused with the flow / certainty update (matcher.py:177-178, 496-506):
+ *   o = d[m, 0:Cp] . w[0:3, 0:Cp]^T + b;  flow[m] += (sx * o0, sy * o1);  cert[m] += o2        (f32 accumulate)
+ * d DEVICE [M, ldd] in dt (f32 / bf16; channels Cp..ldd ignored), w DEVICE f32 [3][Cp], b f32 [3], flow f32 [M,2], cert f32 [M]. */
+int roma_op_refiner_out(const void* d, long ldd, int dt, const float* w, const float* b, float* flow, float* cert, long M,
+                        int Cp, float sx, float sy, void* stream);
 int roma_op_conv3x3_c3(const float* img, const float* w, const float* bias, void* out, int B, int H, int W, int dt_out,
                        void* stream);
 /* First VGG19-BN layer of the bf16 path (encoders.py:17-27, features[0..2] with the BatchNorm folded): img DEVICE f32

@@ -407,6 +407,12 @@ int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, in
   return maxpool2x2_launch(in, out, B, H, W, C, DT(dt), S(stream));
 }
 
+int roma_op_refiner_out(const void* d, long ldd, int dt, const float* w, const float* b, float* flow, float* cert, long M,
+                        int Cp, float sx, float sy, void* stream) {
+  ROMA_REQUIRE(d && w && b && flow && cert && M > 0 && Cp > 0 && ldd >= Cp, "roma_op_refiner_out: bad arguments");
+  return refiner_out_launch(d, ldd, DT(dt), w, b, flow, cert, M, Cp, sx, sy, S(stream));
+}
+
 int roma_op_conv3x3_c3_bf16(const float* img, const void* w, const float* bias, void* out, int B, int H, int W, void* stream) {
   return conv3x3_c3_bf16_launch(img, w, bias, out, B, H, W, S(stream));
 }

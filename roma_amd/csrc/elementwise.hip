@@ -1142,9 +1142,56 @@ __global__ __launch_bounds__(256) void refiner_out_vec_kernel(const T* d, long l
   }
 }
 
+// Narrow rows (bf16, Cp = 24: the stride-1 refiner, 12 M pixels per call): ONE LANE PER ROW.  The shared-row kernel above
+// gives such a row to two lanes (3 chunks: the second lane idles in the second piece, 2.8 TB/s); here a lane reads its
+// row's NCH 16-byte chunks itself (the 48-byte lane stride leaves every fetched line fully used across the NCH loads,
+// L1 serves the repeats), keeps all 3 x Cp weights in registers over ROWS rows, needs no shuffles, and the running
+// flow / certainty are lane-contiguous 8- and 4-byte accesses.
+template <int NCH, int ROWS>
+__global__ __launch_bounds__(256) void refiner_out_row_kernel(const bf16_t* d, long ldd, const float* w, const float* bb,
+                                                              float* flow, float* cert, long M, int Cp, float sx, float sy) {
+  float wr[3][NCH * 8];
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+#pragma unroll
+    for (int j = 0; j < NCH * 8; ++j) wr[o][j] = j < Cp ? w[(long)o * Cp + j] : 0.f;
+  const float b0 = bb[0], b1 = bb[1], b2 = bb[2];
+  const long row0 = (long)blockIdx.x * 256 * ROWS + threadIdx.x;
+#pragma unroll 2
+  for (int it = 0; it < ROWS; ++it) {
+    const long row = row0 + (long)it * 256;
+    if (row >= M) break;
+    const f32x2 f = *reinterpret_cast<const f32x2*>(flow + row * 2);
+    const float c0 = cert[row];
+    float v[NCH][8];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) VecIO<bf16_t>::ld(d + row * ldd + k * 8, v[k]);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a0 = fmaf(v[k][j], wr[0][k * 8 + j], a0);
+        a1 = fmaf(v[k][j], wr[1][k * 8 + j], a1);
+        a2 = fmaf(v[k][j], wr[2][k * 8 + j], a2);
+      }
+    *reinterpret_cast<f32x2*>(flow + row * 2) = f32x2{f[0] + sx * (a0 + b0), f[1] + sy * (a1 + b1)};
+    cert[row] = c0 + (a2 + b2);
+  }
+}
+
 int refiner_out_launch(const void* d, long ldd, int dt, const float* w, const float* b, float* flow, float* cert,
                        long M, int Cp, float sx, float sy, hipStream_t s) {
   ROMA_REQUIRE(Cp % 4 == 0 && ldd % 4 == 0, "refiner_out: channel padding must be a multiple of 4");
+  static const int row_env = getenv("ROMA_OUT_ROW") ? atoi(getenv("ROMA_OUT_ROW")) : 1;
+  if (row_env && dt == DT_BF16 && Cp == 24 && ldd % 8 == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(flow) & 7) == 0) {
+    constexpr int ROWS = 8;
+    dim3 grid((unsigned)((M + 256l * ROWS - 1) / (256l * ROWS)));
+    hipLaunchKernelGGL((refiner_out_row_kernel<3, ROWS>), grid, dim3(256), 0, s, (const bf16_t*)d, ldd, w, b, flow, cert, M, Cp, sx, sy);
+    ROMA_LAUNCH_CHECK();
+    return 0;
+  }
   {
     const int cv = dt == DT_F32 ? 4 : 8;
     const int chunks = Cp / cv;

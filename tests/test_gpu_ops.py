@@ -567,6 +567,28 @@ def test_refiner_block_fused(lib, Cp, B, H, W, mode):
     assert lib.roma_op_refiner_block(P(x.cuda()), P(out), P(wp), P(b.cuda()), P(pw.cuda()), P(pb.cuda()), B, H, W, Cp, F32, None) != 0
 
 
+@pytest.mark.parametrize("dt,Cp,M", [(BF16, 24, 100003), (BF16, 24, 255), (BF16, 144, 30011), (BF16, 576, 5000), (F32, 24, 40001),
+                                      (F32, 1152, 777)])
+def test_refiner_out_conv_update(lib, dt, Cp, M):
+    """out_conv (3 x Cp, f32) fused with the running flow / certainty update - the lane-per-row kernel (bf16, Cp = 24) and the
+    shared-row kernels against f64."""
+    import ctypes as C
+    tdt = torch.float32 if dt == F32 else torch.bfloat16
+    d = rnd(M, Cp, seed=1).to(tdt)
+    w, b = rnd(3, Cp, seed=2, std=Cp ** -0.5), rnd(3, seed=3)
+    flow0, cert0 = rnd(M, 2, seed=4), rnd(M, seed=5)
+    sx, sy = 0.25, 0.125
+    o = d.double() @ w.double().T + b.double()
+    ref_flow = flow0.double() + o[:, :2] * torch.tensor([sx, sy], dtype=torch.float64)
+    ref_cert = cert0.double() + o[:, 2]
+    flow, cert = flow0.cuda(), cert0.cuda()
+    ok(lib, lib.roma_op_refiner_out(P(d.cuda()), Cp, dt, P(w.cuda()), P(b.cuda()), P(flow), P(cert), M, Cp, C.c_float(sx), C.c_float(sy), None))
+    torch.cuda.synchronize()
+    tol = 2e-5 * max(1.0, (Cp / 24) ** 0.5)
+    assert torch.allclose(flow.cpu().double(), ref_flow, atol=tol, rtol=1e-5)
+    assert torch.allclose(cert.cpu().double(), ref_cert, atol=4 * tol, rtol=1e-5)
+
+
 def test_maxpool_and_first_conv(lib):
     B, H, W = 2, 16, 24
     img, w, b = rnd(B, 3, H, W, seed=1), rnd(64, 3, 3, 3, seed=2, std=0.3), rnd(64, seed=3)
