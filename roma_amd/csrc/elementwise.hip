@@ -1102,32 +1102,28 @@ __global__ __launch_bounds__(256) void refiner_out_vec_kernel(const T* d, long l
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     // the running flow / certainty are fetched with the activations, not after the reduction (a dependent
     // load -> add -> store tail per row group otherwise)
-    float f0 = 0.f, f1 = 0.f, c0 = 0.f;
-    if (row < M && sub == 0) {
-      f0 = flow[row * 2 + 0];
-      f1 = flow[row * 2 + 1];
-      c0 = cert[row];
-    }
-    if (row < M) {
+    // branch-free loads (clamped row and chunk, select afterwards): inside exec-masked blocks hipcc waits for every load on
+    // its own, and this kernel is nothing but loads (1.5 TB/s at Cp = 144 with the guarded form)
+    const long rowc = row < M ? row : M - 1;
+    const float f0 = flow[rowc * 2 + 0], f1 = flow[rowc * 2 + 1], c0 = cert[rowc];
+    {
       float v[NK][CV];
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         const int c = (sub + k * lpr) * CV;
-        if (c < Cp) {
-          VecIO<T>::ld(d + row * ldd + c, v[k]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < CV; ++j) v[k][j] = 0.f;
-        }
+        VecIO<T>::ld(d + rowc * ldd + (c < Cp ? c : 0), v[k]);
       }
 #pragma unroll
-      for (int k = 0; k < NK; ++k)
+      for (int k = 0; k < NK; ++k) {
+        const bool ok = (sub + k * lpr) * CV < Cp;
 #pragma unroll
         for (int j = 0; j < CV; ++j) {
-          a0 = fmaf(v[k][j], wr[k][0][j], a0);
-          a1 = fmaf(v[k][j], wr[k][1][j], a1);
-          a2 = fmaf(v[k][j], wr[k][2][j], a2);
+          const float x = ok ? v[k][j] : 0.f;
+          a0 = fmaf(x, wr[k][0][j], a0);
+          a1 = fmaf(x, wr[k][1][j], a1);
+          a2 = fmaf(x, wr[k][2][j], a2);
         }
+      }
     }
     for (int off = lpr >> 1; off >= 1; off >>= 1) {
       a0 += __shfl_xor(a0, off);
@@ -1198,6 +1194,25 @@ int refiner_out_launch(const void* d, long ldd, int dt, const float* w, const fl
     if (Cp % cv == 0 && ldd % cv == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 && chunks >= 1) {
       int lpr = 1;
       while (lpr < 64 && lpr * 2 <= chunks) lpr *= 2;       // largest power of two <= chunks (<= 64)
+      // bf16: chunk counts just above a power of two (18, 72, 144) leave 44 % of the lane-pieces of that split empty (the
+      // second piece has 2 / 8 / 16 active lanes of 16 / 64 / 64): take the power of two that fills the pieces best with
+      // at most 5 per lane (18 = 4 x 5 - 2, 72 = 16 x 5 - 8, 144 = 32 x 5 - 16: 90 %), which also shortens the shuffle
+      // reduction.  The f32 mode keeps its split (bit-for-bit history of the parity runs).
+      static const int lpr_env = getenv("ROMA_OUT_LPR") ? atoi(getenv("ROMA_OUT_LPR")) : 1;
+      if (dt == DT_BF16 && lpr_env) {
+        int best_l = lpr;
+        double best_e = (double)chunks / ((double)lpr * ((chunks + lpr - 1) / lpr));
+        for (int l = lpr / 2; l >= 2; l /= 2) {
+          const int n = (chunks + l - 1) / l;
+          if (n > 5) break;
+          const double e = (double)chunks / ((double)l * n);
+          if (e > best_e + 1e-9) {
+            best_e = e;
+            best_l = l;
+          }
+        }
+        lpr = best_l;
+      }
       const int nk = (chunks + lpr - 1) / lpr;              // 16-byte pieces per lane per row
       if (nk <= 6) {
         const int rows_it = 8;
@@ -1209,6 +1224,7 @@ int refiner_out_launch(const void* d, long ldd, int dt, const float* w, const fl
         if (nk <= 1) { ROMA_ROV(1); }
         else if (nk == 2) { ROMA_ROV(2); }
         else if (nk == 3) { ROMA_ROV(3); }
+        else if (nk == 5) { ROMA_ROV(5); }
         else { ROMA_ROV(6); }
 #undef ROMA_ROV
         ROMA_LAUNCH_CHECK();
