@@ -678,6 +678,8 @@ __global__ __launch_bounds__(256) void refiner_input_pix_kernel(const RefinerInp
   const int x0 = (int)fx0, y0 = (int)fy0;
   const float tx = ix - fx0, ty = iy - fy0;
   const float wgt[4] = {(1.f - tx) * (1.f - ty), tx * (1.f - ty), (1.f - tx) * ty, tx * ty};
+  // (guarded taps on purpose: the branch-free form that helps the vector kernel below - clamped address + select - was
+  //  measured SLOWER here, 0.94 vs 0.78 ms per step)
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
@@ -771,8 +773,8 @@ __global__ __launch_bounds__(256) void refiner_input_vec_kernel(const RefinerInp
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
-    ok[t] = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;  // zeros padding: out-of-image taps are skipped
-    off[t] = ((long)yy * a.W + xx) * a.ldf;
+    ok[t] = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;  // zeros padding: out-of-image taps are dropped (select below)
+    off[t] = ((long)min(max(yy, 0), a.H - 1) * a.W + min(max(xx, 0), a.W - 1)) * a.ldf;  // always a valid address
   }
   for (int c = sub * CV; c < a.C; c += lpp * CV) {
     *reinterpret_cast<uint4*>(d + c) = *reinterpret_cast<const uint4*>(fq + c);
@@ -780,13 +782,12 @@ __global__ __launch_bounds__(256) void refiner_input_vec_kernel(const RefinerInp
 #pragma unroll
     for (int j = 0; j < CV; ++j) r[j] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (ok[t]) {
-        float tv[CV];
-        VecIO<T>::ld(fs + off[t] + c, tv);
+    for (int t = 0; t < 4; ++t) {  // branch-free: the four tap loads of a channel piece are in flight together
+      float tv[CV];
+      VecIO<T>::ld(fs + off[t] + c, tv);
 #pragma unroll
-        for (int j = 0; j < CV; ++j) r[j] += wgt[t] * tv[j];
-      }
+      for (int j = 0; j < CV; ++j) r[j] = ok[t] ? r[j] + wgt[t] * tv[j] : r[j];
+    }
     VecIO<T>::st(d + a.C + c, r);
   }
   const float dx = a.disp_scale * (wx - pix_coord(x, a.W)), dy = a.disp_scale * (wy - pix_coord(y, a.H));
