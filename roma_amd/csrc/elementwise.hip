@@ -647,6 +647,34 @@ __global__ __launch_bounds__(256) void refiner_input_small_kernel(const RefinerI
 }
 
 // stride-1 refiner (C = 9, E = 6, 24 output channels): one thread per pixel, whole rows as 16-byte vectors
+template <typename T> struct VecIO;
+template <> struct VecIO<float> {
+  static constexpr int CV = 4;
+  __device__ static inline void ld(const float* p, float* v) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(p);
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+  }
+  __device__ static inline void st(float* p, const float* v) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
+};
+template <> struct VecIO<bf16_t> {
+  static constexpr int CV = 8;
+  __device__ static inline void ld(const bf16_t* p, float* v) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+  }
+  __device__ static inline void st(bf16_t* p, const float* v) {
+    uint4 u;
+    u.x = pack_bf16x2(v[0], v[1]);
+    u.y = pack_bf16x2(v[2], v[3]);
+    u.z = pack_bf16x2(v[4], v[5]);
+    u.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = u;
+  }
+};
+
 template <typename T, int C, int E>
 __global__ __launch_bounds__(256) void refiner_input_pix_kernel(const RefinerInputArgs a) {
   constexpr int LDF = 16, LDD = 24;
@@ -660,6 +688,51 @@ __global__ __launch_bounds__(256) void refiner_input_pix_kernel(const RefinerInp
   const T* fq = feat + ((long)b * HW + p) * LDF;
   const int simg = (b + a.shift) % a.nimg;
   const T* fs = feat + (long)simg * HW * LDF;
+  if constexpr (sizeof(T) == 2) {
+    // bf16: 16-byte accesses - a pixel's 16 feature channels are two loads (were three 8-byte ones), its 24 output channels
+    // three stores (were six): this kernel is bound by the number of memory instructions, not by bytes
+    static_assert(C <= 16 && 2 * C + E <= LDD && LDD == 24 && LDF == 16, "layout");
+    float q[16], xh[16];
+    VecIO<T>::ld(fq, q);
+    VecIO<T>::ld(fq + 8, q + 8);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xh[j] = 0.f;
+    const float wx = a.flow[pix * 2 + 0], wy = a.flow[pix * 2 + 1];
+    float ix = ((wx + 1.f) * a.W - 1.f) * 0.5f, iy = ((wy + 1.f) * a.H - 1.f) * 0.5f;
+    ix = fminf(fmaxf(ix, -1.0e6f), 1.0e6f);
+    iy = fminf(fmaxf(iy, -1.0e6f), 1.0e6f);
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float tx = ix - fx0, ty = iy - fy0;
+    const float wgt[4] = {(1.f - tx) * (1.f - ty), tx * (1.f - ty), (1.f - tx) * ty, tx * ty};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
+      if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+        const T* r = fs + ((long)yy * a.W + xx) * LDF;
+        float v[16];
+        VecIO<T>::ld(r, v);
+        VecIO<T>::ld(r + 8, v + 8);
+#pragma unroll
+        for (int j = 0; j < C; ++j) xh[j] += wgt[t] * v[j];
+      }
+    }
+    const float dx = a.disp_scale * (wx - pix_coord(x, a.W)), dy = a.disp_scale * (wy - pix_coord(y, a.H));
+    float o[LDD];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      o[c] = q[c];
+      o[C + c] = xh[c];
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) o[2 * C + e] = a.emb_w[e * 2 + 0] * dx + a.emb_w[e * 2 + 1] * dy + a.emb_b[e];
+#pragma unroll
+    for (int c = 2 * C + E; c < LDD; ++c) o[c] = 0.f;
+    T* d = reinterpret_cast<T*>(a.d) + pix * LDD;
+#pragma unroll
+    for (int c8 = 0; c8 < LDD / 8; ++c8) VecIO<T>::st(d + c8 * 8, o + c8 * 8);
+    return;
+  }
   float q[12], xh[12];
 #pragma unroll
   for (int c4 = 0; c4 < 3; ++c4) {
@@ -714,34 +787,6 @@ __global__ __launch_bounds__(256) void refiner_input_pix_kernel(const RefinerInp
 // window is walked row by row so each loaded vector feeds up to 4 outputs.  Workgroups are remapped so that each
 // XCD (private L2) owns a contiguous band of image rows: the 5-row vertical reuse then hits that XCD's L2 instead of
 // being replicated in all eight.
-template <typename T> struct VecIO;
-template <> struct VecIO<float> {
-  static constexpr int CV = 4;
-  __device__ static inline void ld(const float* p, float* v) {
-    const f32x4 x = *reinterpret_cast<const f32x4*>(p);
-    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
-  }
-  __device__ static inline void st(float* p, const float* v) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
-};
-template <> struct VecIO<bf16_t> {
-  static constexpr int CV = 8;
-  __device__ static inline void ld(const bf16_t* p, float* v) {
-    const uint4 u = *reinterpret_cast<const uint4*>(p);
-    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
-    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
-  }
-  __device__ static inline void st(bf16_t* p, const float* v) {
-    uint4 u;
-    u.x = pack_bf16x2(v[0], v[1]);
-    u.y = pack_bf16x2(v[2], v[3]);
-    u.z = pack_bf16x2(v[4], v[5]);
-    u.w = pack_bf16x2(v[6], v[7]);
-    *reinterpret_cast<uint4*>(p) = u;
-  }
-};
-
 // refiner input, vectorised: LPP lanes (a power of two) share one pixel, 64/LPP pixels per wave, 16 bytes per lane
 // per access.  The wave-per-pixel kernel above left 48 of 64 lanes idle at C = 64 (stride-2 refiner, 4.2 M pixels).
 template <typename T>
