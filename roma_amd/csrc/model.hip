@@ -901,7 +901,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       void* t1 = AL((size_t)nimg * (H / 2) * (W / 2) * 64, esz);
       static const int c64_env = getenv("ROMA_CONV64") ? atoi(getenv("ROMA_CONV64")) : 7;
       void* col1 = AL((size_t)nimg * H * W * 32, esz);  // (planned whichever form runs: the switch may change between calls)
-      if (act_dt == DT_BF16 && ((g_conv64_mode >= 0 ? g_conv64_mode : c64_env) & 4)) {
+      if (act_dt == DT_BF16 && ((g_conv64_mode >= 0 ? g_conv64_mode : c64_env) & 4) && (long)3 * H * W < (1l << 23)) {  // (its packed tap offsets)
         // first layer (Cin = 3), bf16: fused kernel straight from the f32 image (conv64.hip)
         RUN(conv3x3_c3_bf16_launch(imA, vgg[0].w, vgg[0].b, t0, B, H, W, st));
         RUN(conv3x3_c3_bf16_launch(imB, vgg[0].w, vgg[0].b, off(t0, (long)B * H * W * 64), B, H, W, st));
