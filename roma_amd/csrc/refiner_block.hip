@@ -17,6 +17,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "gemm.h"  // DT_*
 
 namespace roma {
@@ -723,8 +725,23 @@ template <int CP>
 static int launch_cp(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
                      const float* pw_b, int B, int H, int W, hipStream_t s) {
   typedef RBCfg<CP> Cf;
-  const int SY = H >= 256 ? 36 : 16;  // SY + 4 input rows are read per strip
   const int nxg = (W + Cf::PX - 1) / Cf::PX;
+  // strip height: SY + 4 input rows are read per strip (and ~2 more rows' worth of pipeline fill), and the 512 resident
+  // workgroups take the strips in rounds - pick the split of H that minimises rounds x (SY + 6).  ROMA_RB_SY overrides.
+  static const int sy_env = getenv("ROMA_RB_SY") ? atoi(getenv("ROMA_RB_SY")) : 0;
+  int SY = sy_env;
+  if (SY <= 0) {
+    long best = -1;
+    for (int yt = 1; yt <= std::max(1, H / 8); ++yt) {
+      const int sy = (H + yt - 1) / yt;
+      const long n = (long)B * nxg * ((H + sy - 1) / sy);
+      const long cost = ((n + 511) / 512) * (sy + 6);
+      if (best < 0 || cost < best) {
+        best = cost;
+        SY = sy;
+      }
+    }
+  }
   const long nb = (long)B * ((H + SY - 1) / SY) * nxg;
   ROMA_REQUIRE(nb < (1l << 30), "refiner_block: grid too large");
   const int nblocks = (int)nb;
