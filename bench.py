@@ -30,11 +30,7 @@ import subprocess
 import sys
 import time
 
-# --graph 1 only: ROCm 7.2's pre-built AQL packets for graph kernel nodes fault on the second replay of match() under this
-# loop's launch timing (profiles/r02_graph_replay_fault.md); read by libamdhip64 when it is loaded, i.e. before torch
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-
-import torch  # noqa: E402
+import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -110,8 +106,6 @@ def main():
     ap.add_argument("--upsample", type=int, default=864)
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="sub-batch HIP streams per GPU (2 = the library default: two half-batches, DESIGN.md section 4)")
-    ap.add_argument("--graph", type=int, default=0, choices=[0, 1],
-                    help="replay match() as a captured hipGraph (opt-in; see DEBUG_CLR_GRAPH_PACKET_CAPTURE at the top)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -157,7 +151,6 @@ def main():
         model = roma_outdoor(device=dev, weights=sd, dinov2_weights=dsd, coarse_res=args.coarse, upsample_res=args.upsample,
                              amp_dtype=amp, symmetric=True, upsample_preds=full, max_batch=args.batch)
         model.dual_stream = args.streams == 2
-        model.graph = bool(args.graph)  # opt-in (see the note at the top of this file)
         inp = {k: v.to(dev) for k, v in synthetic.make_inputs(args.batch, args.coarse, args.upsample if full else None,
                                                               seed=1 + rank).items()}
     n_pairs = args.batch * world
@@ -235,7 +228,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"roma_outdoor match() {what}, {args.batch} pairs/GPU/step, seeded synthetic weights + N(0,1) images",
-                   "global_batch": n_pairs, "hip_graph": bool(getattr(model, "graph", False)), "streams_per_gpu": int(os.environ.get("ROMA_STREAMS", args.streams)),
+                   "global_batch": n_pairs, "streams_per_gpu": int(os.environ.get("ROMA_STREAMS", args.streams)),
                    "parallelism": (f"pairs sharded x{world}, {'gloo (dry run)' if args.dry else 'RCCL'} gather of results "
                                    "(step i's gather overlaps step i+1's match)") if world > 1 else "single GPU",
                    "outputs_finite": finite},

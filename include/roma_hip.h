@@ -53,10 +53,7 @@ int roma_finalize(roma_handle_t h);
  *         backbone, encoders.py; 0 = keep it in f32),
  *         "streams" (1..4, default 2) / "dual_stream" (1 = 2 streams, 0 = 1): run a batch of >= 2 pairs as sub-batches on
  *         several HIP streams (+5 % at batch 8 with 2; side workspaces are allocated on first use; results are
- *         bit-identical to the single-stream schedule - DESIGN.md section 4),
- *         "graph" (default 0; 1 = capture the kernel schedule of each (batch, options) configuration into a hipGraph on
- *         its second call and replay it afterwards: one launch instead of ~1 600, for small batches where match() is
- *         host-bound; images / outputs go through persistent staging copies) */
+ *         bit-identical to the single-stream schedule - DESIGN.md section 4) */
 int roma_set_option(roma_handle_t h, const char* key, int value);
 /* "coarse_scale_factor": the displacement-embedding scale of the COARSE pass, sqrt(h_resized * w_resized / 560^2) of the
  * matcher's configured resolution (matcher.py:805) - it differs from the handle's own resolution only when the caller
@@ -171,9 +168,10 @@ int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const fl
                       int* match_b, void* ws_a, void* ws_b, void* stream);
 /* torch.multinomial(weights, k, replacement=False) of RegressionMatcher.sample (matcher.py:615-627): k distinct int64
  * indices, drawn with probability proportional to the non-negative f32 weights [n] (exponential race + radix select, no
- * sort; reproducible from `seed`; output order arbitrary).  At least k weights must be positive (the caller checks, as
- * torch does).  workspace: device memory of roma_op_multinomial_workspace(n) bytes. */
-long roma_op_multinomial_workspace(long n);
+ * sort; reproducible from `seed`), returned in DRAW order (ascending race key) like torch.multinomial, so a prefix of the
+ * result is itself a valid smaller sample.  If fewer than k weights are positive, zero-weight entries complete the sample
+ * (last), as on torch's GPU path.  workspace: device memory of roma_op_multinomial_workspace(n, k) bytes. */
+long roma_op_multinomial_workspace(long n, long k);
 int roma_op_multinomial(const float* weights, long n, long k, unsigned long long seed, long long* out_indices, void* workspace,
                         long workspace_bytes, void* stream);
 /* ---- Tiny RoMa (romatch/models/tiny.py), matcher side; the XFeat backbone is the caller's (model_zoo/__init__.py:24-27).

@@ -60,7 +60,7 @@ SIGNATURES = {
     "roma_op_mutual_nn": (_i, [_vp, _l, _vp, _l, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "roma_op_fb_consistency": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "roma_op_visualize_warp": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "roma_op_multinomial_workspace": (_l, [_l]),
+    "roma_op_multinomial_workspace": (_l, [_l, _l]),
     "roma_op_multinomial": (_i, [_vp, _l, _l, C.c_ulonglong, _vp, _vp, _l, _vp]),
     "roma_op_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "roma_op_tiny_pos_embed": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

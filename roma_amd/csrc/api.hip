@@ -93,7 +93,6 @@ int roma_set_option(roma_handle_t h, const char* key, int value) {
   else if (k == "fuse_refiner_blocks") h->m.fuse_refiner_blocks = value != 0;
   else if (k == "vit_bf16_residual") h->m.vit_bf16_residual = value != 0;
   else if (k == "dual_stream") h->m.n_streams = value != 0 ? 2 : 1;
-  else if (k == "graph") h->m.graph_mode = value != 0 ? 1 : 0;
   else if (k == "trace") h->m.trace_on = value != 0;
   else if (k == "streams") {
     ROMA_REQUIRE(value >= 1 && value <= Model::MAX_STREAMS, "roma_set_option: streams must be 1..4");
@@ -137,7 +136,7 @@ long roma_debug_fetch(roma_handle_t h, const char* name, void* dst_host, long nb
     set_error("roma_debug_fetch: destination too small");
     return ROMA_ERR_ARG;
   }
-  if (hipDeviceSynchronize() != hipSuccess) return ROMA_ERR_HIP;
+  if (hipSetDevice(h->m.cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return ROMA_ERR_HIP;
   if (hipMemcpy(dst_host, it->second.first, it->second.second, hipMemcpyDeviceToHost) != hipSuccess) return ROMA_ERR_HIP;
   return (long)it->second.second;
 }
@@ -156,7 +155,7 @@ long roma_debug_trace(roma_handle_t h, int slot, unsigned long long* sums_host, 
     set_error("roma_debug_trace: destination too small or tracing was never enabled");
     return ROMA_ERR_ARG;
   }
-  if (hipDeviceSynchronize() != hipSuccess) return ROMA_ERR_HIP;
+  if (hipSetDevice(h->m.cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return ROMA_ERR_HIP;
   if (hipMemcpy(sums_host, h->m.trace_dev[slot], (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
     return ROMA_ERR_HIP;
   if (names_host && names_bytes > 0) {
@@ -181,7 +180,6 @@ int roma_tuning(const char* key, int value) {
   else if (k == "gemm_dbg") g_gemm_tuning[1] = value;
   else if (k == "lc_mode") g_lc_mode = value;
   else if (k == "conv64") g_conv64_mode = value;
-  else if (k == "refiner_block") g_rb_mode = value;
   else {
     set_error("roma_tuning: unknown key " + k);
     return ROMA_ERR_ARG;
@@ -371,7 +369,7 @@ int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const fl
                           static_cast<unsigned long long*>(ws_b), S(stream));
 }
 
-long roma_op_multinomial_workspace(long n) { return (long)multinomial_workspace_bytes(n); }
+long roma_op_multinomial_workspace(long n, long k) { return (long)multinomial_workspace_bytes(n, k); }
 int roma_op_multinomial(const float* weights, long n, long k, unsigned long long seed, long long* out_indices, void* workspace,
                         long workspace_bytes, void* stream) {
   return multinomial_launch(weights, n, k, seed, out_indices, workspace, (size_t)workspace_bytes, S(stream));

@@ -443,7 +443,6 @@ static int launch8p(const GemmArgs& a, hipStream_t stream, const char* epi_name)
 // Decides whether this problem belongs to the 8-phase kernel and launches it; returns 1 when it did not take the
 // problem (the caller falls back to gemm.hip), 0 on success, < 0 on error.  `a` is the argument block AFTER
 // gemm_launch's own normalisation (qkv_pad / m_alg already applied).
-int gemm4w_try_launch(const GemmArgs& a, hipStream_t stream);  // gemm4w.hip (experimental; "gemm8p" tuning value 2)
 int conv64_try_launch(const GemmArgs& a, hipStream_t stream);  // conv64.hip (weight-stationary 3x3, Cin = 64)
 
 int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
@@ -472,10 +471,6 @@ int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
   }
   if (!tile256) return 1;
   if ((reinterpret_cast<uintptr_t>(a.C) & 15) != 0) return 1;
-  if (use == 2 && !conv) {  // experimental four-wave kernel for the plain bf16 problems it takes
-    const int r4 = gemm4w_try_launch(a, stream);
-    if (r4 <= 0) return r4;
-  }
   if (a.out_dt == DT_BF16) {
     if (a.mode == EPI_QKV) {
       if (!a.qkv_pad || conv || (a.heads * a.hd) % 64 != 0) return 1;

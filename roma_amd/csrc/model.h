@@ -76,7 +76,6 @@ class Model {
   unsigned long long* trace_dev[MAX_STREAMS_DECL] = {nullptr};
   std::vector<std::string> trace_names[MAX_STREAMS_DECL];
   int trace_n[MAX_STREAMS_DECL] = {0};
-  int graph_mode = 0;  // option "graph": replay match() as a captured hipGraph (model.hip match_graph)
   double coarse_scale_factor = 0.0;  // roma_set_option_f; 0 = sqrt(coarse_h * coarse_w / 560^2)
   std::map<std::string, HostTensor> host;
 
@@ -110,17 +109,6 @@ class Model {
   Arena side_arena[MAX_STREAMS - 1], side_persist[MAX_STREAMS - 1];
   hipStream_t side[MAX_STREAMS - 1] = {nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[MAX_STREAMS - 1] = {nullptr};
-  struct GraphSlot {
-    bool warmed = false;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    ~GraphSlot();
-  };
-  std::map<std::string, GraphSlot> graphs;  // one per (batch, options)
-  hipStream_t g_stream = nullptr;           // capture / replay stream (the caller's may be the un-capturable legacy stream)
-  hipEvent_t g_ev_in = nullptr, g_ev_out = nullptr;
-  float* io_buf = nullptr;                  // staging copies of the images / outputs the graphs work on
-  size_t io_off[6] = {0};
   std::vector<void*> owned;  // device allocations to free
   std::map<std::string, std::pair<void*, size_t>> dbg;
   // debug mode only (roma_debug_inject): device buffers that REPLACE a named intermediate of the next match() calls.
@@ -139,8 +127,6 @@ class Model {
   int ensure_side_streams(int n);
   int match_streams(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
                     float* cert, hipStream_t st);
-  int match_graph(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
-                  float* cert, hipStream_t st);
   int check_contract();
   int pack_weights();
   int match_impl(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,

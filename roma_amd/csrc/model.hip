@@ -32,10 +32,6 @@ Model::~Model() {
     if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
   }
   if (ev_fork) (void)hipEventDestroy(ev_fork);
-  graphs.clear();
-  if (g_stream) (void)hipStreamDestroy(g_stream);
-  if (g_ev_in) (void)hipEventDestroy(g_ev_in);
-  if (g_ev_out) (void)hipEventDestroy(g_ev_out);
   for (void* p : owned) (void)hipFree(p);
   for (auto& kv : dbg) (void)hipFree(kv.second.first);
   for (auto& kv : inject) (void)hipFree(kv.second.first);
@@ -507,98 +503,7 @@ int Model::match(int B, const float* ima, const float* imb, const float* ima_hr,
     ROMA_REQUIRE(ima_hr && imb_hr, "roma_match: upsample_preds requires im_A_high_res and im_B_high_res");
   }
   ROMA_CHECK_HIP(hipSetDevice(cfg.device));
-  static const int env_graph = getenv("ROMA_GRAPH") ? atoi(getenv("ROMA_GRAPH")) : -1;
-  const int gm = env_graph >= 0 ? env_graph : graph_mode;
-  if (gm != 0 && !debug && !prof_enabled()) return match_graph(B, ima, imb, ima_hr, imb_hr, warp, cert, st);
   return match_streams(B, ima, imb, ima_hr, imb_hr, warp, cert, st);
-}
-
-// ---------------------------------------------------------------- hipGraph replay of the whole schedule
-// match() is ~1 600 launches; at batch 8 the GPU is busy for ~110 ms and the host stays ahead, but a coarse-only single
-// pair is ~10 ms of kernels behind ~10 ms of hipLaunchKernel calls (host launch ~3.5 us each).  The schedule for a
-// given (batch, options) is static - same kernels, same arena addresses - so it is captured once from the caller's stream
-// (second call with that configuration; the first runs eagerly and warms function attributes / side streams) and replayed
-// with one hipGraphLaunch.  Caller buffers change from call to call, so the graph works on persistent staging copies of the
-// images and of the outputs (device-to-device copies on the caller's stream outside the graph: ~0.1 ms at batch 8).
-// Capture and replay run on a stream of the handle's own, fenced against the caller's stream with two events: the
-// caller's stream may be the legacy default stream (torch's default), which cannot be captured.
-Model::GraphSlot::~GraphSlot() {
-  if (exec) (void)hipGraphExecDestroy(exec);
-  if (graph) (void)hipGraphDestroy(graph);
-}
-
-int Model::match_graph(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
-                       float* cert, hipStream_t st) {
-  const size_t im_lo = (size_t)3 * cfg.coarse_h * cfg.coarse_w, im_hi = (size_t)3 * cfg.upsample_h * cfg.upsample_w;
-  const int Ho = cfg.upsample_preds ? cfg.upsample_h : cfg.coarse_h, Wo = cfg.upsample_preds ? cfg.upsample_w : cfg.coarse_w;
-  const size_t px = (size_t)Ho * Wo * (cfg.symmetric ? 2 : 1);
-  if (!io_buf) {  // staging for the largest configuration of this handle
-    const size_t mb = (size_t)cfg.max_batch;
-    const size_t pxmax = (size_t)std::max(cfg.coarse_h * cfg.coarse_w, cfg.upsample_h * cfg.upsample_w) * 2;
-    io_off[0] = 0;
-    io_off[1] = io_off[0] + mb * im_lo;
-    io_off[2] = io_off[1] + mb * im_lo;
-    io_off[3] = io_off[2] + mb * im_hi;
-    io_off[4] = io_off[3] + mb * im_hi;          // warp
-    io_off[5] = io_off[4] + mb * pxmax * 4;      // certainty
-    const size_t total = io_off[5] + mb * pxmax;
-    ROMA_CHECK_HIP(hipMalloc((void**)&io_buf, total * sizeof(float)));
-    owned.push_back(io_buf);
-  }
-  float *s_a = io_buf + io_off[0], *s_b = io_buf + io_off[1], *s_ah = io_buf + io_off[2], *s_bh = io_buf + io_off[3];
-  float *s_w = io_buf + io_off[4], *s_c = io_buf + io_off[5];
-  ROMA_CHECK_HIP(hipMemcpyAsync(s_a, ima, B * im_lo * 4, hipMemcpyDeviceToDevice, st));
-  ROMA_CHECK_HIP(hipMemcpyAsync(s_b, imb, B * im_lo * 4, hipMemcpyDeviceToDevice, st));
-  const bool hr = cfg.upsample_preds != 0;
-  if (hr) {
-    ROMA_CHECK_HIP(hipMemcpyAsync(s_ah, ima_hr, B * im_hi * 4, hipMemcpyDeviceToDevice, st));
-    ROMA_CHECK_HIP(hipMemcpyAsync(s_bh, imb_hr, B * im_hi * 4, hipMemcpyDeviceToDevice, st));
-  }
-  char key[160];
-  snprintf(key, sizeof key, "B%d s%d u%d a%d r%d f%d n%d c%.9g", B, cfg.symmetric, cfg.upsample_preds, cfg.attenuate_cert,
-           (int)vit_bf16_residual, (int)fuse_refiner_blocks, n_streams, coarse_scale_factor);
-  GraphSlot& g = graphs[key];
-  if (!g_stream) {
-    ROMA_CHECK_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-    ROMA_CHECK_HIP(hipEventCreateWithFlags(&g_ev_in, hipEventDisableTiming));
-    ROMA_CHECK_HIP(hipEventCreateWithFlags(&g_ev_out, hipEventDisableTiming));
-  }
-  ROMA_CHECK_HIP(hipEventRecord(g_ev_in, st));
-  ROMA_CHECK_HIP(hipStreamWaitEvent(g_stream, g_ev_in, 0));
-  int rc = 0;
-  // ROCm 7.2 note: with the runtime's pre-built graph packets (DEBUG_CLR_GRAPH_PACKET_CAPTURE, on by default) the second
-  // or a later replay of this graph ends in a GPU memory access fault under some launch timings; with that feature off
-  // every replay is clean and bit-identical (profiles/r02_graph_replay_fault.md: bisection).  Nothing on this side changes
-  // it (one launch in flight at a time was tried), so the option stays opt-in and the callers that use it set that
-  // variable before the runtime is loaded.
-  if (g.exec) {
-    ROMA_CHECK_HIP(hipGraphLaunch(g.exec, g_stream));
-  } else if (!g.warmed) {
-    rc = match_streams(B, s_a, s_b, hr ? s_ah : nullptr, hr ? s_bh : nullptr, s_w, s_c, g_stream);
-    g.warmed = true;
-  } else {
-    ROMA_CHECK_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeRelaxed));
-    rc = match_streams(B, s_a, s_b, hr ? s_ah : nullptr, hr ? s_bh : nullptr, s_w, s_c, g_stream);
-    hipGraph_t graph = nullptr;
-    const hipError_t ce = hipStreamEndCapture(g_stream, &graph);
-    if (rc == 0 && ce != hipSuccess) {
-      set_error(std::string("roma_match: hipStreamEndCapture: ") + hipGetErrorString(ce));
-      rc = ROMA_ERR_HIP;
-    }
-    if (rc != 0) {
-      if (graph) (void)hipGraphDestroy(graph);
-      return rc;
-    }
-    g.graph = graph;
-    ROMA_CHECK_HIP(hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
-    ROMA_CHECK_HIP(hipGraphLaunch(g.exec, g_stream));
-  }
-  if (rc) return rc;
-  ROMA_CHECK_HIP(hipEventRecord(g_ev_out, g_stream));
-  ROMA_CHECK_HIP(hipStreamWaitEvent(st, g_ev_out, 0));
-  ROMA_CHECK_HIP(hipMemcpyAsync(warp, s_w, (size_t)B * px * 4 * 4, hipMemcpyDeviceToDevice, st));
-  ROMA_CHECK_HIP(hipMemcpyAsync(cert, s_c, (size_t)B * px * 4, hipMemcpyDeviceToDevice, st));
-  return 0;
 }
 
 int Model::match_streams(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
@@ -807,8 +712,8 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
   }
   auto CK = [&](const std::string& name, const void* p, size_t bytes) -> int {
     if (!tracing) return 0;
+    if (trace_n[tslot] >= TRACE_MAX) return 0;  // table full: later stages are not traced (roma_debug_trace sees <= TRACE_MAX)
     const int k = trace_n[tslot]++;
-    if (k >= TRACE_MAX) return 0;
     if ((int)trace_names[tslot].size() <= k) trace_names[tslot].push_back(name);
     else trace_names[tslot][k] = name;
     return checksum_launch(p, bytes, trace_dev[tslot] + k, st);

@@ -11,7 +11,6 @@ namespace roma {
 // in/out: [B,H,W,Cp] bf16 channels-last (must not alias); dw_w f32 [25][Cp], dw_b f32 [Cp] (BN folded);
 // pw bf16 [Cp][ldpw] (K contiguous), pw_b f32 [Cp].  Supported Cp: 24, 144.  Returns 0 / negative error code.
 bool refiner_block_supported(int Cp, int dt);
-extern int g_rb_mode;  // roma_tuning("refiner_block", v): 0 four-wave kernel (default), 1 wave-specialised (experimental), -1 env ROMA_RB_V2
 int refiner_block_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
                          const float* pw_b, int B, int H, int W, int Cp, int dt, hipStream_t s);
 }  // namespace roma

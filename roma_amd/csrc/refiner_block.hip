@@ -370,355 +370,10 @@ __global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __r
 }
 #undef ROMA_RB_ISSUE_ROW
 
-// =====================================================================================================================
-// Wave-specialised form - EXPERIMENTAL, off by default (roma_tuning("refiner_block", 1) / ROMA_RB_V2=1), bit-identical to
-// the kernel above and tested with it.  Phase ablations of the kernel above (ROMA_RB_DBG,
-// profiles/r02_v27_refiner_block_ablation.log: 827 us at 16 x 432^2 x 144; 417 without the depthwise phase, 600 without
-// the 1x1 phase, 325 with neither) show its three phases - VALU stencil, MFMA 1x1, store - adding up instead of
-// overlapping: every wave walks through all of them between the same two barriers, so the MFMA pipe and the store path
-// idle while the VALU works and vice versa.  This form splits the roles over eight waves so that they can overlap inside
-// one CU.  MEASURED: 834 / 520 us against 818 / 432 us (C = 144 / 24) - no gain.  Its own ablations
-// (profiles/r02_v29_refiner_block2_ablation.log) say why: the stencil role alone needs 510 us (2 830 cycles per 28-pixel
-// row: its 200 v_pk_fma_f32 issue at 8 cycles each here, not 4, + 130 other VALU operations), the pointwise + memory role
-// alone 623 us (3 400 cycles per row for 9-18 MFMAs: ~350 instructions of address arithmetic, branches on the counted
-// waits, bias / pack / staging around them, every LDS and MFMA latency exposed with one wave per SIMD and role), and the
-// two share each SIMD's issue slots.  The per-ROW fixed work is the problem, not the phase order: the next step is a
-// wider row tile per workgroup (56+ pixels) with the tap weights in registers as here, not this split.
-// A workgroup is EIGHT waves with two roles:
-//   * waves 0-3 (depthwise): exactly the stencil above - read input row t from the ring, update the 5 rolling rows,
-//     write the finished row o = t - 4 (bf16) to Xt[o & 1].  No vector-memory traffic at all.
-//   * waves 4-7 (pointwise + memory): per iteration they refill the ring slot the stencil released one iteration ago
-//     (LDS-DMA, input row t + NR - 1), stream output row t - 6 from Ot[t & 1] to HBM, run the 1x1 of row t - 5 from
-//     Xt[(t - 5) & 1] on MFMA into Ot[(t - 5) & 1], and wait (counted vmcnt) for input row t + 1.
-// ONE barrier per row for all eight waves; Xt and Ot are double buffered, so the roles work on different rows and the
-// three pipelines (VALU / MFMA / memory) overlap inside one CU instead of across two workgroups.  One workgroup per CU
-// (8 waves, <= 160 KiB LDS), the same two waves per SIMD as before - but one of each role.
-__device__ __attribute__((aligned(256))) unsigned int g_rb_dump[256 * 4 * 2];  // stores of iterations that have no row yet
-
-template <int CP> struct RB2Cfg {
-  typedef RBCfg<CP> Cf;
-  static constexpr int NR = CP == 24 ? 8 : 6;  // ring rows (the refill runs NR - 1 rows ahead of the stencil)
-  static constexpr int RING_BYTES = NR * Cf::RSTRIDE;
-  static constexpr int XT_BYTES = Cf::PXB * 32 * Cf::XROW;
-  static constexpr int OT_BYTES = Cf::PX * Cf::OPIX;
-  static constexpr int OFF_XT = Cf::OFF_XT;
-  static constexpr int OFF_OT = OFF_XT + 2 * XT_BYTES;
-  static constexpr int WORK_BYTES = OFF_OT + 2 * OT_BYTES;
-  static_assert(OFF_OT % 16 == 0 && XT_BYTES % 16 == 0 && OT_BYTES % 16 == 0, "alignment");
-  static_assert(WORK_BYTES + RING_BYTES <= 160 * 1024, "one workgroup per CU");
-  static_assert((NR - 2) * (Cf::KW + 2) + 2 < 64, "vmcnt range");
-};
-
-template <int CP>
-__global__ __launch_bounds__(512, 1) void refiner_block2_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
-                                                                const float* __restrict__ dww, const float* __restrict__ dwb,
-                                                                const bf16_t* __restrict__ pw, long ldpw,
-                                                                const float* __restrict__ pwb, int B, int H, int W, int SY,
-                                                                int nxg, int nblocks, int dbg) {
-  typedef RBCfg<CP> Cf;
-  typedef RB2Cfg<CP> C2;
-  constexpr int GC = Cf::GC, XQ = Cf::XQ, PX = Cf::PX, PXB = Cf::PXB, KS = Cf::KS, NR = C2::NR, KW = Cf::KW;
-  constexpr int XROW = Cf::XROW, NDMA = Cf::NDMA, RSTRIDE = Cf::RSTRIDE;
-  __shared__ __attribute__((aligned(1024))) unsigned char ring[C2::RING_BYTES];  // DMA target: read with inline asm only
-  __shared__ __attribute__((aligned(16))) unsigned char work[C2::WORK_BYTES];
-  lds_u8* const wk = (lds_u8*)work;
-  lds_f32* const wsm = (lds_f32*)wk;                         // [26][CP] depthwise taps + bias
-  lds_f32* const pbs = (lds_f32*)(wk + Cf::OFF_PWB);         // [CP] 1x1 bias
-  lds_u8* const Wt = wk + Cf::OFF_WT;                        // [TAIL][XROW] remainder-block 1x1 weights
-  lds_u8* const Xt0 = wk + C2::OFF_XT;                       // 2 x [PXB*32][XROW] depthwise output rows (bf16)
-  lds_u8* const Ot0 = wk + C2::OFF_OT;                       // 2 x [PX][OPIX] block output rows (bf16)
-
-  const int per_xcd = (nblocks + 7) / 8;  // each XCD owns a contiguous band of strips (vertical halo hits its own L2)
-  const long lb = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-  if (lb >= nblocks) return;
-  const int xg = (int)(lb % nxg);
-  long rr = lb / nxg;
-  const int yt = (H + SY - 1) / SY;
-  const int ys = (int)(rr % yt) * SY;
-  const int b = (int)(rr / yt);
-  const int tid8 = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid8 >> 6);
-  const bool is_dw = wave < 4;
-  const int tid = tid8 & 255;  // index inside the role
-  const int wv = wave & 3, lane = tid8 & 63, l31 = lane & 31, hh = lane >> 5;
-  const int x0 = xg * PX;
-  const int sy = min(SY, H - ys);
-  const int T = sy + 4;  // input rows ys-2 .. ys+sy+1
-  const int npx = min(PX, W - x0);
-
-  // ---- one-time staging (ordinary loads: they are all retired before the first DMA is issued)
-  {
-    constexpr int nvec = 26 * GC;
-    for (int i = tid8; i < nvec; i += 512)
-      *(lds_f32x4*)(wsm + i * 4) =
-          *reinterpret_cast<const f32x4*>(i < 25 * GC ? dww + (long)i * 4 : dwb + (long)(i - 25 * GC) * 4);
-    if (tid8 < GC) *(lds_f32x4*)(pbs + tid8 * 4) = *reinterpret_cast<const f32x4*>(pwb + tid8 * 4);
-    constexpr int wslots = Cf::TAIL * (XROW / 16);
-    for (int i = tid8; i < wslots; i += 512) {
-      const int n = i / (XROW / 16), sl = i - n * (XROW / 16);
-      u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-      if (sl < CP * 2 / 16) v = *reinterpret_cast<const u32x4_t*>(pw + (long)(32 * Cf::NBF + n) * ldpw + sl * 8);
-      *(lds_u32x4*)(Wt + n * XROW + sl * 16) = v;
-    }
-    for (int i = tid8; i < 2 * C2::XT_BYTES / 16; i += 512) *(lds_u32x4*)(Xt0 + i * 16) = u32x4_t{0u, 0u, 0u, 0u};
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  if (is_dw) {
-    // =============================================================== depthwise role
-    ROMA_RB_BARRIER();  // staged tiles visible
-    ROMA_RB_BARRIER();  // input row 0 landed (the other role waited for it)
-    const int cg = tid % GC, xq = tid / GC;
-    const int xb = x0 + xq * 4;
-    const bool active = xq < XQ && xb < W;
-    const int c = cg * 4;
-    const f32x4 bx = *(lds_f32x4*)(wsm + 25 * CP + c);
-    const f32x2 bias0 = f32x2{bx[0], bx[1]}, bias1 = f32x2{bx[2], bx[3]};
-    f32x2 acc[5][4][2];
-#pragma unroll
-    for (int s5 = 0; s5 < 5; ++s5)
-#pragma unroll
-      for (int px = 0; px < 4; ++px) {
-        acc[s5][px][0] = bias0;
-        acc[s5][px][1] = bias1;
-      }
-    f32x4 wt[25];  // depthwise taps of this lane's 4 channels
-#pragma unroll
-    for (int i = 0; i < 25; ++i) wt[i] = *(lds_f32x4*)(wsm + i * CP + c);
-#pragma unroll
-    for (int i = 0; i < 25; ++i) asm volatile("" : "+v"(wt[i]));
-    const unsigned ring_lds = (unsigned)(size_t)((lds_u8*)ring);
-    const unsigned rd0 = ring_lds + (unsigned)((xq * 4 * CP + c) * 2);
-    int slot = 0;
-#pragma nounroll
-    for (int t = 0; t < T + 2; ++t) {
-      const int o = t - 4;  // output row (relative to ys) finished by input row t
-      if (active && t < T && !(dbg & 1)) {
-        lds_u8* const Xtw = Xt0 + (o & 1) * C2::XT_BYTES;
-      unsigned long long cr[8];
-      const unsigned ra = rd0 + (unsigned)slot * RSTRIDE;
-      asm volatile(
-          "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:%9\n\tds_read_b64 %2, %8 offset:%10\n\t"
-          "ds_read_b64 %3, %8 offset:%11\n\tds_read_b64 %4, %8 offset:%12\n\tds_read_b64 %5, %8 offset:%13\n\t"
-          "ds_read_b64 %6, %8 offset:%14\n\tds_read_b64 %7, %8 offset:%15\n\ts_waitcnt lgkmcnt(0)"
-          : "=&v"(cr[0]), "=&v"(cr[1]), "=&v"(cr[2]), "=&v"(cr[3]), "=&v"(cr[4]), "=&v"(cr[5]), "=&v"(cr[6]), "=&v"(cr[7])
-          : "v"(ra), "n"(CP * 2), "n"(CP * 4), "n"(CP * 6), "n"(CP * 8), "n"(CP * 10), "n"(CP * 12), "n"(CP * 14)
-          : "memory");
-      // Column-major tap order: for tap column kx only the 4-wide window v[kx..kx+3] of converted inputs is live (the
-      // other columns stay packed bf16).  The 25 x 4 tap weights are REGISTERS in this role (no 1x1 weights, no MFMA
-      // accumulators here): the four-wave kernel re-reads them from LDS for every row.
-#define ROMA_RB_CVT(J)                                                                             \
-  {                                                                                                \
-    const uint32_t lo_ = (uint32_t)cr[J], hi_ = (uint32_t)(cr[J] >> 32);                           \
-    v[J][0] = f32x2{__uint_as_float(lo_ << 16), __uint_as_float(lo_ & 0xffff0000u)};               \
-    v[J][1] = f32x2{__uint_as_float(hi_ << 16), __uint_as_float(hi_ & 0xffff0000u)};               \
-  }
-      f32x2 v[8][2];
-      ROMA_RB_CVT(0) ROMA_RB_CVT(1) ROMA_RB_CVT(2)
-#pragma unroll
-      for (int kx = 0; kx < 5; ++kx) {
-        ROMA_RB_CVT(kx + 3)
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {  // acc[k] holds output row t - 4 + k (tap row ky = 4 - k)
-          const f32x4 wx = wt[(4 - k) * 5 + kx];
-          const f32x2 w0 = f32x2{wx[0], wx[1]}, w1 = f32x2{wx[2], wx[3]};
-#pragma unroll
-          for (int px = 0; px < 4; ++px) {
-            acc[k][px][0] = v[px + kx][0] * w0 + acc[k][px][0];
-            acc[k][px][1] = v[px + kx][1] * w1 + acc[k][px][1];
-          }
-        }
-      }
-#undef ROMA_RB_CVT
-      if (o >= 0) {
-        lds_u8* xrow = Xtw + (xq * 4) * XROW + cg * 8;
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-          u32x2_t u;
-          u.x = pack_bf16x2(fmaxf(acc[0][px][0][0], 0.f), fmaxf(acc[0][px][0][1], 0.f));
-          u.y = pack_bf16x2(fmaxf(acc[0][px][1][0], 0.f), fmaxf(acc[0][px][1][1], 0.f));
-          *(lds_u32x2*)(xrow + px * XROW) = u;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-          acc[k][px][0] = acc[k + 1][px][0];
-          acc[k][px][1] = acc[k + 1][px][1];
-        }
-#pragma unroll
-      for (int px = 0; px < 4; ++px) {
-        acc[4][px][0] = bias0;
-        acc[4][px][1] = bias1;
-      }
-      }
-      ROMA_RB_BARRIER();  // Xt[o & 1] complete; ring slot `slot` is free
-      slot = slot + 1 == NR ? 0 : slot + 1;
-    }
-  } else {
-    // =============================================================== pointwise + memory role
-    // weights of this wave's own 32-channel block stay in registers (A operand: row = channel, 8 consecutive k per lane)
-    u32x4_t wown[Cf::NBF ? KS : 1];
-    if constexpr (Cf::NBF > 0) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        wown[ks] = *reinterpret_cast<const u32x4_t*>(pw + (long)(32 * wv + l31) * ldpw + ks * 16 + hh * 8);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wown[ks]));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    // DMA descriptors: wave wv issues the 1 KiB pieces wv, wv+4, .. of every input row; lane -> 16-byte chunk
-    const char* zsrc = reinterpret_cast<const char*>(g_rb_zero_page);
-    const char* inb = reinterpret_cast<const char*>(in + ((long)b * H * W) * CP);
-    const int qoff0 = (wv * 64 + lane) * 16;  // piece q of this wave starts 4 KiB * q further
-    bool qok[KW];
-#pragma unroll
-    for (int q = 0; q < KW; ++q) {
-      const int chunk = (wv + 4 * q) * 64 + lane;
-      const int x = x0 - 2 + chunk / (CP / 8);
-      qok[q] = chunk * 16 < Cf::IN_ROWB && x >= 0 && x < W;
-    }
-    const int kw = (NDMA - wv + 3) / 4;  // pieces this wave really issues per row
-#define ROMA_RB2_ISSUE_ROW(RROW, SLOT)                                                                 \
-  {                                                                                                    \
-    const int yy_ = ys - 2 + (RROW);                                                                   \
-    const bool rok_ = (RROW) < T && yy_ >= 0 && yy_ < H;                                               \
-    const char* rb_ = inb + ((long)(rok_ ? yy_ : 0) * W + x0 - 2) * (CP * 2);                          \
-    _Pragma("unroll") for (int q = 0; q < KW; ++q) {                                                   \
-      if (wv + 4 * q < NDMA)                                                                           \
-        rb_glds16((rok_ && qok[q]) ? rb_ + qoff0 + q * 4096 : zsrc, (lds_u8*)ring + (SLOT) * RSTRIDE + (wv + 4 * q) * 1024); \
-    }                                                                                                  \
-  }
-    ROMA_RB_BARRIER();  // staged tiles visible; nothing of ours in flight yet
-#pragma unroll
-    for (int r = 0; r < NR - 1; ++r) ROMA_RB2_ISSUE_ROW(r, r);
-    if (kw == KW) ROMA_RB_WAIT_VM((NR - 2) * KW); else ROMA_RB_WAIT_VM((NR - 2) * (KW - 1));
-    ROMA_RB_BARRIER();  // input row 0 landed
-
-    bf16_t* obase = out + ((long)b * H * W) * CP;
-    u32x4_t* dump = reinterpret_cast<u32x4_t*>(g_rb_dump) + tid * 2;
-    const int n16 = npx * (CP * 2 / 16);
-    int slotr = NR - 1;  // slot of input row t + NR - 1
-#pragma nounroll
-    for (int t = 0; t < T + 2; ++t) {
-      // (1) refill the ring: input row t + NR - 1 into the slot the stencil released at the last barrier
-      if (!(dbg & 8)) ROMA_RB2_ISSUE_ROW(t + NR - 1, slotr);
-      slotr = slotr + 1 == NR ? 0 : slotr + 1;
-      // (2) stream output row t - 6 out of Ot[t & 1]: always exactly two 16-byte stores per lane (the vmcnt below
-      // counts on it): clamped duplicates inside a row, the dump buffer while there is no row
-      {
-        const int rs = t - 6;
-        const bool has = rs >= 0 && rs < sy;
-        lds_u8* const Otr = Ot0 + (rs & 1) * C2::OT_BYTES;
-        bf16_t* orow = obase + ((long)(ys + (has ? rs : 0)) * W + x0) * CP;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int j = min(tid + 256 * it, n16 - 1);
-          const int jp = j / (CP * 2 / 16), jc = j - jp * (CP * 2 / 16);  // piece -> (pixel, 16-byte column): un-pad
-          const u32x4_t q = *(lds_u32x4*)(Otr + jp * Cf::OPIX + jc * 16);
-          u32x4_t* dst = has ? reinterpret_cast<u32x4_t*>(orow + j * 8) : dump + it;
-          if (!(dbg & 4)) *dst = q;
-        }
-      }
-      // (3) 1x1 convolution of output row t - 5 on MFMA, Xt[(t - 5) & 1] -> Ot[(t - 5) & 1]
-      const int rm = t - 5;
-      if (rm >= 0 && rm < sy && !(dbg & 2)) {
-        lds_u8* const Xtr = Xt0 + (rm & 1) * C2::XT_BYTES;
-        lds_u8* const Otw = Ot0 + (rm & 1) * C2::OT_BYTES;
-      // ---------------- 1x1 convolution of output row o on MFMA, out of LDS
-      if constexpr (Cf::NBF > 0) {
-        f32x16 oa[PXB];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 bq = *(lds_f32x4*)(pbs + 32 * wv + 8 * g + 4 * hh);
-#pragma unroll
-          for (int u = 0; u < PXB; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) oa[u][4 * g + j] = bq[j];
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-          for (int u = 0; u < PXB; ++u) {
-            const u32x4_t xf = *(lds_u32x4*)(Xtr + (u * 32 + l31) * XROW + ks * 32 + hh * 16);
-            oa[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wown[ks]),
-                                                            __builtin_bit_cast(bf16x8_t, xf), oa[u], 0, 0, 0);
-          }
-#pragma unroll
-        for (int u = 0; u < PXB; ++u) {
-          const int pxl = u * 32 + l31;
-          if (pxl < PX) {
-            lds_u8* orow = Otw + pxl * Cf::OPIX + (32 * wv + 4 * hh) * 2;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              u32x2_t q;
-              q.x = pack_bf16x2(oa[u][4 * g + 0], oa[u][4 * g + 1]);
-              q.y = pack_bf16x2(oa[u][4 * g + 2], oa[u][4 * g + 3]);
-              *(lds_u32x2*)(orow + g * 16) = q;
-            }
-          }
-        }
-      }
-      // remainder block (channels 32*NBF ..): its pixel blocks rotate over the waves
-#pragma unroll
-      for (int pb = 0; pb < PXB; ++pb) {
-        if (((pb + rm) & 3) != wv) continue;
-        int lanev = lane;  // opaque copy: keeps the (loop-invariant) LDS addresses below from being hoisted into
-        asm volatile("" : "+v"(lanev));  // long-lived registers - this kernel sits exactly at the 256-VGPR budget
-        const int l31v = lanev & 31, hhv = lanev >> 5;
-        const int wrow = l31v < Cf::TAIL ? l31v : l31v - Cf::TAIL;  // rows >= TAIL of the MFMA tile are never stored
-        f32x16 ta;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-          if (8 * g + 4 * hhv < Cf::TAIL) bq = *(lds_f32x4*)(pbs + 32 * Cf::NBF + 8 * g + 4 * hhv);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) ta[4 * g + j] = bq[j];
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const u32x4_t wf = *(lds_u32x4*)(Wt + wrow * XROW + ks * 32 + hhv * 16);
-          const u32x4_t xf = *(lds_u32x4*)(Xtr + (pb * 32 + l31v) * XROW + ks * 32 + hhv * 16);
-          ta = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, xf),
-                                                       ta, 0, 0, 0);
-        }
-        const int pxl = pb * 32 + l31v;
-        if (pxl < PX) {
-          lds_u8* orow = Otw + pxl * Cf::OPIX + (32 * Cf::NBF + 4 * hhv) * 2;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            if (8 * g + 4 * hhv < Cf::TAIL) {
-              u32x2_t q;
-              q.x = pack_bf16x2(ta[4 * g + 0], ta[4 * g + 1]);
-              q.y = pack_bf16x2(ta[4 * g + 2], ta[4 * g + 3]);
-              *(lds_u32x2*)(orow + g * 16) = q;
-            }
-          }
-        }
-      }
-      }
-      // (4) input row t + 1 must have landed before the barrier hands it to the stencil.  Issued after its DMA: in steady
-      // state NR - 2 whole iterations (kw pieces + 2 stores) and the 2 stores of its own iteration; for the rows of the
-      // prologue at least (NR - 2) kw pieces.
-      if (t >= NR - 2) {
-        if (kw == KW) ROMA_RB_WAIT_VM((NR - 2) * (KW + 2) + 2); else ROMA_RB_WAIT_VM((NR - 2) * (KW + 1) + 2);
-      } else {
-        if (kw == KW) ROMA_RB_WAIT_VM((NR - 2) * KW); else ROMA_RB_WAIT_VM((NR - 2) * (KW - 1));
-      }
-      ROMA_RB_BARRIER();  // Ot[(t - 5) & 1] complete, input row t + 1 visible
-    }
-    ROMA_RB_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
-#undef ROMA_RB2_ISSUE_ROW
-  }
-}
-
 // (A stand-alone depthwise kernel on the same LDS-DMA ring was measured for the wide scales, C = 576 / 1152 / 1408:
 //  0.541 vs 0.504 ms at 16x216x216x576, 0.299 vs 0.266 ms at 16x108x108x1152 - slower than the register-prefetch
 //  kernel in elementwise.hip.  The depthwise phase is bound by its 200 v_pk_fma_f32 + 25 LDS weight reads per row,
 //  not by load latency; the ring only pays off here, where it also frees the registers the 1x1 weights need.)
-int g_rb_mode = -1;  // roma_tuning("refiner_block", v): 0 = the four-wave kernel, 1 = the wave-specialised one, -1 = env ROMA_RB_V2 (default 0)
-
 bool refiner_block_supported(int Cp, int dt) { return dt == DT_BF16 && (Cp == 24 || Cp == 144); }
 
 template <int CP>
@@ -752,13 +407,6 @@ static int launch_cp(const void* in, void* out, const float* dw_w, const float* 
     fprintf(stderr, "refiner_block<%d>: %d workgroups/CU, grid %d\n", CP, nb_cu, nblocks);
   }
   dim3 grid((unsigned)(((nblocks + 7) / 8) * 8));
-  static const int v2_env = getenv("ROMA_RB_V2") ? atoi(getenv("ROMA_RB_V2")) : 0;
-  if (g_rb_mode >= 0 ? g_rb_mode : v2_env) {  // wave-specialised form
-    hipLaunchKernelGGL(refiner_block2_kernel<CP>, grid, dim3(512), 0, s, (const bf16_t*)in, (bf16_t*)out, dw_w, dw_b,
-                       (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks, dbg & 15);
-    ROMA_LAUNCH_CHECK();
-    return 0;
-  }
   hipLaunchKernelGGL(refiner_block_kernel<CP>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, dw_w, dw_b,
                      (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks, dbg);
   ROMA_LAUNCH_CHECK();

@@ -5,9 +5,10 @@
 #include "common.h"
 
 namespace roma {
-size_t multinomial_workspace_bytes(long n);
-// out: k distinct indices (int64) drawn without replacement with probability proportional to weights (>= 0); the caller
-// guarantees at least k positive weights (checked by the Python wrapper like torch does).  ws: device workspace.
+size_t multinomial_workspace_bytes(long n, long k);
+// out: k distinct indices (int64), in draw order, drawn without replacement with probability proportional to weights
+// (>= 0).  Like torch on a GPU, nobody checks that k weights are positive: if fewer are, zero-weight entries complete
+// the sample (they come last).  ws: device workspace.
 int multinomial_launch(const float* weights, long n, long k, unsigned long long seed, long long* out, void* ws, size_t ws_bytes,
                        hipStream_t s);
 }  // namespace roma

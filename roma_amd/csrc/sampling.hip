@@ -9,7 +9,10 @@
 // Selection of the k smallest of n keys without sorting: positive floats order like their bit patterns, so a 3-pass radix
 // select (11 + 11 + 10 bits; LDS histograms, one small scan kernel per pass) finds the k-th key exactly; a final pass
 // compacts every index with key < T and as many with key == T as are still missing.  n = 1.5 M, k = 40 000: ~25 us.
-// The output order is arbitrary (the reference only indexes with it).
+// The sample is then put in DRAW order (ascending race key = the order sequential draws would have produced them, which is
+// what torch.multinomial returns): callers that truncate or stride the result (`matches[:N]`) get a random subset, not the
+// spatially ordered one the compaction leaves.  k <= 40 000 in match(): an all-pairs rank (k^2 compares from LDS tiles) is
+// ~30 us and needs no sort.
 #include "sampling.h"
 
 #include <stdint.h>
@@ -39,7 +42,8 @@ __global__ __launch_bounds__(256) void race_keys_kernel(const float* __restrict_
   float key = __int_as_float(0x7f800000);  // +inf
   if (wi > 0.f) {
     const uint64_t r = mix64(mix64(seed + 0x9e3779b97f4a7c15ull * (uint64_t)(i + 1)) ^ seed);
-    const float u = ((float)(r >> 40) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1): 24 random bits, never 0 or 1
+    // (0, 1) exclusive: 23 random bits + 0.5 is exact in f32 (24 significant bits), so u is never rounded up to 1
+    const float u = ((float)(r >> 41) + 0.5f) * (1.0f / 8388608.0f);
     key = -__logf(u) / wi;
     key = fminf(key, 3.0e38f);  // keep finite keys below +inf
     atomicAdd(&st->n_positive, 1u);
@@ -103,16 +107,40 @@ __global__ __launch_bounds__(256) void race_compact_kernel(const float* __restri
   }
 }
 
-size_t multinomial_workspace_bytes(long n) { return sizeof(SelState) + 2048 * sizeof(unsigned) + (size_t)n * sizeof(float); }
+// rank of every selected element among the selected (key, index) pairs; out[rank] = index
+__global__ __launch_bounds__(256) void race_order_kernel(const float* __restrict__ keys, const long long* __restrict__ sel, long k,
+                                                         long long* __restrict__ out) {
+  __shared__ float tk[256];
+  __shared__ long long ti[256];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long long mi = i < k ? sel[i] : 0;
+  const float ki = i < k ? keys[mi] : 0.f;
+  long rank = 0;
+  for (long j0 = 0; j0 < k; j0 += 256) {
+    const long j = j0 + threadIdx.x;
+    __syncthreads();
+    ti[threadIdx.x] = j < k ? sel[j] : -1;
+    tk[threadIdx.x] = j < k ? keys[sel[j]] : 0.f;
+    __syncthreads();
+    const int m = (int)((k - j0) < 256 ? (k - j0) : 256);
+    for (int t = 0; t < m; ++t) rank += (tk[t] < ki || (tk[t] == ki && ti[t] < mi)) ? 1 : 0;
+  }
+  if (i < k) out[rank] = mi;
+}
+
+size_t multinomial_workspace_bytes(long n, long k) {
+  return sizeof(SelState) + 2048 * sizeof(unsigned) + (size_t)n * sizeof(float) + (size_t)(k > 0 ? k : 0) * sizeof(long long) + 16;
+}
 
 int multinomial_launch(const float* weights, long n, long k, unsigned long long seed, long long* out, void* ws, size_t ws_bytes,
                        hipStream_t s) {
   ROMA_REQUIRE(weights && out && ws && n > 0 && k > 0 && k <= n, "multinomial: bad arguments (need 0 < k <= n)");
   ROMA_REQUIRE(n < (1l << 31), "multinomial: n too large");
-  ROMA_REQUIRE(ws_bytes >= multinomial_workspace_bytes(n), "multinomial: workspace too small (roma_op_multinomial_workspace)");
+  ROMA_REQUIRE(ws_bytes >= multinomial_workspace_bytes(n, k), "multinomial: workspace too small (roma_op_multinomial_workspace)");
   SelState* st = reinterpret_cast<SelState*>(ws);
   unsigned* hist = reinterpret_cast<unsigned*>(st + 1);
   float* keys = reinterpret_cast<float*>(hist + 2048);
+  long long* sel = reinterpret_cast<long long*>((reinterpret_cast<uintptr_t>(keys + n) + 15) & ~(uintptr_t)15);  // compaction order
   ROMA_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(SelState) + 2048 * sizeof(unsigned), s));
   const unsigned gn = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(race_keys_kernel, dim3(gn), dim3(256), 0, s, weights, n, (uint64_t)seed, keys, st);
@@ -129,7 +157,9 @@ int multinomial_launch(const float* weights, long n, long k, unsigned long long 
     hipLaunchKernelGGL(race_scan_kernel, dim3(1), dim3(256), 0, s, hist, shifts[p], bits[p], p == 2 ? 1 : 0, st);
     ROMA_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(race_compact_kernel, dim3(gn), dim3(256), 0, s, keys, n, st, out, k);
+  hipLaunchKernelGGL(race_compact_kernel, dim3(gn), dim3(256), 0, s, keys, n, st, sel, k);
+  ROMA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(race_order_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, s, keys, sel, k, out);
   ROMA_LAUNCH_CHECK();
   return 0;
 }

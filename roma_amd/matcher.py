@@ -104,11 +104,6 @@ class RegressionMatcher:
         # batches of >= 2 pairs run as two half-batches on two HIP streams (+5 % at batch 8; bit-identical to the
         # single-stream schedule: tests/test_gpu_match.py::test_stream_split_*).  False = one stream, half the workspace
         self.dual_stream = True
-        # opt-in: replay the kernel schedule of each (batch, options) configuration as a captured hipGraph from its
-        # third call on (one launch instead of ~1 600: matters for tiny problems, where match() is host-bound).  On
-        # ROCm 7.2 run the process with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (set before libamdhip64 / torch is loaded):
-        # the runtime's pre-built graph packets fault on a later replay (profiles/r02_graph_replay_fault.md)
-        self.graph = False
         self.trace = False  # tests / tools only: per-stage output checksums (debug_trace)
         self._weights = weights
         self._dinov2_weights = dinov2_weights
@@ -237,7 +232,7 @@ class RegressionMatcher:
                              "use one matcher (one handle) per GPU")
         self._ensure_handle(call_hw)
         lib = _lib.load()
-        for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug", "vit_bf16_residual", "dual_stream", "graph", "trace"):
+        for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug", "vit_bf16_residual", "dual_stream", "trace"):
             _lib.check(lib.roma_set_option(self._handle, k.encode(), int(bool(getattr(self, k)))))
         _lib.check(lib.roma_set_option_f(self._handle, b"coarse_scale_factor", float(scale_factor)))
         B = a.shape[0]

@@ -14,7 +14,7 @@ from . import _lib
 
 
 def multinomial(weights: torch.Tensor, num_samples: int, generator=None) -> torch.Tensor:
-    """Indices [num_samples] (int64, distinct, arbitrary order) drawn without replacement with probability proportional to
+    """Indices [num_samples] (int64, distinct, in draw order like torch.multinomial) drawn without replacement with probability proportional to
     `weights` [n] (>= 0).  Like torch on a GPU, the number of positive weights is not checked (no host synchronisation):
     if fewer than num_samples are positive, zero-weight entries complete the sample."""
     if not weights.is_cuda:
@@ -29,7 +29,7 @@ def multinomial(weights: torch.Tensor, num_samples: int, generator=None) -> torc
     seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())  # CPU generator: no device synchronisation
     dev = w.device
     out = torch.empty((k,), device=dev, dtype=torch.int64)
-    nws = int(lib.roma_op_multinomial_workspace(n))
+    nws = int(lib.roma_op_multinomial_workspace(n, k))
     ws = torch.empty((nws,), device=dev, dtype=torch.uint8)
     with torch.cuda.device(dev):
         _lib.check(lib.roma_op_multinomial(C.c_void_p(w.data_ptr()), n, k, C.c_ulonglong(seed), C.c_void_p(out.data_ptr()),

@@ -1,12 +1,7 @@
 import os
 import sys
 
-# hipGraph replay (option `graph`): ROCm 7.2's pre-built AQL packets for graph kernel nodes end in a GPU memory access
-# fault on the second replay of match() under some launch timings (profiles/r02_graph_replay_fault.md); the runtime's
-# normal enqueue path is clean.  Must be in the environment before libamdhip64 is loaded, i.e. before `import torch`.
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-
-import pytest  # noqa: E402
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -194,28 +194,6 @@ def test_full_resolution_vs_reference_golden(built_lib, weights0):
     assert np.allclose(c.sum(axis=2, dtype=np.float64), g["cert_rowsum"], atol=0.05)
 
 
-def test_bf16_mode_statistical(built_lib, weights0):
-    """bf16 throughput mode cannot meet 1e-3 max-abs through ~60 layers; it is judged statistically vs the oracle."""
-    from oracle import roma_oracle as O
-    from roma_amd import roma_model, synthetic
-    sd, dsd = weights0
-    inp = synthetic.make_inputs(1, 112, 168, seed=1)
-    d = _to_dev(inp)
-    m = roma_model((112, 112), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=torch.bfloat16,
-                   symmetric=True, upsample_res=(168, 168), max_batch=1)
-    w_ref, c_ref = O.match(inp["im_A"], inp["im_B"], sd, dsd, inp["im_A_high_res"], inp["im_B_high_res"])
-    for res16 in (True, False):  # DINOv2 residual stream in bf16 (default, = the reference's bf16 backbone) / in f32
-        m.vit_bf16_residual = res16
-        warp, cert = m.match(d["im_A"], d["im_B"], im_A_high_res=d["im_A_high_res"], im_B_high_res=d["im_B_high_res"])
-        ew = (warp.cpu() - w_ref).abs()
-        ec = (cert.cpu() - c_ref).abs()
-        print(f"bf16 (vit_bf16_residual={res16}): median|dwarp|={ew.median():.3e} "
-              f"p99={ew.flatten().kthvalue(int(0.99 * ew.numel())).values:.3e} "
-              f"median|dcert|={ec.median():.3e} max={ec.max():.3e}")
-        assert torch.isfinite(warp).all() and torch.isfinite(cert).all()
-        assert ew.median() < 5e-3 and ec.median() < 5e-2
-
-
 @pytest.mark.parametrize("amp", [torch.float32, torch.bfloat16])
 def test_stream_split_matches_single_stream(built_lib, weights0, amp):
     """Batches of >= 2 pairs as sub-batches on two HIP streams (model.h `streams`).  Pairs are independent everywhere in
@@ -297,44 +275,3 @@ def test_non_square_and_pil_inputs(built_lib, weights0, tmp_path):
     assert (w1.cpu() - w_ref).abs().max() < TOL and (c1.cpu() - c_ref).abs().max() < TOL
     with pytest.raises(NotImplementedError):  # utils.py:659-661
         m.match(ims[0].convert("L"), ims[1])
-
-
-@pytest.mark.parametrize("amp", [torch.float32, torch.bfloat16])
-def test_graph_replay_is_bit_identical(built_lib, weights0, amp):
-    """`graph = True`: the first call of a configuration runs eagerly, the second is captured into a hipGraph, later ones
-    replay it.  Same kernels, same arena addresses: every call must reproduce the eager result exactly - also after the
-    batch size or an option changed and came back (one graph per configuration), with fresh input / output tensors each
-    call (the graph works on staging copies) and from a non-default stream."""
-    from roma_amd import roma_model, synthetic
-    sd, dsd = weights0
-    m = roma_model((112, 112), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=amp,
-                   symmetric=True, upsample_res=(168, 168), max_batch=2)
-    inp2 = _to_dev(synthetic.make_inputs(2, 112, 168, seed=21))
-    inp1 = {k: v[:1].clone() for k, v in inp2.items()}
-
-    def run(inp):
-        x = {k: v.clone() for k, v in inp.items()}  # fresh tensors: addresses differ from call to call
-        return m.match(x["im_A"], x["im_B"], im_A_high_res=x["im_A_high_res"], im_B_high_res=x["im_B_high_res"])
-
-    ref2, ref1 = run(inp2), run(inp1)
-    m.symmetric = False
-    refn = run(inp2)
-    m.symmetric = True
-    m.graph = True
-    s = torch.cuda.Stream()
-    for it in range(4):          # eager, capture, replay, replay (from another stream)
-        for inp, ref in ((inp2, ref2), (inp1, ref1)):
-            if it == 3:
-                with torch.cuda.stream(s):
-                    w, c = run(inp)
-                s.synchronize()
-            else:
-                w, c = run(inp)
-            assert torch.equal(w, ref[0]) and torch.equal(c, ref[1]), (it, inp["im_A"].shape[0])
-        m.symmetric = False
-        w, c = run(inp2)
-        m.symmetric = True
-        assert torch.equal(w, refn[0]) and torch.equal(c, refn[1]), it
-    m.graph = False
-    w, c = run(inp2)
-    assert torch.equal(w, ref2[0]) and torch.equal(c, ref2[1])

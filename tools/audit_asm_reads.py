@@ -1,4 +1,4 @@
-"""ISA audit of every hand-scheduled K loop in libroma_hip (gemm.hip, gemm8p.hip, gemm6p.hip, gemm4w.hip, conv64.hip): no instruction may touch a register
+"""ISA audit of every hand-scheduled K loop in libroma_hip (gemm.hip, gemm8p.hip, gemm6p.hip, conv64.hip): no instruction may touch a register
 that has an inline-asm LDS read in flight.
 
 Background (the round-1 "f32 carried k-group produced wrong sums" defect, root-caused in round 2): the 8-wave GEMM
@@ -16,7 +16,7 @@ Works on an llvm-objdump listing of the gfx950 code object, so it needs no speci
 from the second-to-last s_barrier before the first MFMA to the last MFMA is scanned; every ds_read is in flight until the
 `s_waitcnt lgkmcnt(N)` that retires it (LDS returns in order; N = reads still allowed in flight).
 
-    python tools/audit_asm_reads.py            # audits roma_amd/csrc/build/{gemm,gemm8p,gemm6p,gemm4w,conv64}.o
+    python tools/audit_asm_reads.py            # audits roma_amd/csrc/build/{gemm,gemm8p,gemm6p,conv64}.o
 """
 import os
 import re
@@ -114,7 +114,7 @@ def audit_listing(text):
 
 
 def main(objs=None):
-    objs = objs or [os.path.join(ROOT, "roma_amd", "csrc", "build", f) for f in ("gemm.o", "gemm8p.o", "gemm6p.o", "gemm4w.o", "conv64.o")]
+    objs = objs or [os.path.join(ROOT, "roma_amd", "csrc", "build", f) for f in ("gemm.o", "gemm8p.o", "gemm6p.o", "conv64.o")]
     bad = 0
     for obj in objs:
         rep = audit_listing(disassemble(obj))

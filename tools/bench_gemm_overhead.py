@@ -54,10 +54,10 @@ def shape(M, N, K, act=0):
         rc = lib.roma_op_gemm(P(A), K, P(W), K, P(out), N, M, N, K, 1, 0, 0, 0, P(b), None, None, 0, act, 1.0, BF16, BF16, None)
         assert rc == 0, lib.roma_last_error()
     res = {"shape": [M, N, K], "act": act, "tiles_256": ((M + 255) // 256) * ((N + 255) // 256)}
-    for kern, mode in (("classic", 0), ("gemm8p", 1), ("gemm4w", 2)):  # gemm4w: experimental four-wave kernel (plain bf16 only)
+    for kern, mode in (("classic", 0), ("gemm8p", 1)):
         lib.roma_tuning(b"gemm8p", mode)
         r = {}
-        for bits in ((0, 1, 256) if mode == 2 else (0, 1, 2, 3) + ((128, 256, 258, 512, 2048) if mode else ())):
+        for bits in (0, 1, 2, 3) + ((128, 256, 258, 512, 2048) if mode else ()):
             lib.roma_tuning(b"gemm_dbg", bits)
             r[f"dbg{bits}_us"] = round(timed(call), 1)
         lib.roma_tuning(b"gemm_dbg", 0)
