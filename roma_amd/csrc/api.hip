@@ -180,6 +180,8 @@ int roma_tuning(const char* key, int value) {
   else if (k == "gemm_dbg") g_gemm_tuning[1] = value;
   else if (k == "lc_mode") g_lc_mode = value;
   else if (k == "conv64") g_conv64_mode = value;
+  else if (k == "attn_xcd") g_attn_xcd_map = value;
+  else if (k == "refiner_group_mb") g_refiner_group_mb = value;
   else {
     set_error("roma_tuning: unknown key " + k);
     return ROMA_ERR_ARG;

@@ -15,6 +15,8 @@ struct AttnArgs {
   long ldo = 0;
   int in_dt = 0, out_dt = 0;  // DT_F32 / DT_BF16
   int exp2_domain = 0;        // bf16 kernel: q was pre-scaled by log2(e)/sqrt(hd), softmax uses v_exp_f32 (2^x) directly
+  int xcd_map = 1;            // set by attention_launch (g_attn_xcd_map): workgroup -> work item order, see attention.hip
 };
+extern int g_attn_xcd_map;
 int attention_launch(const AttnArgs& a, hipStream_t stream);
 }  // namespace roma

@@ -9,12 +9,36 @@
 // order inside a k-step is a free permutation as long as V^T is read with the same one),
 // so P never leaves registers and the running max / rescale factor is one scalar per lane.
 #include "attention.h"
+
+#include <stdlib.h>
 #include <stdio.h>
 #include "gemm.h"  // DT_*
 
 namespace roma {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+// Work item of a workgroup = (query tile qt, head, image b).  Workgroup g runs on XCD g % 8 and every XCD has its own L2,
+// so with the plain (qt fastest) order the 13 query tiles of one (b, head) land on 8 different XCDs and EVERY XCD streams
+// EVERY head's K / V^T from the fabric (FETCH_SIZE 4.6 x the algorithmic bytes, profiles/r02_pmc_summary.json).  With
+// xcd_map the work list is cut into 8 contiguous bands, one per XCD: all query tiles of a (b, head) - and its K / V^T -
+// stay on one XCD's L2.
+__device__ __forceinline__ bool attn_decode_block(const AttnArgs& a, int& qt, int& head, int& b) {
+  const int nq = (a.N + 127) / 128;
+  const long n = (long)nq * a.heads * a.B;
+  long w = blockIdx.x;
+  if (a.xcd_map) {
+    const long per = (n + 7) / 8;
+    const long slot = blockIdx.x / 8;
+    w = (long)(blockIdx.x % 8) * per + slot;
+    if (slot >= per || w >= n) return false;
+  }
+  qt = (int)(w % nq);
+  const long bh = w / nq;
+  head = (int)(bh % a.heads);
+  b = (int)(bh / a.heads);
+  return true;
+}
 
 template <int HD, typename TOUT>
 __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a) {
@@ -25,9 +49,10 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Vs[HD * VS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  int qt, head, b;
+  if (!attn_decode_block(a, qt, head, b)) return;
   const long bh = (long)b * a.heads + head;
-  const int qi = blockIdx.x * 128 + wave * 32 + l31;
+  const int qi = qt * 128 + wave * 32 + l31;
   const float* Q = reinterpret_cast<const float*>(a.q) + (bh * a.npad) * HD;
   const float* K = reinterpret_cast<const float*>(a.k) + (bh * a.npad) * HD;
   const float* Vt = reinterpret_cast<const float*>(a.vt) + (bh * HD) * a.npad;
@@ -141,9 +166,10 @@ __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_bf16_kernel(const 
   __shared__ __attribute__((aligned(16))) bf16_t Vs[HD * VS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
+  int qt, head, b;
+  if (!attn_decode_block(a, qt, head, b)) return;
   const long bh = (long)b * a.heads + head;
-  const int qi = blockIdx.x * 128 + wave * 32 + l31;
+  const int qi = qt * 128 + wave * 32 + l31;
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (bh * a.npad) * HD;
   const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (bh * a.npad) * HD;
   const bf16_t* Vt = reinterpret_cast<const bf16_t*>(a.vt) + (bh * HD) * a.npad;
@@ -280,11 +306,18 @@ __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_bf16_kernel(const 
 
 #undef ROMA_ATTN_FETCH
 
-int attention_launch(const AttnArgs& a, hipStream_t stream) {
+int g_attn_xcd_map = -1;  // roma_tuning("attn_xcd", v): 1 = per-XCD bands of (b, head) (default), 0 = plain order, -1 = env ROMA_ATTN_XCD
+
+int attention_launch(const AttnArgs& a_in, hipStream_t stream) {
+  AttnArgs a = a_in;
   ROMA_REQUIRE(a.hd == 64 || a.hd == 128, "attention: head dim must be 64 or 128");
   ROMA_REQUIRE(a.npad % 128 == 0 && a.npad >= a.N, "attention: Npad must be a multiple of 128 and >= N");
   ROMA_REQUIRE(a.ldo % 4 == 0, "attention: ldo must be a multiple of 4");
-  dim3 grid((unsigned)((a.N + 127) / 128), (unsigned)a.heads, (unsigned)a.B);
+  const long nwork = (long)((a.N + 127) / 128) * a.heads * a.B;
+  static const int map_env = getenv("ROMA_ATTN_XCD") ? atoi(getenv("ROMA_ATTN_XCD")) : 1;
+  a.xcd_map = g_attn_xcd_map >= 0 ? g_attn_xcd_map : map_env;
+  ROMA_REQUIRE(nwork > 0 && nwork < (1l << 30), "attention: bad problem size");
+  dim3 grid((unsigned)(a.xcd_map ? 8 * ((nwork + 7) / 8) : nwork));
   char pname[64];
   snprintf(pname, sizeof pname, "attn_%s_kernel<%d>", a.in_dt == DT_F32 ? "f32" : "bf16", a.hd);
   ProfScope ps(pname, 4.0 * (double)a.B * a.heads * (double)a.N * a.N * a.hd, "flop", stream);
