@@ -35,7 +35,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 PMC_SUMMARIES = ("profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json")
 
@@ -99,7 +99,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (default 8; 1 for --config coarse)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="bf16 = the metric's dtype (the reference's timing script); f16 = the reference's default amp_dtype "
+                         "(IEEE binary16 storage, libroma_hip_f16.so); f32 = the exact parity mode")
     ap.add_argument("--config", default="full", choices=["full", "coarse"],
                     help="full = 560 -> 864 upsample path (the metric); coarse = coarse-only 560 (BASELINE config 2)")
     ap.add_argument("--coarse", type=int, default=560)
@@ -147,7 +149,7 @@ def main():
     else:
         from roma_amd import _lib, roma_outdoor
         sd, dsd = synthetic.make_matcher_state_dict(0), synthetic.make_dinov2_state_dict(0)
-        amp = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        amp = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
         model = roma_outdoor(device=dev, weights=sd, dinov2_weights=dsd, coarse_res=args.coarse, upsample_res=args.upsample,
                              amp_dtype=amp, symmetric=True, upsample_preds=full, max_batch=args.batch)
         model.dual_stream = args.streams == 2
@@ -256,7 +258,7 @@ def main():
         # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream (separate instrumented pass)
         # every kernel is timed owning the chip on the full-batch launch: with --streams 2 the split is switched off for
         # this pass only
-        lib = _lib.load()
+        lib = model._lib  # the library of this dtype (bf16 / f16 storage builds)
         model.dual_stream = False
         lib.roma_profile_enable(1)
         nprof = max(1, min(3, args.steps))
@@ -274,7 +276,8 @@ def main():
         name, v = dom
         if v["unit"] == "flop":
             ach = v["work"] / (v["total_ms"] * 1e-3) / 1e12
-            peak = PEAK_TFLOPS["bf16" if "bf16" in name.split(",")[0] else "f32"]
+            head = name.split(",")[0]  # "gemm6p_kernel<bf16", "attn_f32_kernel<64>", ...: the INPUT type names the MFMA rate
+            peak = PEAK_TFLOPS["bf16" if ("bf16" in head or "f16" in head) else "f32"]  # one 16-bit rate for bf16 / f16
             roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}
         else:
             ach = v["work"] / (v["total_ms"] * 1e-3) / 1e9
@@ -323,7 +326,7 @@ def main():
                    "coarse_argmax": PM.coarse_flips(own, PM.nchw_to_tokens(g["gm_flow16"]),
                                                     PM.nchw_to_tokens(g["cls16_top2gap"][:, None])),
                    "outputs": PM.output_errors(w, c, g["warp_sub"], g["cert_sub"], tol=tol)}
-            if args.dtype == "bf16":  # continuous part of the pipeline: the reference's coarse match injected
+            if args.dtype != "f32":  # continuous part of the pipeline: the reference's coarse match injected
                 w, c, _ = run(True)
                 par["outputs_with_reference_coarse_match_injected"] = PM.output_errors(w, c, g["warp_sub"], g["cert_sub"], tol=tol)
             result["parity"] = par

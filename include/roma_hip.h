@@ -24,7 +24,12 @@ extern "C" {
 
 typedef struct roma_model* roma_handle_t;
 
-enum { ROMA_F32 = 0, ROMA_BF16 = 1 };            /* arithmetic / storage type of activations */
+/* arithmetic / storage type of activations.  The 16-bit format is a property of the library BUILD: libroma_hip.so stores
+ * bfloat16 and accepts ROMA_F32 / ROMA_BF16; libroma_hip_f16.so (same sources, -DROMA_H16_F16) stores IEEE binary16 - the
+ * reference's default amp_dtype (model_zoo/__init__.py:37) - and accepts ROMA_F32 / ROMA_F16.  The other code is an error
+ * (ROMA_ERR_ARG), never a reinterpretation.  roma_h16_format() returns the code of the loaded library. */
+enum { ROMA_F32 = 0, ROMA_BF16 = 1, ROMA_F16 = 2 };
+int roma_h16_format(void);
 enum { ROMA_ERR_ARG = -1, ROMA_ERR_HIP = -2, ROMA_ERR_STATE = -3 };
 
 typedef struct {
@@ -33,7 +38,7 @@ typedef struct {
   int symmetric;              /* matcher.py:801   */
   int upsample_preds;         /* matcher.py:836   */
   int attenuate_cert;         /* matcher.py:839   */
-  int precision;              /* ROMA_F32 (exact f32 MFMA; CPU-oracle parity) or ROMA_BF16          */
+  int precision;              /* ROMA_F32 (exact f32 MFMA; CPU-oracle parity) or the library's 16-bit code */
   int max_batch;              /* largest number of image pairs per roma_match call                 */
   int device;                 /* HIP device ordinal                                                */
 } roma_config_t;
@@ -89,12 +94,14 @@ int roma_tuning(const char* key, int value);
 int roma_profile_enable(int on);
 long roma_profile_report(char* buf, long nbytes);
 
-/* ---- operator entry points (dt: ROMA_F32 / ROMA_BF16) ------------------------------------------------ */
+/* ---- operator entry points (dt: ROMA_F32 or the library's 16-bit code, ROMA_BF16 / ROMA_F16) ------------ */
 
-/* Drop-in for local_corr.local_corr(feature0[B,HW,C], feature1[B,H,W,C], warp[B,HW,K,2], "bilinear",
- * normalized_coords=True) -> out[B,HW,K]   (local_correlation.py:26-32).  feature0 is expected pre-scaled. */
+/* Drop-in for local_corr.local_corr(feature0[B,HW,C], feature1[B,H,W,C], warp[B,HW,K,2], mode, normalized_coords=True)
+ * -> out[B,HW,K]   (local_correlation.py:26-32).  feature0 is expected pre-scaled.  nearest = 0: mode "bilinear"; 1: mode
+ * "nearest" (the sample_mode the reference threads through local_correlation.py:19,30,85: the pixel at nearbyint of the
+ * un-normalised coordinate, zero outside the image - F.grid_sample(mode="nearest", align_corners=False)). */
 int roma_op_local_corr(const void* feature0, const void* feature1, const float* warp, void* out, int B, int H, int W,
-                       int C, int K, int dt_in, int dt_out, void* stream);
+                       int C, int K, int nearest, int dt_in, int dt_out, void* stream);
 /* Window form: warp is the centre coordinate [B,HW,2]; taps = (2r+1)^2 one-pixel steps; scale multiplies the
  * result (1/sqrt(C) when feature0 is not pre-scaled); out row stride ldo >= K. */
 int roma_op_local_corr_window(const void* feature0, const void* feature1, const float* warp, void* out, int B, int H,
@@ -161,11 +168,20 @@ int roma_op_kde(const float* x, long n, int down, float std, int half_inputs, fl
  *   align_corners=False); warp [H,W,4] f32, cert [H,W] f32, xa [n,2] normalised (x,y).
  * mutual_nn: match_b[i] = j if b[j] is the nearest neighbour of a[i], a[i] is at the column-minimum distance of
  *   b[j], cert_a[i] > cert_th (cert_a may be NULL) and |a[i]-b[j]| < max_dist; else -1.  Row ties resolve to the
- *   lowest j (the reference returns every tied pair).  ws_a / ws_b: 8*na / 8*nb byte workspaces. */
+ *   lowest j.  ws_a / ws_b: 8*na / 8*nb byte workspaces.
+ * mutual_nn_count / mutual_nn_fill: the tie-complete form, i.e. torch.nonzero of the reference's mask
+ *   (D == row min) * (D == column min) * (cert > th) * (D < max_dist) (matcher.py:756-762) with EVERY tied pair (duplicate
+ *   keypoints), row-major.  count runs the two nearest-neighbour passes and writes offsets[0..na] (int64): the exclusive
+ *   prefix sums of the per-row match counts, offsets[na] = number of pairs; the caller reads that one value, allocates
+ *   pairs[n][2] (int64: index into a, index into b) and calls fill with the same arguments and workspaces. */
 int roma_op_sample_warp_at(const float* warp, const float* cert, int H, int W, const float* xa, long n, float* xa_to_b,
                            float* cert_a, void* stream);
 int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
                       int* match_b, void* ws_a, void* ws_b, void* stream);
+int roma_op_mutual_nn_count(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
+                            void* ws_a, void* ws_b, long long* offsets, void* stream);
+int roma_op_mutual_nn_fill(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
+                           const void* ws_a, const void* ws_b, long long* offsets, long long* pairs, void* stream);
 /* torch.multinomial(weights, k, replacement=False) of RegressionMatcher.sample (matcher.py:615-627): k distinct int64
  * indices, drawn with probability proportional to the non-negative f32 weights [n] (exponential race + radix select, no
  * sort; reproducible from `seed`), returned in DRAW order (ascending race key) like torch.multinomial, so a prefix of the

@@ -200,9 +200,10 @@ def cls_to_flow_refine(cls):
     return flow / nb.sum(dim=1)
 
 
-def local_correlation(f0, f1, r, warp):
+def local_correlation(f0, f1, r, warp, sample_mode="bilinear"):
     """romatch/utils/local_correlation.py:77-143 with the torch fallback :39-74
-    (the semantics the external fused kernel must reproduce).  warp: [B,2,H,W]."""
+    (the semantics the external fused kernel must reproduce).  warp: [B,2,H,W]; sample_mode "bilinear" | "nearest"
+    (:19,30,85 - the matcher only ever passes "bilinear", matcher.py:43)."""
     K = (2 * r + 1) ** 2
     B, c, h, w = f0.shape
     warp = warp.permute(0, 2, 3, 1)
@@ -212,7 +213,7 @@ def local_correlation(f0, f1, r, warp):
     corr = torch.empty((B, K, h, w), dtype=f0.dtype)
     for i in range(B):
         coords = (warp[i, :, :, None] + lw[:, None, None]).reshape(1, h, w * K, 2)
-        wf = F.grid_sample(f1[i:i + 1], coords, padding_mode="zeros", align_corners=False, mode="bilinear")
+        wf = F.grid_sample(f1[i:i + 1], coords, padding_mode="zeros", align_corners=False, mode=sample_mode)
         wf = wf.reshape(c, h, w, K)
         corr[i] = (f0[i, ..., None] / (c ** 0.5) * wf).sum(dim=0).permute(2, 0, 1)
     return corr

@@ -1,4 +1,8 @@
-"""ctypes binding of libroma_hip.so (C ABI declared in include/roma_hip.h).
+"""ctypes binding of libroma_hip.so / libroma_hip_f16.so (C ABI declared in include/roma_hip.h).
+
+The 16-bit storage format is a build-time property of the library (csrc/common.h): `load("bf16")` (the default) binds
+libroma_hip.so, `load("f16")` binds libroma_hip_f16.so - the same sources compiled for IEEE binary16, the reference's
+default amp_dtype.  Both export the same symbols; f32-only operators live in either.
 
 There is deliberately NO fallback: if the HIP library is missing or does not export a symbol
 the import fails loudly (the product path never routes through the CPU oracle).
@@ -10,8 +14,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libroma_hip.so")
+LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(_HERE, "libroma_hip_f16.so")}
 
-ROMA_F32, ROMA_BF16 = 0, 1
+ROMA_F32, ROMA_BF16, ROMA_F16 = 0, 1, 2
+H16_CODE = {"bf16": ROMA_BF16, "f16": ROMA_F16}
 
 
 class RomaConfig(C.Structure):
@@ -26,6 +32,7 @@ _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "roma_last_error": (C.c_char_p, []),
     "roma_version": (C.c_char_p, []),
+    "roma_h16_format": (_i, []),
     "roma_create": (_i, [C.POINTER(RomaConfig), C.POINTER(_vp)]),
     "roma_set_tensor": (_i, [_vp, C.c_char_p, _i, C.POINTER(C.c_int64), _vp, _i]),
     "roma_finalize": (_i, [_vp]),
@@ -39,7 +46,7 @@ SIGNATURES = {
     "roma_tuning": (_i, [C.c_char_p, _i]),
     "roma_profile_enable": (_i, [_i]),
     "roma_profile_report": (_l, [C.c_char_p, _l]),
-    "roma_op_local_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "roma_op_local_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "roma_op_local_corr_window": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _i, _i, _vp]),
     "roma_op_gemm": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _l, _l, _l, _vp, _vp, _vp, _l, _i, _f, _i, _i, _vp]),
     "roma_op_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -58,6 +65,8 @@ SIGNATURES = {
     "roma_op_kde": (_i, [_vp, _l, _i, _f, _i, _vp, _vp]),
     "roma_op_sample_warp_at": (_i, [_vp, _vp, _i, _i, _vp, _l, _vp, _vp, _vp]),
     "roma_op_mutual_nn": (_i, [_vp, _l, _vp, _l, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "roma_op_mutual_nn_count": (_i, [_vp, _l, _vp, _l, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "roma_op_mutual_nn_fill": (_i, [_vp, _l, _vp, _l, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "roma_op_fb_consistency": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "roma_op_visualize_warp": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "roma_op_multinomial_workspace": (_l, [_l, _l]),
@@ -73,35 +82,43 @@ SIGNATURES = {
     "roma_op_refiner_out": (_i, [_vp, _l, _i, _vp, _vp, _vp, _vp, _l, _i, _f, _f, _vp]),
 }
 
-_lib = None
+_libs = {}
 
 
 class RomaHipError(RuntimeError):
     pass
 
 
-def load():
-    """dlopen the library and bind every declared symbol (raises if anything is missing)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+def load(fmt: str = "bf16"):
+    """dlopen the library that stores `fmt` ("bf16" | "f16") and bind every declared symbol (raises if anything is missing)."""
+    if fmt in _libs:
+        return _libs[fmt]
+    path = LIB_PATHS[fmt]
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(roma_amd has no CPU fallback)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    if lib.roma_h16_format() != H16_CODE[fmt]:
+        raise ImportError(f"{path} does not store {fmt} (roma_h16_format() = {lib.roma_h16_format()})")
+    lib.h16 = fmt
+    _libs[fmt] = lib
     return lib
 
 
-def last_error() -> str:
-    return load().roma_last_error().decode("utf-8", "replace")
+def fmt_of(dtype) -> str:
+    """library format for a torch dtype: float16 -> "f16", everything else (bfloat16, float32) -> "bf16"."""
+    return "f16" if str(dtype) == "torch.float16" else "bf16"
 
 
-def check(rc: int, exc=RomaHipError):
+def last_error(lib=None) -> str:
+    return (lib or load()).roma_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, exc=RomaHipError, lib=None):
     if rc != 0:
-        raise exc(last_error())
+        raise exc(last_error(lib))
     return rc

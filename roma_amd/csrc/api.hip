@@ -46,12 +46,34 @@ struct roma_model {
 using namespace roma;
 
 static inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
-static inline int DT(int dt) { return dt == ROMA_BF16 ? DT_BF16 : DT_F32; }
+// public dtype code -> internal one.  The 16-bit storage format is a property of the BUILD (common.h): this library accepts
+// ROMA_F32 and its own 16-bit code only; the other one fails loudly instead of reinterpreting the bits.
+#ifdef ROMA_H16_F16
+static constexpr int ROMA_H16_CODE = ROMA_F16, ROMA_OTHER16_CODE = ROMA_BF16;
+#else
+static constexpr int ROMA_H16_CODE = ROMA_BF16, ROMA_OTHER16_CODE = ROMA_F16;
+#endif
+static inline int dt_code(int dt) {
+  if (dt == ROMA_F32) return DT_F32;
+  if (dt == ROMA_H16_CODE) return DT_BF16;
+  set_error(dt == ROMA_OTHER16_CODE
+                ? std::string("this library stores ") + ROMA_H16_NAME + ": load " +
+                      (ROMA_H16_CODE == ROMA_BF16 ? "libroma_hip_f16.so for ROMA_F16" : "libroma_hip.so for ROMA_BF16")
+                : std::string("bad dtype code"));
+  return -1;
+}
+#define DT(dt)                           \
+  ({                                     \
+    const int _d = dt_code(dt);          \
+    if (_d < 0) return ROMA_ERR_ARG;     \
+    _d;                                  \
+  })
 
 extern "C" {
 
 const char* roma_last_error(void) { return g_err.c_str(); }
-const char* roma_version(void) { return "roma_hip 0.1 (gfx950)"; }
+const char* roma_version(void) { return "roma_hip 0.3 (gfx950, 16-bit storage = " ROMA_H16_NAME ")"; }
+int roma_h16_format(void) { return ROMA_H16_CODE; }
 
 int roma_create(const roma_config_t* cfg, roma_handle_t* out) {
   ROMA_REQUIRE(cfg && out, "roma_create: null argument");
@@ -61,7 +83,7 @@ int roma_create(const roma_config_t* cfg, roma_handle_t* out) {
   ROMA_REQUIRE(cfg->upsample_h % 8 == 0 && cfg->upsample_w % 8 == 0 && cfg->upsample_h >= 0,
                "roma_create: upsample resolution must be a multiple of 8");
   ROMA_REQUIRE(cfg->max_batch >= 1, "roma_create: max_batch must be >= 1");
-  ROMA_REQUIRE(cfg->precision == ROMA_F32 || cfg->precision == ROMA_BF16, "roma_create: bad precision");
+  if (dt_code(cfg->precision) < 0) return ROMA_ERR_ARG;  // ROMA_F32 or this build's 16-bit format
   int ndev = 0;
   ROMA_CHECK_HIP(hipGetDeviceCount(&ndev));
   ROMA_REQUIRE(cfg->device >= 0 && cfg->device < ndev, "roma_create: no such HIP device (the HIP path has no CPU fallback)");
@@ -181,7 +203,6 @@ int roma_tuning(const char* key, int value) {
   else if (k == "lc_mode") g_lc_mode = value;
   else if (k == "conv64") g_conv64_mode = value;
   else if (k == "attn_xcd") g_attn_xcd_map = value;
-  else if (k == "refiner_group_mb") g_refiner_group_mb = value;
   else {
     set_error("roma_tuning: unknown key " + k);
     return ROMA_ERR_ARG;
@@ -224,8 +245,9 @@ long roma_profile_report(char* buf, long nbytes) {
 
 // ------------------------------------------------------------------------------------ operators
 int roma_op_local_corr(const void* feature0, const void* feature1, const float* warp, void* out, int B, int H, int W,
-                       int C, int K, int dt_in, int dt_out, void* stream) {
+                       int C, int K, int nearest, int dt_in, int dt_out, void* stream) {
   LocalCorrArgs a;
+  a.nearest = nearest ? 1 : 0;
   a.f0 = feature0; a.f1 = feature1; a.warp = warp; a.out = out; a.B = B; a.H = H; a.W = W; a.C = C; a.K = K;
   a.ld0 = C; a.ld1 = C; a.ldo = K; a.nimg = B; a.f1_shift = 0; a.scale = 1.f; a.in_dt = DT(dt_in); a.out_dt = DT(dt_out);
   return local_corr_general_launch(a, S(stream));
@@ -369,6 +391,17 @@ int roma_op_mutual_nn(const float* a, long na, const float* b, long nb, const fl
                       int* match_b, void* ws_a, void* ws_b, void* stream) {
   return mutual_nn_launch(a, na, b, nb, cert_a, cert_th, max_dist, match_b, static_cast<unsigned long long*>(ws_a),
                           static_cast<unsigned long long*>(ws_b), S(stream));
+}
+
+int roma_op_mutual_nn_count(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
+                            void* ws_a, void* ws_b, long long* offsets, void* stream) {
+  return mutual_nn_count_launch(a, na, b, nb, cert_a, cert_th, max_dist, static_cast<unsigned long long*>(ws_a),
+                                static_cast<unsigned long long*>(ws_b), offsets, S(stream));
+}
+int roma_op_mutual_nn_fill(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
+                           const void* ws_a, const void* ws_b, long long* offsets, long long* pairs, void* stream) {
+  return mutual_nn_fill_launch(a, na, b, nb, cert_a, cert_th, max_dist, static_cast<const unsigned long long*>(ws_a),
+                               static_cast<const unsigned long long*>(ws_b), offsets, pairs, S(stream));
 }
 
 long roma_op_multinomial_workspace(long n, long k) { return (long)multinomial_workspace_bytes(n, k); }

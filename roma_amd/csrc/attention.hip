@@ -231,8 +231,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_bf16_kernel(const 
 #pragma unroll
       for (int st = 0; st < NS; ++st) {
         const uint4 kf = *reinterpret_cast<const uint4*>(&Ks[(32 * kt + l31) * KS + 16 * st + 8 * h]);
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf),
-                                                        __builtin_bit_cast(bf16x8_t, qf[st]), s[kt], 0, 0, 0);
+        s[kt] = mfma_h16_32x32x16(kf,
+                                                        qf[st], s[kt]);
       }
     }
     if (kv0 + KV > a.N) {  // only the last tile has keys >= N to mask (uniform branch)
@@ -282,8 +282,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_bf16_kernel(const 
           const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
           const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 8);
           const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
-                                                         __builtin_bit_cast(bf16x8_t, pk), o[d], 0, 0, 0);
+          o[d] = mfma_h16_32x32x16(vf,
+                                                         pk, o[d]);
         }
       }
     __syncthreads();
@@ -319,7 +319,7 @@ int attention_launch(const AttnArgs& a_in, hipStream_t stream) {
   ROMA_REQUIRE(nwork > 0 && nwork < (1l << 30), "attention: bad problem size");
   dim3 grid((unsigned)(a.xcd_map ? 8 * ((nwork + 7) / 8) : nwork));
   char pname[64];
-  snprintf(pname, sizeof pname, "attn_%s_kernel<%d>", a.in_dt == DT_F32 ? "f32" : "bf16", a.hd);
+  snprintf(pname, sizeof pname, "attn_%s_kernel<%d>", a.in_dt == DT_F32 ? "f32" : ROMA_H16_NAME, a.hd);
   ProfScope ps(pname, 4.0 * (double)a.B * a.heads * (double)a.N * a.N * a.hd, "flop", stream);
 #define ROMA_ATTN(KERNEL, HDV, TOUT) hipLaunchKernelGGL((KERNEL<HDV, TOUT>), grid, dim3(256), 0, stream, a)
 #define ROMA_ATTNB(HDV, TOUT)                                                                         \

@@ -6,7 +6,26 @@
 
 namespace roma {
 
-typedef unsigned short bf16_t;  // raw bfloat16 bits
+// The library's 16-bit storage type ("h16"), as raw bits.  It is a BUILD-TIME property: libroma_hip.so stores bfloat16
+// (torch.bfloat16: the reference's timing script, tests/test_roma_upsample_inference_time.py:45), libroma_hip_f16.so -
+// the same sources compiled with -DROMA_H16_F16 - stores IEEE binary16 (torch.float16: the reference's DEFAULT amp_dtype,
+// model_zoo/__init__.py:37, matcher.py:46,341, encoders.py:7).  Both run the same v_mfma_f32_32x32x16 rate; binary16 has
+// 11 significand bits against 8 (8 x less storage rounding through the 45 refiner blocks) and overflows at 65504.
+// `bf16_t`, DT_BF16 and "bf16" in kernel / function names are the historical names of this type: they mean "the h16 of
+// this build".  Everything format specific lives in this header: conversions, packing, the MFMA and the dot product.
+typedef unsigned short h16_t;
+typedef h16_t bf16_t;
+#ifdef ROMA_H16_F16
+#define ROMA_H16_NAME "f16"
+typedef _Float16 h16_native;
+#else
+#define ROMA_H16_NAME "bf16"
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __bf16 h16_native;
+#else
+typedef unsigned short h16_native;  // host side: only the bit pattern is ever touched
+#endif
+#endif
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -32,7 +51,27 @@ void set_error(const std::string& msg);
   } while (0)
 #define ROMA_LAUNCH_CHECK() ROMA_CHECK_HIP(hipGetLastError())
 
-// ---- bf16 <-> f32 (round-to-nearest-even), usable on host and device ----
+// ---- h16 <-> f32 (round-to-nearest-even), usable on host and device ----
+#ifdef ROMA_H16_F16
+__host__ __device__ inline float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__host__ __device__ inline bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+// low / high half of a dword holding two h16
+__device__ __forceinline__ float h16_lo(uint32_t u) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 pk_h;
+  return (float)__builtin_bit_cast(pk_h, u)[0];
+}
+__device__ __forceinline__ float h16_hi(uint32_t u) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 pk_h;
+  return (float)__builtin_bit_cast(pk_h, u)[1];
+}
+// two f32 -> packed h16x2, round-to-nearest-even (v_cvt_pk_f16_f32 on gfx950; left to the compiler, see below)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) float pk_f32x2;
+  typedef __attribute__((ext_vector_type(2))) _Float16 pk_h;
+  const pk_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pk_h));
+}
+#else
 __host__ __device__ inline float bf16_to_f32(bf16_t v) {
   union { uint32_t u; float f; } x;
   x.u = ((uint32_t)v) << 16;
@@ -45,6 +84,9 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
   uint32_t r = 0x7fffu + ((x.u >> 16) & 1u);
   return (bf16_t)((x.u + r) >> 16);
 }
+// low / high half of a dword holding two h16 (bf16: one shift / one mask)
+__device__ __forceinline__ float h16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float h16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
 // two f32 -> packed bf16x2 (round-to-nearest-even) in ONE instruction: gfx950's v_cvt_pk_bf16_f32 (no builtin;
 // the software rounding costs ~6 VALU ops per element and made the attention softmax / GEMM epilogues VALU-bound)
@@ -58,6 +100,34 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pk_bf16x2));
 #else
   return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+#endif
+}
+#endif
+
+// D[32x32] += A[32 x 16] . B[16 x 32] on the matrix core, 16-bit operands of this build's format, f32 accumulate:
+// v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x16_f16 (same rate, same register layout: 8 consecutive k per lane).
+// a, b: any 16-byte register type holding 8 h16.
+typedef __attribute__((ext_vector_type(8))) h16_native h16x8_t;
+template <typename TA, typename TB>
+__device__ __forceinline__ f32x16 mfma_h16_32x32x16(TA a, TB b, f32x16 c) {
+  static_assert(sizeof(TA) == 16 && sizeof(TB) == 16, "8 h16 per operand");
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return c;  // host pass of the single-source compile: never executed
+#elif defined(ROMA_H16_F16)
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
+#endif
+}
+// acc + x.lo * y.lo + x.hi * y.hi on packed h16 pairs (v_dot2c_f32_bf16 / v_dot2_f32_f16)
+__device__ __forceinline__ float dot2_h16(uint32_t x, uint32_t y, float acc) {
+  typedef h16_native pk_h16x2 __attribute__((ext_vector_type(2)));
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return acc;
+#elif defined(ROMA_H16_F16)
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(pk_h16x2, x), __builtin_bit_cast(pk_h16x2, y), acc, false);
+#else
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(pk_h16x2, x), __builtin_bit_cast(pk_h16x2, y), acc, false);
 #endif
 }
 
@@ -74,10 +144,10 @@ template <> struct ElemIO<bf16_t> {
   __device__ static inline f32x4 ld4(const bf16_t* p) {
     uint2 u = *reinterpret_cast<const uint2*>(p);
     f32x4 r;
-    r[0] = __uint_as_float(u.x << 16);
-    r[1] = __uint_as_float(u.x & 0xffff0000u);
-    r[2] = __uint_as_float(u.y << 16);
-    r[3] = __uint_as_float(u.y & 0xffff0000u);
+    r[0] = h16_lo(u.x);
+    r[1] = h16_hi(u.x);
+    r[2] = h16_lo(u.y);
+    r[3] = h16_hi(u.y);
     return r;
   }
   __device__ static inline void st4(bf16_t* p, f32x4 v) {

@@ -193,8 +193,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const bf16_t* __res
         }
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[t * 4 + g]),
-                                                            __builtin_bit_cast(bf16x8_t, fa[tm][g]), acc[tm], 0, 0, 0);
+          acc[tm] = mfma_h16_32x32x16(wreg[t * 4 + g],
+                                                            fa[tm][g], acc[tm]);
         // group g of the next tap overwrites fa[.][g] behind the ISSUED MFMAs (operands are read at issue, LDS data comes
         // back >= 64 cycles later); behind the last tap: tap 0 of the next output row, whose ring row is already resident.
         __builtin_amdgcn_sched_barrier(0);
@@ -442,8 +442,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c128_kernel(const bf16_t* __re
         }
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
-          acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wreg[t * 4 + g]),
-                                                            __builtin_bit_cast(bf16x8_t, fa[tm][g]), acc[tm], 0, 0, 0);
+          acc[tm] = mfma_h16_32x32x16(wreg[t * 4 + g],
+                                                            fa[tm][g], acc[tm]);
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < 9) {
           C128_READ_G(((o + (t + 1) / 3) & 3) * RSTRIDE, (t + 1) % 3, g)
@@ -559,8 +559,8 @@ __global__ __launch_bounds__(256, 4) void conv3x3_c3_bf16_kernel(const float* __
       for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[cb][ks]),
-                                                          __builtin_bit_cast(bf16x8_t, fr[ks]), acc[cb], 0, 0, 0);
+        acc[cb] = mfma_h16_32x32x16(wf[cb][ks],
+                                                          fr[ks], acc[cb]);
     }
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)

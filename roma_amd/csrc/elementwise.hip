@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const floa
         const unsigned rp[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          v[i][j >> 1][2 * (j & 1)] = __uint_as_float(rp[j] << 16);
-          v[i][j >> 1][2 * (j & 1) + 1] = __uint_as_float(rp[j] & 0xffff0000u);
+          v[i][j >> 1][2 * (j & 1)] = h16_lo(rp[j]);
+          v[i][j >> 1][2 * (j & 1) + 1] = h16_hi(rp[j]);
         }
       } else {
         v[i][0] = *reinterpret_cast<const f32x4*>(xr + i * 512 + lane * 8);
@@ -660,10 +660,10 @@ template <> struct VecIO<bf16_t> {
   static constexpr int CV = 8;
   __device__ static inline void ld(const bf16_t* p, float* v) {
     const uint4 u = *reinterpret_cast<const uint4*>(p);
-    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
-    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+    v[0] = h16_lo(u.x); v[1] = h16_hi(u.x);
+    v[2] = h16_lo(u.y); v[3] = h16_hi(u.y);
+    v[4] = h16_lo(u.z); v[5] = h16_hi(u.z);
+    v[6] = h16_lo(u.w); v[7] = h16_hi(u.w);
   }
   __device__ static inline void st(bf16_t* p, const float* v) {
     uint4 u;
@@ -849,7 +849,7 @@ int refiner_input_launch(const RefinerInputArgs& a, hipStream_t s) {
   // read once (2 s C), the flow (8), the written row of d without the correlation slice another kernel fills
   const double es = a.dt == DT_F32 ? 4.0 : 2.0;
   char pname[64];
-  snprintf(pname, sizeof pname, "refiner_input_warp<C=%d,%s>", a.C, a.dt == DT_F32 ? "f32" : "bf16");
+  snprintf(pname, sizeof pname, "refiner_input_warp<C=%d,%s>", a.C, a.dt == DT_F32 ? "f32" : ROMA_H16_NAME);
   ProfScope ps(pname, (double)npix * (2.0 * a.C * es + 8.0 + (double)(a.ldd - a.Kcorr) * es), "byte", s);
   if (a.C == 9 && a.E == 6 && a.Kcorr == 0 && a.ldf == 16 && a.ldd == 24) {
     dim3 grid((unsigned)((npix + 255) / 256));
@@ -914,8 +914,8 @@ template <> struct RawVec<bf16_t> {
   __device__ static inline raw zero() { return make_uint2(0, 0); }
   __device__ static inline raw mask(raw r, uint32_t m) { return make_uint2(r.x & m, r.y & m); }
   __device__ static inline void cvt(raw r, f32x2& a, f32x2& b) {
-    a = f32x2{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
-    b = f32x2{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+    a = f32x2{h16_lo(r.x), h16_hi(r.x)};
+    b = f32x2{h16_lo(r.y), h16_hi(r.y)};
   }
   __device__ static inline void st(bf16_t* p, f32x2 a, f32x2 b) {
     uint2 u;
@@ -1078,7 +1078,7 @@ int dwconv5x5_launch(const void* in, void* out, const float* w, const float* bia
   const int nblocks = (int)nb;
   dim3 grid((unsigned)(((nblocks + 7) / 8) * 8));
   const size_t lds = (size_t)26 * 256 * sizeof(float);  // fixed 256-float rows (see kernel)
-  ProfScope ps(dt == DT_F32 ? "dwconv5x5_kernel<f32>" : "dwconv5x5_kernel<bf16>",
+  ProfScope ps(dt == DT_F32 ? "dwconv5x5_kernel<f32>" : "dwconv5x5_kernel<" ROMA_H16_NAME ">",
                2.0 * (double)B * H * W * Cp * (dt == DT_F32 ? 4.0 : 2.0), "byte", s);
   ROMA_DT_SWITCH(dt, T, hipLaunchKernelGGL(dwconv5x5_kernel<T>, grid, dim3(256), lds, s, (const T*)in, (T*)out, w, bias, B, H, W, Cp, SY, GC, nchunk, nxg, nblocks));
   ROMA_LAUNCH_CHECK();

@@ -215,8 +215,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
       acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(WV[tn].z), __uint_as_float(AV[tm].z), acc[tn][tm], 0, 0, 0); \
       acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(WV[tn].w), __uint_as_float(AV[tm].w), acc[tn][tm], 0, 0, 0); \
     } else {                                                                                                \
-      acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, WV[tn]),           \
-                                                            __builtin_bit_cast(bf16x8_t, AV[tm]), acc[tn][tm], 0, 0, 0); \
+      acc[tn][tm] = mfma_h16_32x32x16(WV[tn],           \
+                                                            AV[tm], acc[tn][tm]); \
     }                                                                                                       \
   }
 #define ROMA_WAIT_LGKM(N)                                  \
@@ -515,8 +515,8 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   }
   dim3 grid((unsigned)gx, 1, (unsigned)a.batch);
   char pname[96];
-  snprintf(pname, sizeof pname, "gemm_kernel<%s,%s,%d,%d,%d,%d,%s>", sizeof(TIN) == 4 ? "f32" : "bf16",
-           sizeof(TOUT) == 4 ? "f32" : "bf16", WM, WN, TM, TN, CONV ? "conv3x3" : "dense");
+  snprintf(pname, sizeof pname, "gemm_kernel<%s,%s,%d,%d,%d,%d,%s>", sizeof(TIN) == 4 ? "f32" : ROMA_H16_NAME,
+           sizeof(TOUT) == 4 ? "f32" : ROMA_H16_NAME, WM, WN, TM, TN, CONV ? "conv3x3" : "dense");
   // algorithmic FLOPs: the caller's M (a.M may have been padded to npad tokens per image for the QKV epilogue)
   ProfScope ps(pname, 2.0 * (double)(a.m_alg > 0 ? a.m_alg : a.M) * a.N * a.K * a.batch * (a.lower_only ? 0.5 : 1.0), "flop", stream);
   // the > 64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: one flag per device ordinal

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(512, 2) void gemm6p_kernel(const GemmArgs a) {
   // D[n][m] += W[n][k] A[m][k]: the W fragment is the first operand, so a lane owns 4 consecutive n of one m
 #define R6_MFMA(NT_, BF)                                                                                       \
   _Pragma("unroll") for (int g = 0; g < 4; ++g) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                 \
-      acc[NT_][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, BF[g]),              \
-                                                             __builtin_bit_cast(bf16x8_t, af[mt][g]), acc[NT_][mt], 0, 0, 0);
+      acc[NT_][mt] = mfma_h16_32x32x16(BF[g],              \
+                                                             af[mt][g], acc[NT_][mt]);
 #define R6_PHASE(WAIT, MF)                       \
   __builtin_amdgcn_sched_barrier(0);             \
   __builtin_amdgcn_s_barrier();                  \
@@ -265,7 +265,7 @@ static int launch6p(const GemmArgs& a, hipStream_t stream, const char* epi_name)
   const size_t lds = (size_t)2 * (BM + BN) * ROWB + 8 * 6144;  // 160 KiB: one persistent workgroup per CU
   const long gx = std::min<long>(((nblk + 7) / 8) * 8, 256);
   char pname[96];
-  snprintf(pname, sizeof pname, "gemm6p_kernel<bf16,%s,dense,%s>", sizeof(TOUT) == 4 ? "f32" : "bf16", epi_name);
+  snprintf(pname, sizeof pname, "gemm6p_kernel<" ROMA_H16_NAME ",%s,dense,%s>", sizeof(TOUT) == 4 ? "f32" : ROMA_H16_NAME, epi_name);
   ProfScope ps(pname, 2.0 * (double)a.M * a.N * a.K, "flop", stream);
   static bool attr_set[64] = {false};
   int dev = 0;

@@ -211,14 +211,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
   // D[n][m] += W[n][k] A[m][k]: the W fragment is the first operand, so a lane owns 4 consecutive n of one m
 #define R8_MFMA_Q(MH, NH, BF)                                                                                  \
   _Pragma("unroll") for (int g = 0; g < 4; ++g) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                 \
-      acc[NH][(MH) * 2 + mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, BF[g]),    \
-                                                                       __builtin_bit_cast(bf16x8_t, af[mt][g]), \
-                                                                       acc[NH][(MH) * 2 + mt], 0, 0, 0);
+      acc[NH][(MH) * 2 + mt] = mfma_h16_32x32x16(BF[g],    \
+                                                                       af[mt][g], \
+                                                                       acc[NH][(MH) * 2 + mt]);
 #define R8_MFMA_G(MH, NH, BF, G)                                                                               \
   _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                              \
-      acc[NH][(MH) * 2 + mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, BF[G]),    \
-                                                                       __builtin_bit_cast(bf16x8_t, af[mt][G]), \
-                                                                       acc[NH][(MH) * 2 + mt], 0, 0, 0);
+      acc[NH][(MH) * 2 + mt] = mfma_h16_32x32x16(BF[G],    \
+                                                                       af[mt][G], \
+                                                                       acc[NH][(MH) * 2 + mt]);
   // DMAMF phase (experiment, off by default): the two LDS-DMA pieces of the phase are issued BETWEEN the MFMAs (after the
   // 2nd and the 4th of 8) instead of in the load block.  The idea: an LDS-DMA instruction costs the issuing wave ~100-180
   // cycles in a block that also carries the fragment reads but ~60 among bare MFMAs (MI355X_MICROARCH.md).  Measured: no
@@ -425,7 +425,7 @@ static int launch8p(const GemmArgs& a, hipStream_t stream, const char* epi_name)
   const size_t lds = (size_t)2 * (BM + BN) * ROWB + 8 * 4096;  // 160 KiB: one persistent workgroup per CU
   const long gx = std::min<long>(((nblk + 7) / 8) * 8, 256);
   char pname[96];
-  snprintf(pname, sizeof pname, "gemm8p_kernel<bf16,%s,%s,%s>", sizeof(TOUT) == 4 ? "f32" : "bf16", CONV ? "conv3x3" : "dense", epi_name);
+  snprintf(pname, sizeof pname, "gemm8p_kernel<" ROMA_H16_NAME ",%s,%s,%s>", sizeof(TOUT) == 4 ? "f32" : ROMA_H16_NAME, CONV ? "conv3x3" : "dense", epi_name);
   ProfScope ps(pname, 2.0 * (double)(a.m_alg > 0 ? a.m_alg : a.M) * a.N * a.K, "flop", stream);
   static bool attr_set[64] = {false};
   int dev = 0;

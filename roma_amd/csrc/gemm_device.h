@@ -192,8 +192,8 @@ __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], con
           unsigned o[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            o[j] = pack_bf16x2(__uint_as_float(vp[j] << 16) + __uint_as_float(rp[j] << 16),
-                               __uint_as_float(vp[j] & 0xffff0000u) + __uint_as_float(rp[j] & 0xffff0000u));
+            o[j] = pack_bf16x2(h16_lo(vp[j]) + h16_lo(rp[j]),
+                               h16_hi(vp[j]) + h16_hi(rp[j]));
           v = make_uint4(o[0], o[1], o[2], o[3]);
         }
         if (tm + 1 < TM) load_res(tm + 1, i);  // the register is free again: request the same piece of the next block

@@ -11,6 +11,14 @@ int sample_warp_at_launch(const float* warp, const float* cert, int H, int W, co
 // match_b[i] = j (index into b) or -1.  ws_a / ws_b: 8-byte workspaces of na / nb entries.
 int mutual_nn_launch(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
                      int* match_b, unsigned long long* ws_a, unsigned long long* ws_b, hipStream_t s);
+// Tie-complete form = torch.nonzero of the reference's mask (matcher.py:756-762), two calls around one host read:
+//   count: runs both nearest-neighbour passes, then offs[0 .. na] (int64) = exclusive prefix sums of the per-row match
+//          counts, offs[na] = number of pairs;  fill: pairs[offs[na]][2] (int64: index into a, index into b), row-major.
+int mutual_nn_count_launch(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
+                           unsigned long long* ws_a, unsigned long long* ws_b, long long* offs, hipStream_t s);
+int mutual_nn_fill_launch(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
+                          const unsigned long long* ws_a, const unsigned long long* ws_b, long long* offs, long long* pairs,
+                          hipStream_t s);
 // conf_from_fb_consistency (matcher.py:672-699): flows [B,H,W,2] f32 -> in_th [B,H,W] f32 (0 / 1)
 // visualize_warp (matcher.py:936-986): warp [H,W2,4], certainty [H,W2], images [3,im_h,im_w] f32 -> out [3,H,W2]
 int visualize_warp_launch(const float* warp, const float* cert, const float* im_a, const float* im_b, int H, int W,

@@ -126,6 +126,122 @@ int mutual_nn_launch(const float* a, long na, const float* b, long nb, const flo
   return 0;
 }
 
+// ------------------------------------------------------------------ tie-complete mutual matches
+// The reference returns torch.nonzero of the full mask (D == row min) * (D == column min) * (cert > th) * (D < max_dist)
+// (matcher.py:756-762): EVERY tied pair, row-major.  Ties are what duplicate keypoints produce (detectors emit the same
+// location at several scales), so they are exact in any arithmetic.  After the two nearest-neighbour passes the row / column
+// minima are known; a row's matches are then all j whose squared distance has the bits of BOTH minima.
+//   MODE 0: offs[i + 1] = number of matches of row i (offs[0] = 0); an in-place inclusive scan follows
+//   MODE 1: pairs[offs[i] + k] = (i, j_k), j ascending
+template <int MODE>
+__global__ __launch_bounds__(256) void mutual_pairs_kernel(const float* __restrict__ a, long na, const float* __restrict__ b, long nb,
+                                                           const unsigned long long* __restrict__ best_a,
+                                                           const unsigned long long* __restrict__ best_b,
+                                                           const float* __restrict__ cert_a, float cert_th, float max_d2,
+                                                           long long* __restrict__ offs, long long* __restrict__ pairs) {
+  __shared__ float qs[1024 * 2];
+  __shared__ unsigned qmin[1024];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  float px = 0.f, py = 0.f;
+  unsigned rowmin = 0xffffffffu;
+  bool live = false;
+  if (i < na) {
+    px = a[i * 2 + 0];
+    py = a[i * 2 + 1];
+    const unsigned long long ba = best_a[i];
+    rowmin = (unsigned)(ba >> 32);
+    live = (unsigned)(ba & 0xffffffffull) != 0xffffffffu && (cert_a == nullptr || cert_a[i] > cert_th) &&
+           __uint_as_float(rowmin) < max_d2;
+  }
+  long n = 0;
+  const long base = (MODE == 1 && i < na) ? offs[i] : 0;
+  for (long j0 = 0; j0 < nb; j0 += 1024) {
+    const int cnt = (int)min((long)1024, nb - j0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt * 2; t += 256) qs[t] = b[j0 * 2 + t];
+    for (int t = threadIdx.x; t < cnt; t += 256) qmin[t] = (unsigned)(best_b[j0 + t] >> 32);
+    __syncthreads();
+    if (!live) continue;
+    for (int t = 0; t < cnt; ++t) {
+      if (qmin[t] != rowmin) continue;
+      const float dx = px - qs[2 * t], dy = py - qs[2 * t + 1];
+      if (__float_as_uint(fmaf(dy, dy, dx * dx)) != rowmin) continue;  // same expression as nn_kernel
+      if (MODE == 1) {
+        pairs[(base + n) * 2 + 0] = i;
+        pairs[(base + n) * 2 + 1] = j0 + t;
+      }
+      ++n;
+    }
+  }
+  if (MODE == 0 && i < na) offs[i + 1] = n;
+}
+
+// in-place inclusive scan of v[1 .. n] (v[0] = 0): one workgroup, 1024-element chunks
+__global__ __launch_bounds__(1024) void scan_inclusive_kernel(long long* __restrict__ v, long n) {
+  __shared__ long long part[1024];
+  __shared__ long long carry;
+  if (threadIdx.x == 0) {
+    carry = 0;
+    v[0] = 0;
+  }
+  __syncthreads();
+  for (long c0 = 1; c0 <= n; c0 += 1024) {
+    const long idx = c0 + threadIdx.x;
+    part[threadIdx.x] = idx <= n ? v[idx] : 0;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const long long add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (idx <= n) v[idx] = part[threadIdx.x] + carry;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+}
+
+int mutual_nn_count_launch(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
+                           unsigned long long* ws_a, unsigned long long* ws_b, long long* offs, hipStream_t s) {
+  ROMA_REQUIRE(offs && na >= 0, "mutual_nn_count: bad arguments");
+  if (na == 0) {
+    ROMA_CHECK_HIP(hipMemsetAsync(offs, 0, sizeof(long long), s));
+    return 0;
+  }
+  ROMA_REQUIRE(a && ws_a && ws_b && nb >= 0 && (b || nb == 0), "mutual_nn_count: bad arguments");
+  ROMA_REQUIRE(na < (1l << 31) && nb < (1l << 31), "mutual_nn_count: too many points");
+  ROMA_CHECK_HIP(hipMemsetAsync(ws_a, 0xff, (size_t)na * 8, s));
+  if (nb > 0) ROMA_CHECK_HIP(hipMemsetAsync(ws_b, 0xff, (size_t)nb * 8, s));
+  auto run = [&](const float* p, long np, const float* q, long nq, unsigned long long* best) {
+    const long pblocks = (np + 255) / 256;
+    long slices = std::max<long>(1, std::min<long>((nq + 1023) / 1024, (1024 + pblocks - 1) / pblocks));
+    const long per = (((nq + slices - 1) / slices) + 1023) / 1024 * 1024;
+    slices = (nq + per - 1) / per;
+    hipLaunchKernelGGL(nn_kernel, dim3((unsigned)pblocks, (unsigned)slices), dim3(256), 0, s, p, np, q, nq, best, per);
+  };
+  if (nb > 0) {
+    run(a, na, b, nb, ws_a);
+    run(b, nb, a, na, ws_b);
+  }
+  hipLaunchKernelGGL(mutual_pairs_kernel<0>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, s, a, na, b, nb, ws_a, ws_b, cert_a,
+                     cert_th, max_dist * max_dist, offs, (long long*)nullptr);
+  hipLaunchKernelGGL(scan_inclusive_kernel, dim3(1), dim3(1024), 0, s, offs, na);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+int mutual_nn_fill_launch(const float* a, long na, const float* b, long nb, const float* cert_a, float cert_th, float max_dist,
+                          const unsigned long long* ws_a, const unsigned long long* ws_b, long long* offs, long long* pairs,
+                          hipStream_t s) {
+  if (na == 0 || nb == 0) return 0;
+  ROMA_REQUIRE(a && b && ws_a && ws_b && offs && pairs, "mutual_nn_fill: bad arguments");
+  hipLaunchKernelGGL(mutual_pairs_kernel<1>, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, s, a, na, b, nb, ws_a, ws_b, cert_a,
+                     cert_th, max_dist * max_dist, offs, pairs);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------ forward-backward consistency (matcher.py:672-699)
 // in_th[b,y,x] = || grid(x,y) - bilinear_zeropad(flow_backward[b], flow_forward[b,y,x]) || < th_n
 __global__ __launch_bounds__(256) void fb_consistency_kernel(const float* __restrict__ ff, const float* __restrict__ fb,

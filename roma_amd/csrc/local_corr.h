@@ -19,6 +19,7 @@ struct LocalCorrArgs {
   int nimg = 0, f1_shift = 0;  // image of f0 = b, image of f1 = (b + f1_shift) % nimg
   float scale = 1.f;           // 1/sqrt(C) when f0 is not pre-scaled
   int in_dt = 0, out_dt = 0;
+  int nearest = 0;             // general form only: mode="nearest" of the plugin (local_correlation.py:19,30): one tap, weight 1
   // window form: device scratch for the tile work list, (2 * tiles + 4) ints with tiles = B * ceil(H/8) * ceil(W/8); nullptr =
   // allocate stream-ordered scratch for the call.  force_gather is set by the launcher (tuning switch).
   int* ws = nullptr;

@@ -33,17 +33,20 @@ template <> struct LcIO<bf16_t> {
   static constexpr int CE = 8;
   __device__ static inline void ld(const bf16_t* p, float* v) {
     uint4 u = *reinterpret_cast<const uint4*>(p);
-    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
-    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+    v[0] = h16_lo(u.x); v[1] = h16_hi(u.x);
+    v[2] = h16_lo(u.y); v[3] = h16_hi(u.y);
+    v[4] = h16_lo(u.z); v[5] = h16_hi(u.z);
+    v[6] = h16_lo(u.w); v[7] = h16_hi(u.w);
   }
 };
 
-__device__ inline void unnormalize_floor(float w, int size, int& i0, float& frac) {
+__device__ inline float unnormalize(float w, int size) {
   // grid_sample, align_corners=False: ((x + 1) * size - 1) / 2
-  float ix = ((w + 1.f) * size - 1.f) * 0.5f;
-  ix = fminf(fmaxf(ix, -1.0e6f), 1.0e6f);  // also maps NaN to a finite (all-zero-padding) location
+  const float ix = ((w + 1.f) * size - 1.f) * 0.5f;
+  return fminf(fmaxf(ix, -1.0e6f), 1.0e6f);  // also maps NaN to a finite (all-zero-padding) location
+}
+__device__ inline void unnormalize_floor(float w, int size, int& i0, float& frac) {
+  const float ix = unnormalize(w, size);
   const float f = floorf(ix);
   i0 = (int)f;
   frac = ix - f;
@@ -214,10 +217,7 @@ template <> struct LcDot<float> {  // 32 channels per 128-byte chunk
 };
 template <> struct LcDot<bf16_t> {  // 64 channels per 128-byte chunk, packed pairs
   static constexpr int CC = 64;
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  __device__ static __forceinline__ float d2(unsigned x, unsigned y, float acc) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, x), __builtin_bit_cast(bf16x2, y), acc, false);
-  }
+  __device__ static __forceinline__ float d2(unsigned x, unsigned y, float acc) { return dot2_h16(x, y, acc); }
   __device__ static __forceinline__ float dot(const uint4 (&q)[8], const char* p, float acc) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -551,13 +551,18 @@ __global__ __launch_bounds__(256) void local_corr_general_kernel(const LocalCorr
     float fx, fy;
     unnormalize_floor(a.warp[(pix * a.K + k) * 2 + 0], a.W, x0, fx);
     unnormalize_floor(a.warp[(pix * a.K + k) * 2 + 1], a.H, y0, fy);
+    if (a.nearest) {  // grid_sample mode="nearest": nearbyint of the un-normalised coordinate (ties to even), zero padding
+      x0 = (int)rintf(unnormalize(a.warp[(pix * a.K + k) * 2 + 0], a.W));
+      y0 = (int)rintf(unnormalize(a.warp[(pix * a.K + k) * 2 + 1], a.H));
+      fx = fy = 0.f;  // wgt = {1, 0, 0, 0}: the single tap (y0, x0)
+    }
     const float wgt[4] = {(1.f - fy) * (1.f - fx), (1.f - fy) * fx, fy * (1.f - fx), fy * fx};
     float sum = 0.f;
     for (int c = lane * CE; c < a.C; c += 64 * CE) {
       float q[CE];
       LcIO<T>::ld(f0p + c, q);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < (a.nearest ? 1 : 4); ++t) {
         const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
         if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
           float v[CE];
@@ -629,7 +634,7 @@ static int launch_window_r(const LocalCorrArgs& a, hipStream_t stream) {
   // algorithmic bytes: f0 + f1 read once, centre warp, K outputs
   const double es_in = a.in_dt == DT_F32 ? 4.0 : 2.0, es_out = a.out_dt == DT_F32 ? 4.0 : 2.0;
   char pname[64];
-  snprintf(pname, sizeof pname, "local_corr_window_kernel<%d,%s>", R, a.in_dt == DT_F32 ? "f32" : "bf16");
+  snprintf(pname, sizeof pname, "local_corr_window_kernel<%d,%s>", R, a.in_dt == DT_F32 ? "f32" : ROMA_H16_NAME);
   ProfScope ps(pname, (double)total * (2.0 * a.C * es_in + 8.0 + (2.0 * R + 1) * (2.0 * R + 1) * es_out), "byte", stream);
   static const int env_mode = getenv("ROMA_LC_MODE") ? atoi(getenv("ROMA_LC_MODE")) : 0;
   const int mode = g_lc_mode >= 0 ? g_lc_mode : env_mode;

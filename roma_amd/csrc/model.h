@@ -137,8 +137,6 @@ class Model {
   int make_lin(const std::vector<float>& w, const std::vector<float>* b, int N, int K, Lin* out);
 };
 
-extern int g_refiner_group_mb;  // model.hip: working-set budget of the per-group refiner chains
-
 // GP match encoder for all directed pairs of a call (model.hip); scratch comes from `arena` (dry = plan sizes only)
 int gp_posterior(const void* pf, long ldf, int act_dt, int B, bool symmetric, int th, int tw, const float* gp_w,
                  const float* gp_b, float* mu, long ld_mu, Arena& arena, hipStream_t st, bool dry);

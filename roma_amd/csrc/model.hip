@@ -17,8 +17,6 @@
 
 namespace roma {
 
-int g_refiner_group_mb = -1;  // roma_tuning("refiner_group_mb", v); -1 = env ROMA_REFINER_GROUP_MB (default 0 = off)
-
 static const int VGG_IDX[12] = {0, 3, 7, 10, 14, 17, 20, 23, 27, 30, 33, 36};
 static const int VGG_CH[12] = {64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512};
 static const char* SCALES[5] = {"16", "8", "4", "2", "1"};
@@ -427,7 +425,7 @@ int Model::finalize() {
   ROMA_REQUIRE(!finalized, "roma_finalize: already finalized");
   ROMA_CHECK_HIP(hipSetDevice(cfg.device));
   if (int rc = check_contract()) return rc;
-  act_dt = cfg.precision == ROMA_BF16 ? DT_BF16 : DT_F32;
+  act_dt = cfg.precision == ROMA_F32 ? DT_F32 : DT_BF16;  // roma_create admitted only this build's 16-bit code
   if (int rc = pack_weights()) return rc;
   host.clear();
   // plan the workspace with a dry run at the largest configuration
@@ -1008,37 +1006,25 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         void *dcur = d0, *dalt = d1;
         if (int rc = CK(tp + "_din", d0, (size_t)M * r.Cp * esz)) return rc;
         const bool fused = fuse_refiner_blocks && refiner_block_supported(r.Cp, act_dt);
-        // The nine blocks of a refiner are pixel-local per directed pair, so the chain can run over GROUPS of pairs: with a
-        // group whose ping-pong pair (2 x group x hw x Cp) fits the 256 MiB Infinity Cache every block reads what the
-        // previous block just wrote from the cache instead of streaming the whole batch through HBM nine times.
-        // roma_tuning("refiner_group_mb", v) / env ROMA_REFINER_GROUP_MB: working-set budget in MiB, 0 = whole batch at once.
-        static const int grp_env = getenv("ROMA_REFINER_GROUP_MB") ? atoi(getenv("ROMA_REFINER_GROUP_MB")) : 0;
-        const long grp_mb = g_refiner_group_mb >= 0 ? g_refiner_group_mb : grp_env;
-        int gsz = ndp;
-        if (grp_mb > 0 && !tracing)
-          gsz = (int)std::max<long>(1, std::min<long>(ndp, (grp_mb << 20) / std::max<long>(1, 2 * hw * r.Cp * (long)esz)));
-        for (int g0 = 0; g0 < ndp; g0 += gsz) {
-          const int gn = std::min(gsz, ndp - g0);
-          const long Mg = (long)gn * hw;
-          void *gcur = off(d0, (long)g0 * hw * r.Cp), *galt = off(d1, (long)g0 * hw * r.Cp);
-          for (int b = 0; b < 9; ++b) {
-            if (fused) {  // narrow scales: dw5x5 + 1x1 in one pass over HBM (refiner_block.hip)
-              RUN(refiner_block_launch(gcur, galt, r.dw_w[b], r.dw_b[b], r.pw[b].w, r.pw[b].ldw, r.pw[b].b, gn, hs, ws,
-                                       r.Cp, act_dt, st));
-              std::swap(gcur, galt);
-              if (int rc = CK(tp + "_blk" + std::to_string(b), gcur, (size_t)Mg * r.Cp * esz)) return rc;
-              continue;
-            }
-            RUN(dwconv5x5_launch(gcur, galt, r.dw_w[b], r.dw_b[b], gn, hs, ws, r.Cp, act_dt, st));
-            if (int rc = CK(tp + "_dw" + std::to_string(b), galt, (size_t)Mg * r.Cp * esz)) return rc;
-            GemmArgs g;
-            g.A = galt; g.lda = r.Cp; g.W = r.pw[b].w; g.ldw = r.pw[b].ldw; g.C = gcur; g.ldc = r.Cp;
-            g.M = (int)Mg; g.N = r.Cp; g.K = r.Cp; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = r.pw[b].b;
-            RUN(gemm_launch(g, st));
-            if (int rc = CK(tp + "_blk" + std::to_string(b), gcur, (size_t)Mg * r.Cp * esz)) return rc;
+        // (Running the nine-block chain over GROUPS of pairs whose ping-pong buffers fit the 256 MiB Infinity Cache was
+        // measured in round 3 and is slower: 97.4 ms/step whole batch, 98.6 / 99.3 / 101.3 with 400 / 200 / 100 MiB
+        // groups - the smaller launches lose more than the cache hits win, profiles/r03_v1_ab_attn_map_refiner_groups.log.)
+        for (int b = 0; b < 9; ++b) {
+          if (fused) {  // narrow scales: dw5x5 + 1x1 in one pass over HBM (refiner_block.hip)
+            RUN(refiner_block_launch(dcur, dalt, r.dw_w[b], r.dw_b[b], r.pw[b].w, r.pw[b].ldw, r.pw[b].b, ndp, hs, ws,
+                                     r.Cp, act_dt, st));
+            std::swap(dcur, dalt);
+            if (int rc = CK(tp + "_blk" + std::to_string(b), dcur, (size_t)M * r.Cp * esz)) return rc;
+            continue;
           }
+          RUN(dwconv5x5_launch(dcur, dalt, r.dw_w[b], r.dw_b[b], ndp, hs, ws, r.Cp, act_dt, st));
+          if (int rc = CK(tp + "_dw" + std::to_string(b), dalt, (size_t)M * r.Cp * esz)) return rc;
+          GemmArgs g;
+          g.A = dalt; g.lda = r.Cp; g.W = r.pw[b].w; g.ldw = r.pw[b].ldw; g.C = dcur; g.ldc = r.Cp;
+          g.M = (int)M; g.N = r.Cp; g.K = r.Cp; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = r.pw[b].b;
+          RUN(gemm_launch(g, st));
+          if (int rc = CK(tp + "_blk" + std::to_string(b), dcur, (size_t)M * r.Cp * esz)) return rc;
         }
-        if (fused) std::swap(dcur, dalt);  // nine swaps: the fused chain ends in the other buffer
         const float sx = (float)ins / (4.0f * (float)W), sy = (float)ins / (4.0f * (float)H);
         RUN(refiner_out_launch(dcur, r.Cp, act_dt, r.out_w, r.out_b, flow, cert, M, r.Cp, sx, sy, st));
         if (int rc = CK(tp + "_flow", flow, (size_t)M * 2 * 4)) return rc;

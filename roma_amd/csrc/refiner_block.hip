@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __r
 #define ROMA_RB_CVT(J)                                                                             \
   {                                                                                                \
     const uint32_t lo_ = (uint32_t)cr[J], hi_ = (uint32_t)(cr[J] >> 32);                           \
-    v[J][0] = f32x2{__uint_as_float(lo_ << 16), __uint_as_float(lo_ & 0xffff0000u)};               \
-    v[J][1] = f32x2{__uint_as_float(hi_ << 16), __uint_as_float(hi_ & 0xffff0000u)};               \
+    v[J][0] = f32x2{h16_lo(lo_), h16_hi(lo_)};               \
+    v[J][1] = f32x2{h16_lo(hi_), h16_hi(hi_)};               \
   }
       f32x2 v[8][2];
       ROMA_RB_CVT(0) ROMA_RB_CVT(1) ROMA_RB_CVT(2)
@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __r
 #pragma unroll
           for (int u = 0; u < PXB; ++u) {
             const u32x4_t xf = *(lds_u32x4*)(Xt + (u * 32 + l31) * XROW + ks * 32 + hh * 16);
-            oa[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wown[ks]),
-                                                            __builtin_bit_cast(bf16x8_t, xf), oa[u], 0, 0, 0);
+            oa[u] = mfma_h16_32x32x16(wown[ks],
+                                                            xf, oa[u]);
           }
 #pragma unroll
         for (int u = 0; u < PXB; ++u) {
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __r
         for (int ks = 0; ks < KS; ++ks) {
           const u32x4_t wf = *(lds_u32x4*)(Wt + wrow * XROW + ks * 32 + hhv * 16);
           const u32x4_t xf = *(lds_u32x4*)(Xt + (pb * 32 + l31v) * XROW + ks * 32 + hhv * 16);
-          ta = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, xf),
-                                                       ta, 0, 0, 0);
+          ta = mfma_h16_32x32x16(wf, xf,
+                                                       ta);
         }
         const int pxl = pb * 32 + l31v;
         if (pxl < PX) {

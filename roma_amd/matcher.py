@@ -71,7 +71,6 @@ class RegressionMatcher:
     def __init__(self, weights, dinov2_weights, h=560, w=560, sample_mode="threshold_balanced", upsample_preds=False,
                  symmetric=False, sample_thresh=0.05, name=None, attenuate_cert=None, upsample_res=None,
                  device=None, amp_dtype=torch.float16, max_batch=8):
-        _lib.load()
         dev = torch.device(device if device is not None else "cuda")
         if dev.type != "cuda":
             raise _lib.RomaHipError(f"roma_amd runs only on a HIP device (got device={device!r}); there is no CPU fallback")
@@ -89,12 +88,11 @@ class RegressionMatcher:
         self.sample_thresh = sample_thresh
         if amp_dtype not in (torch.float32, torch.bfloat16, torch.float16):
             raise ValueError(f"amp_dtype must be torch.float32, torch.bfloat16 or torch.float16 (got {amp_dtype})")
-        if amp_dtype == torch.float16:
-            # the reference's GPU default (model_zoo/__init__.py:37); gfx950's MFMA has one 16-bit rate for both formats
-            # and this library stores its reduced-precision activations as bf16 (8-bit mantissa, f32 range)
-            warn("roma_amd: amp_dtype=torch.float16 runs in bfloat16 (f32 accumulate); pass torch.float32 for the "
-                 "exact-f32 parity mode", stacklevel=3)
+        # torch.float16 (the reference's GPU default, model_zoo/__init__.py:37) runs on libroma_hip_f16.so: IEEE binary16
+        # storage, f32 accumulate; torch.bfloat16 (the reference's timing script) and torch.float32 on libroma_hip.so.
+        # gfx950's MFMA has one 16-bit rate for both formats.
         self.amp_dtype = amp_dtype
+        self._lib = _lib.load(_lib.fmt_of(amp_dtype))
         self.max_batch = int(max_batch)
         self.training = False
         self.debug = False
@@ -118,7 +116,7 @@ class RegressionMatcher:
         h, w = hw if hw is not None else (self.h_resized, self.w_resized)
         up = tuple(int(v) for v in self.upsample_res) if self.upsample_preds else (0, 0)
         return (int(h), int(w), up,
-                _lib.ROMA_F32 if self.amp_dtype == torch.float32 else _lib.ROMA_BF16, self.max_batch, self.device.index)
+                _lib.ROMA_F32 if self.amp_dtype == torch.float32 else _lib.H16_CODE[self._lib.h16], self.max_batch, self.device.index)
 
     def _ensure_handle(self, hw=None):
         key = self._config_key(hw)
@@ -127,14 +125,14 @@ class RegressionMatcher:
         if (self._handle is not None and key[2] == (0, 0) and self._built[:2] + self._built[3:] == key[:2] + key[3:]):
             return  # upsample_preds switched off: the handle planned for the upsample pass also runs coarse-only
         self._release()
-        lib = _lib.load()
+        lib = self._lib
         uh, uw = key[2]
         if uh % 8 or uw % 8:
             raise ValueError("upsample_res must be a multiple of 8 (VGG19 feature pyramid)")
         cfg = _lib.RomaConfig(key[0], key[1], uh, uw, int(bool(self.symmetric)), int(bool(self.upsample_preds)),
                               int(bool(self.attenuate_cert)), key[3], self.max_batch, self.device.index)
         h = C.c_void_p()
-        _lib.check(lib.roma_create(C.byref(cfg), C.byref(h)), exc=AssertionError)
+        _lib.check(lib.roma_create(C.byref(cfg), C.byref(h)), exc=AssertionError, lib=lib)
         try:
             for prefix, sd in (("", self._weights), ("dinov2.", self._dinov2_weights)):
                 for k, v in sd.items():
@@ -143,9 +141,9 @@ class RegressionMatcher:
                     if not is_i64:
                         t = t.float().contiguous()
                     shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
-                    _lib.check(lib.roma_set_tensor(h, (prefix + k).encode(), t.dim(), shape, C.c_void_p(t.data_ptr()), int(is_i64)))
+                    _lib.check(lib.roma_set_tensor(h, (prefix + k).encode(), t.dim(), shape, C.c_void_p(t.data_ptr()), int(is_i64)), lib=lib)
             # strict key/shape contract, as matcher.load_state_dict(weights) (roma_models.py:204)
-            _lib.check(lib.roma_finalize(h), exc=RuntimeError)
+            _lib.check(lib.roma_finalize(h), exc=RuntimeError, lib=lib)
         except Exception:
             lib.roma_destroy(h)
             raise
@@ -154,7 +152,7 @@ class RegressionMatcher:
 
     def _release(self):
         if getattr(self, "_handle", None) is not None:
-            _lib.load().roma_destroy(self._handle)
+            self._lib.roma_destroy(self._handle)
             self._handle = None
 
     def __del__(self):
@@ -231,10 +229,10 @@ class RegressionMatcher:
             raise ValueError(f"roma_amd.match: inputs live on {device} but this matcher was built for {self.device}; "
                              "use one matcher (one handle) per GPU")
         self._ensure_handle(call_hw)
-        lib = _lib.load()
+        lib = self._lib
         for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug", "vit_bf16_residual", "dual_stream", "trace"):
-            _lib.check(lib.roma_set_option(self._handle, k.encode(), int(bool(getattr(self, k)))))
-        _lib.check(lib.roma_set_option_f(self._handle, b"coarse_scale_factor", float(scale_factor)))
+            _lib.check(lib.roma_set_option(self._handle, k.encode(), int(bool(getattr(self, k)))), lib=lib)
+        _lib.check(lib.roma_set_option_f(self._handle, b"coarse_scale_factor", float(scale_factor)), lib=lib)
         B = a.shape[0]
         Ho, Wo = self.get_output_resolution() if self.upsample_preds else (a.shape[-2], a.shape[-1])
         Wout = 2 * Wo if self.symmetric else Wo
@@ -254,19 +252,19 @@ class RegressionMatcher:
 
     def debug_fetch(self, name: str, dtype=np.float32) -> np.ndarray:
         """Intermediate tensor captured by the last match() when `self.debug` is set (tests only)."""
-        lib = _lib.load()
+        lib = self._lib
         n = lib.roma_debug_fetch(self._handle, name.encode(), None, 0)
         if n < 0:
-            raise KeyError(_lib.last_error())
+            raise KeyError(_lib.last_error(lib))
         buf = np.empty(n // np.dtype(dtype).itemsize, dtype=dtype)
         got = lib.roma_debug_fetch(self._handle, name.encode(), C.c_void_p(buf.ctypes.data), n)
         if got < 0:
-            raise _lib.RomaHipError(_lib.last_error())
+            raise _lib.RomaHipError(_lib.last_error(lib))
         return buf
 
     def debug_trace(self, slot: int = 0):
         """(names, uint64 checksums) of the stages of the last match() on sub-batch stream `slot` (needs `self.trace`)."""
-        lib = _lib.load()
+        lib = self._lib
         n = lib.roma_debug_trace(self._handle, slot, None, 0, None, 0)
         if n <= 0:
             return [], np.zeros(0, dtype=np.uint64)
@@ -274,19 +272,19 @@ class RegressionMatcher:
         names = C.create_string_buffer(64 * n + 16)
         got = lib.roma_debug_trace(self._handle, slot, C.c_void_p(sums.ctypes.data), n, names, len(names))
         if got < 0:
-            raise _lib.RomaHipError(_lib.last_error())
+            raise _lib.RomaHipError(_lib.last_error(lib))
         return names.value.decode().split("\n")[:n], sums
 
     def debug_inject(self, name: str, value: Optional[np.ndarray]):
         """Tests only (needs `self.debug`): override the named intermediate ("gm_flow16" [b,T,2], "gm_cert16" [b,T]) of
         the following match() calls with `value`; None removes the override."""
-        lib = _lib.load()
+        lib = self._lib
         self._ensure_handle()
         if value is None:
-            _lib.check(lib.roma_debug_inject(self._handle, name.encode(), None, 0))
+            _lib.check(lib.roma_debug_inject(self._handle, name.encode(), None, 0), lib=lib)
             return
         a = np.ascontiguousarray(value, dtype=np.float32)
-        _lib.check(lib.roma_debug_inject(self._handle, name.encode(), C.c_void_p(a.ctypes.data), a.nbytes))
+        _lib.check(lib.roma_debug_inject(self._handle, name.encode(), C.c_void_p(a.ctypes.data), a.nbytes), lib=lib)
 
     # ------------------------------------------------------------------ sampling (matcher.py:598-629)
     def sample(self, matches, certainty, num=10000):
@@ -318,9 +316,9 @@ class RegressionMatcher:
         """Mutual-nearest-neighbour matching of detector keypoints through the dense warp.
 
         x_A [Na,2], x_B [Nb,2] normalised (x,y); warp [H,W,4] / certainty [H,W] of ONE pair (as returned by match() with
-        the batch dimension removed).  `roma_op_sample_warp_at` + `roma_op_mutual_nn` replace the reference's
-        grid_sample + Na x Nb cdist matrix; a keypoint of A tied between several nearest B keypoints yields one pair
-        (lowest index) where the reference yields all of them."""
+        the batch dimension removed).  `roma_op_sample_warp_at` + `roma_op_mutual_nn_count / _fill` replace the reference's
+        grid_sample + Na x Nb cdist matrix and return what its torch.nonzero returns: every mutual pair, tied pairs
+        (duplicate keypoints) included, in row-major order."""
         for t in (x_A, x_B, warp, certainty):
             if not t.is_cuda:
                 raise _lib.RomaHipError("match_keypoints: tensors must live on a HIP device; there is no CPU fallback")
@@ -336,17 +334,21 @@ class RegressionMatcher:
         dev = xa.device
         xab = torch.empty((na, 2), device=dev, dtype=torch.float32)
         ca = torch.empty((na,), device=dev, dtype=torch.float32)
-        match_b = torch.empty((na,), device=dev, dtype=torch.int32)
+        offs = torch.empty((na + 1,), device=dev, dtype=torch.int64)
         ws_a = torch.empty((max(na, 1),), device=dev, dtype=torch.int64)
         ws_b = torch.empty((max(nb, 1),), device=dev, dtype=torch.int64)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         with torch.cuda.device(dev):
             _lib.check(lib.roma_op_sample_warp_at(P(w), P(c), H, W, P(xa), na, P(xab), P(ca), stream))
-            _lib.check(lib.roma_op_mutual_nn(P(xab), na, P(xb), nb, P(ca), float(cert_th), float(max_dist), P(match_b),
-                                             P(ws_a), P(ws_b), stream))
-        inds_A = torch.nonzero(match_b >= 0, as_tuple=True)[0]
-        inds_B = match_b[inds_A].to(torch.int64)
+            _lib.check(lib.roma_op_mutual_nn_count(P(xab), na, P(xb), nb, P(ca), float(cert_th), float(max_dist),
+                                                   P(ws_a), P(ws_b), P(offs), stream))
+            n_pairs = int(offs[na].item())  # the one host read (torch.nonzero synchronises in the reference too)
+            pairs = torch.empty((n_pairs, 2), device=dev, dtype=torch.int64)
+            if n_pairs:
+                _lib.check(lib.roma_op_mutual_nn_fill(P(xab), na, P(xb), nb, P(ca), float(cert_th), float(max_dist),
+                                                      P(ws_a), P(ws_b), P(offs), P(pairs), stream))
+        inds_A, inds_B = pairs[:, 0], pairs[:, 1]
         if return_tuple:
             if return_inds:
                 return inds_A, inds_B

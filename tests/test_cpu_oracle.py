@@ -33,6 +33,10 @@ def test_oracle_ops_vs_reference_golden():
         assert torch.allclose(out, ref, atol=1e-6), name
     flow = O.cls_to_flow_refine(torch.from_numpy(g["c2f_cls"]))
     assert torch.allclose(flow, torch.from_numpy(g["c2f_flow"]), atol=1e-6)
+    gn = np.load(os.path.join(GOLDEN, "ops_nearest_reference.npz"))  # sample_mode="nearest" (local_correlation.py:19,30,85)
+    for name, r in (("nn_r3", 3), ("nn_r2", 2)):
+        f0, f1, warp, ref = [torch.from_numpy(gn[f"{name}_{k}"]) for k in ("f0", "f1", "warp", "corr")]
+        assert torch.allclose(O.local_correlation(f0, f1, r, warp, sample_mode="nearest"), ref, atol=1e-6), name
 
 
 def test_oracle_match_vs_reference_golden_tiny(weights0):
@@ -187,9 +191,14 @@ def test_library_exports_every_declared_symbol(built_lib):
     header = open(os.path.join(ROOT, "include", "roma_hip.h")).read()
     declared = set(re.findall(r"\b(roma_[a-z0-9_]+)\s*\(", header)) - {"roma_model"}
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    for name in declared:
-        assert hasattr(built_lib, name), name
-    assert b"gfx950" in built_lib.roma_version()
+    # both builds of the library (16-bit storage = bf16 / IEEE binary16, csrc/common.h) export the whole ABI
+    for fmt, code in (("bf16", _lib.ROMA_BF16), ("f16", _lib.ROMA_F16)):
+        lib = _lib.load(fmt)
+        for name in declared:
+            assert hasattr(lib, name), (fmt, name)
+        assert b"gfx950" in lib.roma_version() and fmt.encode() in lib.roma_version()
+        assert lib.roma_h16_format() == code
+    assert _lib.load("bf16") is built_lib
 
 
 def test_c_abi_argument_validation_without_gpu(built_lib):
@@ -198,6 +207,11 @@ def test_c_abi_argument_validation_without_gpu(built_lib):
     cfg = _lib.RomaConfig(100, 112, 0, 0, 1, 0, 1, 0, 1, 0)  # 100 is not a multiple of 14
     rc = built_lib.roma_create(C.byref(cfg), C.byref(h))
     assert rc != 0 and b"multiple of 14" in built_lib.roma_last_error()
+    # the 16-bit format is a build property: each library rejects the other one's code (never reinterprets the bits)
+    for fmt, other in (("bf16", _lib.ROMA_F16), ("f16", _lib.ROMA_BF16)):
+        lib = _lib.load(fmt)
+        cfg = _lib.RomaConfig(112, 112, 0, 0, 1, 0, 1, other, 1, 0)
+        assert lib.roma_create(C.byref(cfg), C.byref(h)) != 0 and b"this library stores" in lib.roma_last_error()
     if not torch.cuda.is_available():
         cfg = _lib.RomaConfig(112, 112, 0, 0, 1, 0, 1, 0, 1, 0)
         rc = built_lib.roma_create(C.byref(cfg), C.byref(h))

@@ -372,6 +372,31 @@ def test_local_corr_reference_golden(lib, name, r):
     assert torch.allclose(out2.cpu(), ref, atol=5e-5, rtol=1e-5), (out2.cpu() - ref).abs().max()
 
 
+@pytest.mark.parametrize("name,r", [("nn_r3", 3), ("nn_r2", 2)])
+def test_local_corr_nearest_reference_golden(lib, name, r):
+    """mode="nearest" of the plugin (local_correlation.py:19,30,85) against the reference's own fallback: exact half-pixel
+    ties (nearbyint, to even), exact centres, out-of-range taps; window form and plugin-signature form."""
+    from roma_amd.local_correlation import local_corr, local_correlation
+    g = np.load(os.path.join(GOLDEN, "ops_nearest_reference.npz"))
+    f0, f1, warp, ref = [torch.from_numpy(g[f"{name}_{k}"]) for k in ("f0", "f1", "warp", "corr")]
+    out = local_correlation(f0.cuda(), f1.cuda(), r, warp.cuda(), sample_mode="nearest")
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    assert torch.allclose(out.cpu(), ref, atol=5e-5, rtol=1e-5), (out.cpu() - ref).abs().max()
+    B, c, h, w = f0.shape
+    K = (2 * r + 1) ** 2
+    lw = torch.meshgrid(torch.linspace(-2 * r / h, 2 * r / h, 2 * r + 1), torch.linspace(-2 * r / w, 2 * r / w, 2 * r + 1), indexing="ij")
+    lw = torch.stack((lw[1], lw[0]), dim=-1).reshape(1, K, 2)
+    coords = (warp.permute(0, 2, 3, 1)[..., None, :] + lw[:, None, None]).reshape(B, h * w, K, 2)
+    out2 = local_corr(f0.reshape(B, c, h * w).permute(0, 2, 1).contiguous().cuda() / (c ** 0.5),
+                      f1.permute(0, 2, 3, 1).contiguous().cuda(), coords.cuda(), mode="nearest")
+    out2 = out2.permute(0, 2, 1).reshape(B, K, h, w)
+    assert torch.allclose(out2.cpu(), ref, atol=5e-5, rtol=1e-5), (out2.cpu() - ref).abs().max()
+    with pytest.raises(ValueError):
+        local_corr(f0.reshape(B, c, h * w).permute(0, 2, 1).contiguous().cuda(), f1.permute(0, 2, 3, 1).contiguous().cuda(),
+                   coords.cuda(), mode="bicubic")
+
+
 def test_local_corr_real_shape_vs_oracle(lib):
     """stride-8 shape of the real model (C=512, r=3) with a smooth + noisy warp, bf16 and f32."""
     from oracle import roma_oracle
@@ -737,6 +762,20 @@ def test_match_keypoints_vs_reference_golden():
     # empty keypoint sets do not launch anything
     e = m.match_keypoints(t["x_A"][:0], t["x_B"], t["warp"], t["cert"], return_inds=True)
     assert len(e[0]) == 0 and len(e[1]) == 0
+
+
+def test_match_keypoints_ties_vs_reference_golden():
+    """Duplicate keypoints: the reference's torch.nonzero returns every tied mutual pair in row-major order
+    (matcher.py:756-762); roma_op_mutual_nn_count / _fill must return exactly that list."""
+    from roma_amd.matcher import RegressionMatcher
+    g = np.load(os.path.join(GOLDEN, "keypoints_ties_reference.npz"))
+    t = {k: torch.from_numpy(g[k]).cuda() for k in ("warp", "cert", "x_A", "x_B")}
+    m = RegressionMatcher.__new__(RegressionMatcher)
+    for name, kw in (("default", {}), ("loose", dict(max_dist=0.02, cert_th=0.6))):
+        iA, iB = m.match_keypoints(t["x_A"], t["x_B"], t["warp"], t["cert"], return_inds=True, **kw)
+        assert len(g["inds_A_" + name]) > len(np.unique(g["inds_A_" + name]))  # the fixture does contain tied pairs
+        assert np.array_equal(iA.cpu().numpy(), g["inds_A_" + name]), name
+        assert np.array_equal(iB.cpu().numpy(), g["inds_B_" + name]), name
 
 
 def test_visualize_warp_vs_reference_golden(tmp_path):

@@ -34,24 +34,33 @@ TOL_F32 = 1e-3
 # of the coarse tokens flip, every flipped token has a reference gap <= 0.58; with the reference's coarse match injected
 # the outputs differ by <= 1.5e-4 (flow, p99 1.0e-4) / 1.1e-2 (certainty, p99 5.4e-3) at 560 -> 864, 4.8e-4 / 6.5e-3 at
 # 112 -> 168; encoder pyramids <= 0.9 % of their range (stride 16: 2.5 %)
-BF16 = dict(logit=3.0,            # max |class logit - oracle|
-            gap_flipped=1.5,      # a token may only flip where the reference's own top-2 gap is below this
-            flip_frac=0.05,       # and at most this share of the tokens does
-            flow_max=1.5e-3, flow_p99=1.0e-3, cert_max=3e-2, cert_p99=1.5e-2,   # final outputs, coarse match injected
+# Round 3: gates tightened to ~1.5 x the measurements (logit 3.0 -> 2.0, flip share 0.05 -> 0.03,
+# certainty 3e-2 -> 1.5e-2).
+BF16 = dict(logit=2.0,            # max |class logit - oracle|
+            gap_flipped=1.0,      # a token may only flip where the reference's own top-2 gap is below this
+            flip_frac=0.03,       # and at most this share of the tokens does
+            flow_max=1.0e-3, flow_p99=5.0e-4, cert_max=1.5e-2, cert_p99=1.0e-2,   # final outputs, coarse match injected
             cert_logit_stage=0.2, # per-scale certainty logits (before the sigmoid), coarse match injected
             feat_rel=3e-2)        # max |stage - oracle| / max |oracle| of the encoder pyramids (x2 at stride 16 / GP)
+# IEEE binary16 storage (amp_dtype=torch.float16, the reference's default policy; libroma_hip_f16.so): 11 significand bits
+# instead of 8, so every continuous bound is tightened by 4 (the roundings are 8 x smaller; 2 x margin on top)
+F16 = dict(logit=0.75, gap_flipped=0.4, flip_frac=0.0125, flow_max=4e-4, flow_p99=2.5e-4, cert_max=7.5e-3, cert_p99=4e-3,
+           cert_logit_stage=0.05, feat_rel=7.5e-3)
 
 
 def _dev(d):
     return {k: v.cuda() for k, v in d.items()}
 
 
-def _bf16_np(u16):
+def _h16_np(u16, fmt):
+    """raw 16-bit activations of a debug stage -> f32 (fmt = the storage format of the model's library)"""
+    if fmt == "f16":
+        return u16.view(np.float16).astype(np.float32)
     return (u16.astype(np.uint32) << 16).view(np.float32)
 
 
-def _fetch(m, name, bf16):
-    return _bf16_np(m.debug_fetch(name, dtype=np.uint16)) if bf16 else m.debug_fetch(name)
+def _fetch(m, name, h16):
+    return _h16_np(m.debug_fetch(name, dtype=np.uint16), m._lib.h16) if h16 else m.debug_fetch(name)
 
 
 def _report(name, obj):
@@ -101,7 +110,10 @@ def test_bf16_vgg_front_end_kernels_vs_implicit_gemm_in_the_model(built_lib, wei
 
 
 # ------------------------------------------------------------------------------------------------ 112 -> 168, stage-wise
-def test_bf16_tiny_stagewise_vs_oracle(built_lib, weights0):
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
+def test_h16_tiny_stagewise_vs_oracle(built_lib, weights0, fmt):
+    BF16 = {"bf16": globals()["BF16"], "f16": F16}[fmt]  # the bounds of this storage format
+    amp = torch.bfloat16 if fmt == "bf16" else torch.float16
     from oracle import roma_oracle as O
     from roma_amd import roma_model, synthetic
     sd, dsd = weights0
@@ -111,8 +123,9 @@ def test_bf16_tiny_stagewise_vs_oracle(built_lib, weights0):
     w_ref, c_ref = w_ref.numpy(), c_ref.numpy()
     d = _dev(inp)
     kw = dict(im_A_high_res=d["im_A_high_res"], im_B_high_res=d["im_B_high_res"])
-    m = roma_model((112, 112), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=torch.bfloat16,
+    m = roma_model((112, 112), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=amp,
                    symmetric=True, upsample_res=(168, 168), max_batch=1)
+    assert m._lib.h16 == fmt
     m.debug = True
     rep = {}
     checks = []  # (condition, message): everything is measured and reported first, asserted at the end
@@ -168,7 +181,7 @@ def test_bf16_tiny_stagewise_vs_oracle(built_lib, weights0):
         checks.append((e["flow"]["max"] < BF16["flow_max"] and e["flow"]["p99"] < BF16["flow_p99"], str(("tiny injected flow", e["flow"]))))
         checks.append((e["cert"]["max"] < BF16["cert_max"] and e["cert"]["p99"] < BF16["cert_p99"], str(("tiny injected cert", e["cert"]))))
         rep[f"vit_bf16_residual={res16}"] = r
-    _report("bf16_tiny_stagewise", rep)
+    _report(fmt + "_tiny_stagewise", rep)
     failed = [msg for cond, msg in checks if not cond]
     assert not failed, failed
 
@@ -180,7 +193,7 @@ def full_models(built_lib, weights0):
     from roma_amd import roma_model
     sd, dsd = weights0
     out = {}
-    for name, amp in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+    for name, amp in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16)):
         out[name] = roma_model((560, 560), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=amp,
                                symmetric=True, upsample_res=(864, 864), max_batch=8)
     return out
@@ -204,7 +217,8 @@ def _run(m, inp, debug=False, inject=None):
 
 
 def _bf16_vs_golden(tag, m, inp, g):
-    """uninjected run: flips counted and explained; injected run: bounded."""
+    """uninjected run: flips counted and explained; injected run: bounded (bounds of the model's storage format)."""
+    BF16 = {"bf16": globals()["BF16"], "f16": F16}[m._lib.h16]
     w, c, own = _run(m, inp, debug=True)
     fl = PM.coarse_flips(own, PM.nchw_to_tokens(g["gm_flow16"]), PM.nchw_to_tokens(g["cls16_top2gap"][:, None]))
     e_raw = PM.output_errors(w[:, ::8, ::8], c[:, ::8, ::8], g["warp_sub"], g["cert_sub"])
@@ -215,7 +229,7 @@ def _bf16_vs_golden(tag, m, inp, g):
     assert fl["max_gap_of_flipped"] < BF16["gap_flipped"], fl     # flips only where the reference itself is undecided
     assert fl["flips"] <= BF16["flip_frac"] * fl["tokens"], fl
     assert fl["max_flow16_err_unflipped"] < 1e-2, fl
-    _check_out(tag, e_inj)
+    _check_out(tag, e_inj, BF16)
     return fl, e_raw, e_inj
 
 
@@ -246,6 +260,14 @@ def test_bf16_full8_vs_reference_golden(full_models):
     from roma_amd import synthetic
     g = np.load(os.path.join(GOLDEN, "match_full8.npz"))
     _bf16_vs_golden("bf16_full8", full_models["bf16"], _dev(synthetic.make_inputs(8, 560, 864, seed=1)), g)
+
+
+def test_f16_full8_vs_reference_golden(full_models):
+    """The bench workload in the reference's DEFAULT precision policy (amp_dtype=torch.float16: IEEE binary16 storage,
+    libroma_hip_f16.so) against the reference's fp32 output: same gates, 4 x tighter bounds."""
+    from roma_amd import synthetic
+    g = np.load(os.path.join(GOLDEN, "match_full8.npz"))
+    _bf16_vs_golden("f16_full8", full_models["f16"], _dev(synthetic.make_inputs(8, 560, 864, seed=1)), g)
 
 
 def test_f32_full8_indoor_vs_reference_golden(built_lib):

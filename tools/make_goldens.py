@@ -5,6 +5,7 @@ fixtures are what travels to the GPU box.  Usage:
 
     python tools/make_goldens.py contract      # state-dict key/shape contract
     python tools/make_goldens.py ops           # operator-level goldens from reference functions
+    python tools/make_goldens.py ops_nearest   # local_correlation(sample_mode="nearest") from the reference's fallback
     python tools/make_goldens.py tiny          # match() 112 -> 168, B=1 symmetric (+ stage tensors)
     python tools/make_goldens.py small         # match() 224 -> 336, B=2, non-symmetric and symmetric coarse-only
     python tools/make_goldens.py full          # match() 560 -> 864, B=1 symmetric (sub-sampled)
@@ -13,6 +14,7 @@ fixtures are what travels to the GPU box.  Usage:
     python tools/make_goldens.py full8_indoor  # same geometry, seeds 2 / 3 (BASELINE config 5 "indoor")
     python tools/make_goldens.py kde           # romatch.utils.kde.kde on seeded match-like points
     python tools/make_goldens.py keypoints     # RegressionMatcher.match_keypoints on a seeded warp + keypoints
+    python tools/make_goldens.py keypoints_ties  # the same with duplicate keypoints: every tied pair is returned
     python tools/make_goldens.py vis           # RegressionMatcher.visualize_warp on a seeded warp + images
     python tools/make_goldens.py tinyroma      # TinyRoMa.match / forward with the seeded stand-in XFeat backbone
 """
@@ -87,6 +89,34 @@ def ops():
     out["c2f_cls"], out["c2f_flow"] = np32(cls), np32(cls_to_flow_refine(cls))
     np.savez_compressed(os.path.join(GOLD, "ops_reference.npz"), **out)
     print("ops:", {k: v.shape for k, v in out.items()})
+
+
+def ops_nearest():
+    """sample_mode="nearest" of local_correlation (local_correlation.py:19,30,85) from the reference's torch fallback,
+    incl. exact half-pixel ties (nearbyint: to even), exact centres and out-of-range taps."""
+    install_stubs()
+    from romatch.utils.local_correlation import local_correlation
+    g = np.random.Generator(np.random.PCG64(321))
+
+    def rn(*s, std=1.0):
+        return torch.from_numpy(g.standard_normal(size=s, dtype=np.float32) * np.float32(std))
+
+    out = {}
+    for name, (r, C, h, w) in {"nn_r3": (3, 64, 12, 12), "nn_r2": (2, 32, 16, 20)}.items():
+        B = 2
+        f0, f1 = rn(B, C, h, w), rn(B, C, h, w)
+        ys = torch.linspace(-1 + 1 / h, 1 - 1 / h, h)
+        xs = torch.linspace(-1 + 1 / w, 1 - 1 / w, w)
+        gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+        warp = torch.stack((gx, gy))[None].expand(B, 2, h, w) + rn(B, 2, h, w, std=0.3)
+        warp[0, :, 0, 0] = torch.tensor([-0.5, 0.5])        # w = 12: ix = 2.5 exactly (tie -> 2); h = 12: iy = 8.5 (tie -> 8)
+        warp[0, :, 0, 1] = torch.tensor([1.0 - 1.0 / w, -1.0 + 1.0 / h])  # exact pixel centre
+        warp[0, :, 0, 2] = torch.tensor([-1.9, 0.1])        # far outside
+        warp[1, :, 1, 1] = torch.tensor([0.0, 0.0])         # ix = (w - 1) / 2: a tie for even w
+        corr = local_correlation(f0, f1, r, warp, use_custom_corr=False, sample_mode="nearest")
+        out[name + "_f0"], out[name + "_f1"], out[name + "_warp"], out[name + "_corr"] = map(np32, (f0, f1, warp, corr))
+    np.savez_compressed(os.path.join(GOLD, "ops_nearest_reference.npz"), **out)
+    print("ops_nearest:", {k: v.shape for k, v in out.items()})
 
 
 def _run_reference(cfg_name, coarse, up, B, symmetric, upsample_preds, seed_w, seed_in, capture=True):
@@ -262,6 +292,34 @@ def keypoints_golden():
     np.savez_compressed(os.path.join(GOLD, "keypoints_reference.npz"), **out)
 
 
+def keypoints_ties_golden():
+    """match_keypoints with DUPLICATE keypoints (a detector that reports one location at several scales): the reference's
+    torch.nonzero returns every tied mutual pair (matcher.py:756-762).  Same warp as keypoints_golden; every third
+    keypoint of B and every fifth of A is repeated."""
+    install_stubs()
+    from romatch.models.matcher import RegressionMatcher
+    g = torch.Generator().manual_seed(12)
+    H, W = 96, 128
+    ys, xs = torch.meshgrid(torch.linspace(-1 + 1 / H, 1 - 1 / H, H), torch.linspace(-1 + 1 / W, 1 - 1 / W, W), indexing="ij")
+    bx = 0.9 * xs + 0.08 * torch.sin(3.0 * ys) + 0.03
+    by = 0.85 * ys - 0.06 * torch.cos(2.0 * xs) - 0.02
+    warp = torch.stack([xs, ys, bx, by], dim=-1)
+    cert = torch.sigmoid(4.0 * (1.0 - (xs ** 2 + ys ** 2)))
+    x_A = torch.rand(300, 2, generator=g) * 1.9 - 0.95
+    wA = torch.nn.functional.grid_sample(warp[..., 2:].permute(2, 0, 1)[None], x_A[None, None], align_corners=False)[0, :, 0].mT
+    x_B = torch.cat([wA[:200] + 0.002 * torch.randn(200, 2, generator=g), torch.rand(150, 2, generator=g) * 2 - 1])
+    x_B = torch.cat([x_B, x_B[::3], x_B[::7]])           # duplicates (some points three times)
+    x_B = x_B[torch.randperm(len(x_B), generator=g)]
+    x_A = torch.cat([x_A, x_A[::5]])
+    x_A = x_A[torch.randperm(len(x_A), generator=g)]
+    out = dict(warp=np32(warp), cert=np32(cert), x_A=np32(x_A), x_B=np32(x_B))
+    for name, kw in (("default", {}), ("loose", dict(max_dist=0.02, cert_th=0.6))):
+        iA, iB = RegressionMatcher.match_keypoints(None, x_A, x_B, warp, cert, return_tuple=True, return_inds=True, **kw)
+        out["inds_A_" + name], out["inds_B_" + name] = iA.numpy().astype(np.int64), iB.numpy().astype(np.int64)
+        print(name, len(iA), "pairs,", len(torch.unique(iA)), "distinct A keypoints")
+    np.savez_compressed(os.path.join(GOLD, "keypoints_ties_reference.npz"), **out)
+
+
 def tinyroma_golden():
     """The reference's own TinyRoMa (romatch/models/tiny.py; tiny_roma_v1_model with exact_softmax=False, eval) on seeded
     image pairs, with roma_amd.synthetic.XFeatStandIn in place of the un-vendored XFeat hub model and seeded matcher
@@ -340,4 +398,4 @@ def vis_golden():
 
 if __name__ == "__main__":
     for what in sys.argv[1:]:
-        {"contract": contract, "ops": ops, "tiny": tiny, "small": small, "full": full, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden, "vis": vis_golden, "tinyroma": tinyroma_golden}[what]()
+        {"contract": contract, "ops": ops, "ops_nearest": ops_nearest, "tiny": tiny, "small": small, "full": full, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden, "keypoints_ties": keypoints_ties_golden, "vis": vis_golden, "tinyroma": tinyroma_golden}[what]()
