@@ -47,7 +47,7 @@ def pmc_traffic(kernel):
     # "gemm_kernel<bf16,f32,2,4,4,2,dense>" -> "void roma::gemm_kernel<unsigned short, float, 2, 4, 4, 2, false>"
     base, _, targs = kernel.partition("<")
     targs = targs.rstrip(">").split(",") if targs else []
-    conv = {"bf16": "unsigned short", "f32": "float", "dense": "false", "conv3x3": "true"}
+    conv = {"bf16": "unsigned short", "f16": "unsigned short", "f32": "float", "dense": "false", "conv3x3": "true"}
     want = "void roma::" + base + ("<" + ", ".join(conv.get(t, t) for t in targs) + ">" if targs else "")
     if base == "gemm8p_kernel" and len(targs) == 4:    # profile scope <in,out,form,epilogue> -> <TOUT, CONV, EPI, DMAMF>
         epi = {"none": 0, "relu": 1, "gelu": 2, "res_bf16": 3, "qkv": 4}[targs[3]]
@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the extra legs of the default run: BASELINE configs 2 (coarse-only B = 1) and 5 (f32 B = 8, "
+                         "indoor weights) and the f16 storage mode, each with its own roofline object")
     ap.add_argument("--cpu-baseline-reps", type=int, default=3)
     ap.add_argument("--dry", action="store_true", help="CPU-only launch-logic check: gloo backend, stand-in match()")
     args = ap.parse_args()
@@ -254,26 +257,24 @@ def main():
             dist.destroy_process_group()
         return
 
-    if rank == 0 and world == 1 and not args.no_roofline:
-        # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream (separate instrumented pass)
-        # every kernel is timed owning the chip on the full-batch launch: with --streams 2 the split is switched off for
-        # this pass only
-        lib = model._lib  # the library of this dtype (bf16 / f16 storage builds)
-        model.dual_stream = False
+    def instrumented_pass(mdl, run_step, nprof, two_streams):
+        """roofline of the dominant kernel + the per-kernel table: per-launch HIP events on the launch stream in a separate
+        instrumented pass.  Every kernel is timed owning the chip on the full-batch launch: the sub-batch stream split is
+        switched off for this pass only."""
+        lib = mdl._lib  # the library of this dtype (bf16 / f16 storage builds)
+        mdl.dual_stream = False
         lib.roma_profile_enable(1)
-        nprof = max(1, min(3, args.steps))
         for _ in range(nprof):
-            step()
+            run_step()
         torch.cuda.synchronize()
-        model.dual_stream = args.streams == 2
+        mdl.dual_stream = two_streams
         n = lib.roma_profile_report(None, 0)
         buf = C.create_string_buffer(int(n))
         lib.roma_profile_report(buf, n)
         lib.roma_profile_enable(0)
         prof = json.loads(buf.value.decode())
         tot_ms = sum(v["total_ms"] for v in prof.values())
-        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-        name, v = dom
+        name, v = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
         if v["unit"] == "flop":
             ach = v["work"] / (v["total_ms"] * 1e-3) / 1e12
             head = name.split(",")[0]  # "gemm6p_kernel<bf16", "attn_f32_kernel<64>", ...: the INPUT type names the MFMA rate
@@ -286,16 +287,47 @@ def main():
         roof.update({"traffic": traffic,
                      "traffic_source": (f"{src}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench "
                                         "(tools/pmc_round.sh), not measured in this run") if src else None,
+                     "work_counted": "algorithmic: un-padded M, N, K of the reference's layer (the padded channels of the "
+                                     "refiner buffers are not counted)" if v["unit"] == "flop" else "algorithmic bytes (DESIGN.md section 4)",
                      "launches_per_step": v["calls"] / nprof, "avg_launch_ms": v["total_ms"] / v["calls"],
                      "share_of_instrumented_time": v["total_ms"] / tot_ms})
-        if args.streams == 2:
+        if two_streams:
             roof["mode"] = ("instrumented pass with the sub-batch stream split off: full-batch launches, one kernel on the "
                             "chip at a time; the timed region overlaps two half-batch streams")
-        result["roofline"] = roof
-        result["kernels"] = {k: {"ms_per_step": x["total_ms"] / nprof, "calls_per_step": x["calls"] / nprof,
-                                 ("TFLOP/s" if x["unit"] == "flop" else "GB/s"):
-                                     x["work"] / (x["total_ms"] * 1e-3) / (1e12 if x["unit"] == "flop" else 1e9)}
-                             for k, x in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+        kernels = {k: {"ms_per_step": x["total_ms"] / nprof, "calls_per_step": x["calls"] / nprof,
+                       ("TFLOP/s" if x["unit"] == "flop" else "GB/s"):
+                           x["work"] / (x["total_ms"] * 1e-3) / (1e12 if x["unit"] == "flop" else 1e9)}
+                   for k, x in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+        return roof, kernels
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        result["roofline"], result["kernels"] = instrumented_pass(model, step, max(1, min(3, args.steps)), args.streams == 2)
+        if full and args.dtype != "f32":
+            # ---- the regime a TRAINED matcher produces: smooth (coherent) warps.  The random-weight benchmark model's coarse
+            # matches are incoherent (neighbouring tokens point ~12 of 40 tokens apart), which sends every local-correlation
+            # tile to the gather work list.  Here a smooth coarse match (identity + a low-frequency displacement) is injected
+            # behind cls_to_flow_refine (roma_debug_inject) and the same instrumented pass is repeated: the local-correlation
+            # and grid-sample-warp kernels below then run on the warps they were designed for.
+            import numpy as np
+            T = (args.coarse // 14) ** 2
+            th = args.coarse // 14
+            ys, xs = np.meshgrid(np.linspace(-1 + 1 / th, 1 - 1 / th, th), np.linspace(-1 + 1 / th, 1 - 1 / th, th), indexing="ij")
+            gx = 0.92 * xs + 0.05 * np.sin(2.5 * ys) + 0.02
+            gy = 0.95 * ys - 0.04 * np.cos(2.0 * xs) - 0.01
+            flow = np.stack([gx, gy], -1).reshape(1, T, 2).astype(np.float32).repeat(2 * args.batch, 0)
+            model.debug = True
+            model.debug_inject("gm_flow16", flow)
+            model.debug_inject("gm_cert16", np.full((2 * args.batch, T, 1), 2.0, np.float32))
+            try:
+                _, kc = instrumented_pass(model, step, 1, args.streams == 2)
+            finally:
+                model.debug = False
+                model.debug_inject("gm_flow16", None)
+                model.debug_inject("gm_cert16", None)
+            result["kernels_coherent"] = {
+                "what": "one instrumented match() with a smooth coarse match injected (identity + low-frequency displacement): "
+                        "the warp regime of a trained matcher; only the warp-dependent kernels are listed",
+                "kernels": {k: v for k, v in kc.items() if k.startswith("local_corr") or k.startswith("refiner_input")}}
 
     if rank == 0 and not args.no_parity:
         # ---- parity of the timed configuration (rank 0's shard = seeds 0 / 1) against the reference's own output
@@ -333,6 +365,63 @@ def main():
         else:
             result["parity"] = None
 
+    default_run = full and args.dtype == "bf16" and args.coarse == 560 and args.upsample == 864 and args.batch == 8
+    if rank == 0 and world == 1 and default_run and not args.no_other_configs:
+        # ---- the other single-GPU configurations of BASELINE.json, as nested objects of the same JSON line (they are NOT
+        # the metric): each builds its own handle, is timed like the main loop (synchronise / K steps / synchronise) and
+        # gets its own instrumented pass.
+        import numpy as np
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import parity_metrics as PM
+
+        def side_config(dtype, is_full, batch, steps, warmup, seed_w, seed_in, golden):
+            amp_ = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype]
+            sd_, dsd_ = (sd, dsd) if seed_w == 0 else (synthetic.make_matcher_state_dict(seed_w), synthetic.make_dinov2_state_dict(seed_w))
+            m_ = roma_outdoor(device=dev, weights=sd_, dinov2_weights=dsd_, coarse_res=560, upsample_res=864, amp_dtype=amp_,
+                              symmetric=True, upsample_preds=is_full, max_batch=batch)
+            i_ = {k: v.to(dev) for k, v in synthetic.make_inputs(batch, 560, 864 if is_full else None, seed=seed_in).items()}
+            kw_ = dict(im_A_high_res=i_["im_A_high_res"], im_B_high_res=i_["im_B_high_res"]) if is_full else {}
+            run = lambda: m_.match(i_["im_A"], i_["im_B"], **kw_)  # noqa: E731
+            for _ in range(max(1, warmup)):
+                run()
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(steps):
+                out_ = run()
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t_
+            r_ = {"value": batch * steps / dt_, "unit": "image-pairs/s", "ms_per_step": 1e3 * dt_ / steps, "steps": steps,
+                  "dtype": dtype, "batch": batch, "workload": "560 -> 864 full" if is_full else "560 coarse-only"}
+            r_["roofline"], kern = instrumented_pass(m_, run, 1, batch >= 2)
+            r_["kernels_top5"] = dict(list(kern.items())[:5])
+            gpath = os.path.join(ROOT, "tests", "golden", golden)
+            if os.path.exists(gpath):
+                g_ = np.load(gpath)
+                if dtype == "f32":
+                    r_["parity"] = {"golden": "tests/golden/" + golden, "tolerance": 1e-3,
+                                    "outputs": PM.output_errors(out_[0].cpu().numpy()[:, ::8, ::8], out_[1].cpu().numpy()[:, ::8, ::8],
+                                                                g_["warp_sub"], g_["cert_sub"], tol=1e-3)}
+                else:
+                    m_.debug = True
+                    m_.debug_inject("gm_flow16", PM.nchw_to_tokens(g_["gm_flow16"]))
+                    m_.debug_inject("gm_cert16", PM.nchw_to_tokens(g_["gm_cert16"]))
+                    wi, ci = run()
+                    torch.cuda.synchronize()
+                    m_.debug = False
+                    m_.debug_inject("gm_flow16", None)
+                    m_.debug_inject("gm_cert16", None)
+                    r_["parity"] = {"golden": "tests/golden/" + golden, "outputs_with_reference_coarse_match_injected":
+                                    PM.output_errors(wi.cpu().numpy()[:, ::8, ::8], ci.cpu().numpy()[:, ::8, ::8], g_["warp_sub"], g_["cert_sub"])}
+            del m_
+            torch.cuda.empty_cache()
+            return r_
+
+        result["other_configs"] = {
+            "config2_coarse_only_b1_bf16": side_config("bf16", False, 1, 30, 5, 0, 1, "match_full_coarse.npz"),
+            "config5_indoor_f32_b8": side_config("f32", True, 8, 3, 1, 2, 3, "match_full8_indoor.npz"),
+            "f16_storage_b8 (the reference's default amp_dtype)": side_config("f16", True, 8, 10, 3, 0, 1, "match_full8.npz"),
+        }
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle (CPU restatement of the reference; the reference itself is not on the GPU box) on
         # the host cores, ONE symmetric pair of the same workload per call: 1 warm-up + N timed calls, median
@@ -343,11 +432,21 @@ def main():
         times = []
         for i in range(1 + max(1, args.cpu_baseline_reps)):
             t0 = time.perf_counter()
-            roma_oracle.match(cin["im_A"], cin["im_B"], sd, dsd, cin.get("im_A_high_res"), cin.get("im_B_high_res"), **ckw)
+            cpu_out = roma_oracle.match(cin["im_A"], cin["im_B"], sd, dsd, cin.get("im_A_high_res"), cin.get("im_B_high_res"), **ckw)
             if i > 0:
                 times.append(time.perf_counter() - t0)
         med = statistics.median(times)
+        checked = None
+        gold1 = os.path.join(ROOT, "tests", "golden", "match_full.npz" if full else "match_full_coarse.npz")
+        if args.coarse == 560 and (not full or args.upsample == 864) and os.path.exists(gold1):
+            # the timed CPU leg is also a checked one: same seeds as the reference-generated golden (weights 0, inputs 1)
+            import numpy as np
+            g1 = np.load(gold1)
+            checked = {"golden": os.path.relpath(gold1, ROOT),
+                       "max_abs_warp": float(np.abs(cpu_out[0].numpy()[:, ::8, ::8] - g1["warp_sub"]).max()),
+                       "max_abs_certainty": float(np.abs(cpu_out[1].numpy()[:, ::8, ::8] - g1["cert_sub"]).max())}
         result["cpu_baseline"] = {"value": 1.0 / med, "unit": "image-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "checked_against_reference_golden": checked,
                                   "sample": f"1 symmetric pair {what}, fp32, torch CPU oracle: 1 warm-up + {len(times)} timed calls, "
                                             f"median {med:.1f} s (all: {', '.join(f'{t:.1f}' for t in times)})",
                                   "host_cores_available": os.cpu_count()}

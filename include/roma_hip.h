@@ -33,8 +33,8 @@ int roma_h16_format(void);
 enum { ROMA_ERR_ARG = -1, ROMA_ERR_HIP = -2, ROMA_ERR_STATE = -3 };
 
 typedef struct {
-  int coarse_h, coarse_w;     /* multiples of 14 (DINOv2 patch) and of 8 (VGG pyramid)            */
-  int upsample_h, upsample_w; /* multiples of 8; used when upsample_preds != 0                     */
+  int coarse_h, coarse_w;     /* multiples of 14 (DINOv2 patch; roma_models.py:58-59), e.g. 560, 518, 672 */
+  int upsample_h, upsample_w; /* any size >= 16 (0 = no upsample pass); used when upsample_preds != 0 */
   int symmetric;              /* matcher.py:801   */
   int upsample_preds;         /* matcher.py:836   */
   int attenuate_cert;         /* matcher.py:839   */
@@ -194,9 +194,21 @@ int roma_op_multinomial(const float* weights, long n, long k, unsigned long long
  * All tensors f32, channels-last unless noted.  corr_volume (tiny.py:182-196) = roma_op_gemm with A = feats of image B
  * [H1*W1, C], W = feats of image A [H0*W0, C], alpha = 1/sqrt(C), batch = pairs: cv [B, H1*W1, H0*W0]. */
 int roma_op_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, void* stream);
-/* pos_embed, inference path (tiny.py:114-142 with exact_softmax = False): out [B, H0*W0, 2] = soft arg-max over the
- * 4x-subsampled correlation column plus the arg-max position (H1, W1 multiples of 4). */
-int roma_op_tiny_pos_embed(const float* corr_volume, float* out, int B, int H1, int W1, int H0, int W0, void* stream);
+/* pos_embed (tiny.py:114-142): out [B, H0*W0, 2].  exact_softmax = 0: the inference path, soft arg-max over the
+ * 4x-subsampled correlation column plus the arg-max position (H1, W1 multiples of 4); 1: the exact_softmax=True branch
+ * (tiny.py:139-141), the softmax over all H1 x W1 positions. */
+int roma_op_tiny_pos_embed(const float* corr_volume, float* out, int B, int H1, int W1, int H0, int W0, int exact_softmax,
+                           void* stream);
+/* TinyRoMa.forward_single (tiny.py:81-99) - the caller's XFeat network, replayed layer by layer, channels-last f32:
+ * gray_instnorm: out [B,H,W,1] = InstanceNorm2d(1)(mean over the C channels of in [B,H,W,C]) (no affine, biased variance);
+ * conv2d_nhwc: out [B,Ho,Wo,Cout] = act(conv(in [B,H,W,Cin], w [K*K*Cin][Cout] (tap-major, BatchNorm folded)) + bias) + res;
+ *   K 1 or 3, stride 1 or 2, padding 0 or 1, Cout % 4 == 0; bias, res may be NULL;  avgpool_nhwc: AvgPool2d(k, k);
+ * add3: out = a + b (+ c, may be NULL).  The bilinear resizes are roma_op_resize_bilinear. */
+int roma_op_gray_instnorm(const float* in, float* out, int B, int H, int W, int C, float eps, void* stream);
+int roma_op_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* res, float* out, int B, int H, int W,
+                        int Cin, int Cout, int K, int stride, int pad, int relu, void* stream);
+int roma_op_avgpool_nhwc(const float* in, float* out, int B, int H, int W, int C, int k, void* stream);
+int roma_op_add3(const float* a, const float* b, const float* c, float* out, long n, void* stream);
 /* d[B,H,W,Cp] = cat(f0 [B,H,W,C], grid_sample(f1 [B,H1,W1,C], warp[..., 0:2]), warp[..., 0:2], zero pad)  (tiny.py:290-291,
  * 298-299; bilinear, zeros padding, align_corners=False); warp has warp_channels >= 2 channels per pixel. */
 int roma_op_tiny_matcher_input(const float* f0, const float* f1, const float* warp, int warp_channels, float* d, int B, int H,

@@ -39,8 +39,9 @@ def corr_volume(feat0, feat1):
     return torch.einsum("bci,bcj->bji", feat0.reshape(B, C, H0 * W0), feat1.reshape(B, C, H1 * W1)).reshape(B, H1, W1, H0, W0) / math.sqrt(C)
 
 
-def pos_embed(cv):
-    """tiny.py:114-142, the inference branch (not training, exact_softmax False): low-resolution softmax plus the arg-max
+def pos_embed(cv, exact_softmax=False):
+    """tiny.py:114-142.  exact_softmax=True (:139-141): softmax over every position of image B, expectation of the grid.
+    Default = the inference branch (not training, exact_softmax False): low-resolution softmax plus the arg-max
     entry.  Note tiny.py:134 concatenates the arg-max INDEX tensor, so the last logit is the index value itself.
 
     Batch semantics: tiny.py:137 multiplies P_lowres[:, -1] ([B, H0, W0]) with grid[best_match].permute(0, 3, 1, 2)
@@ -49,10 +50,13 @@ def pos_embed(cv):
     (match_from_path / PIL inputs, demo/demo_match_tiny.py); pairs are treated independently here, i.e. every pair gets the
     reference's B = 1 result."""
     if cv.shape[0] > 1:
-        return torch.cat([pos_embed(cv[b:b + 1]) for b in range(cv.shape[0])], dim=0)
+        return torch.cat([pos_embed(cv[b:b + 1], exact_softmax) for b in range(cv.shape[0])], dim=0)
     B, H1, W1, H0, W0 = cv.shape
     grid = torch.stack(torch.meshgrid(torch.linspace(-1 + 1 / W1, 1 - 1 / W1, W1), torch.linspace(-1 + 1 / H1, 1 - 1 / H1, H1),
                                       indexing="xy"), dim=-1).float().reshape(H1 * W1, 2)
+    if exact_softmax:
+        P = cv.reshape(B, H1 * W1, H0, W0).softmax(dim=1)
+        return torch.einsum("bchw,cd->bdhw", P, grid)
     down = 4
     grid_lr = torch.stack(torch.meshgrid(torch.linspace(-1 + down / W1, 1 - down / W1, W1 // down),
                                          torch.linspace(-1 + down / H1, 1 - down / H1, H1 // down), indexing="xy"),
@@ -73,11 +77,11 @@ def matcher(x, sd, name):
     return F.conv2d(x, sd[f"{name}.4.weight"], sd[f"{name}.4.bias"])
 
 
-def forward_from_features(f0_f, f0_c, f1_f, f1_c, sd, H1, W1):
+def forward_from_features(f0_f, f0_c, f1_f, f1_c, sd, H1, W1, exact_softmax=False):
     """tiny.py:278-303 after forward_single; (H1, W1) = the pre-processed size of image B.  Returns {8: ..., 4: ...}."""
     to_normalized = torch.tensor((2 / W1, 2 / H1, 1.0))[None, :, None, None]
     cv = corr_volume(f0_c, f1_c)
-    coarse_warp = pos_embed(cv)
+    coarse_warp = pos_embed(cv, exact_softmax)
     coarse_matches = torch.cat((coarse_warp, torch.zeros_like(coarse_warp[:, -1:])), dim=1)
     f1c_w = F.grid_sample(f1_c, coarse_matches.permute(0, 2, 3, 1)[..., :2], mode="bilinear", align_corners=False)
     delta = matcher(torch.cat((f0_c, f1c_w, coarse_warp), dim=1), sd, "coarse_matcher")
@@ -91,12 +95,12 @@ def forward_from_features(f0_f, f0_c, f1_f, f1_c, sd, H1, W1):
     return out
 
 
-def forward(im0, im1, xfeat, sd):
+def forward(im0, im1, xfeat, sd, exact_softmax=False):
     """tiny.py:267-303."""
     im0, im1 = preprocess_tensor(im0), preprocess_tensor(im1)
     f0_f, f0_c = forward_single(xfeat, im0)
     f1_f, f1_c = forward_single(xfeat, im1)
-    return forward_from_features(f0_f, f0_c, f1_f, f1_c, sd, im1.shape[-2], im1.shape[-1])
+    return forward_from_features(f0_f, f0_c, f1_f, f1_c, sd, im1.shape[-2], im1.shape[-1], exact_softmax)
 
 
 def finish_match(corresps, H0, W0):
@@ -109,7 +113,7 @@ def finish_match(corresps, H0, W0):
     return torch.cat((grid, flow), dim=-1), cert[:, 0].sigmoid()
 
 
-def match(im0, im1, xfeat, sd):
+def match(im0, im1, xfeat, sd, exact_softmax=False):
     """TinyRoMa.match for batched tensors (tiny.py:205-242)."""
     with torch.no_grad():
-        return finish_match(forward(im0, im1, xfeat, sd), im0.shape[-2], im0.shape[-1])
+        return finish_match(forward(im0, im1, xfeat, sd, exact_softmax), im0.shape[-2], im0.shape[-1])

@@ -72,7 +72,11 @@ SIGNATURES = {
     "roma_op_multinomial_workspace": (_l, [_l, _l]),
     "roma_op_multinomial": (_i, [_vp, _l, _l, C.c_ulonglong, _vp, _vp, _l, _vp]),
     "roma_op_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "roma_op_tiny_pos_embed": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "roma_op_tiny_pos_embed": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "roma_op_gray_instnorm": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "roma_op_conv2d_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "roma_op_avgpool_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "roma_op_add3": (_i, [_vp, _vp, _vp, _vp, _l, _vp]),
     "roma_op_tiny_matcher_input": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "roma_op_tiny_update": (_i, [_vp, _i, _vp, _l, _f, _f, _vp, _l, _vp]),
     "roma_op_tiny_final": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -79,9 +79,11 @@ int roma_create(const roma_config_t* cfg, roma_handle_t* out) {
   ROMA_REQUIRE(cfg && out, "roma_create: null argument");
   ROMA_REQUIRE(cfg->coarse_h > 0 && cfg->coarse_w > 0 && cfg->coarse_h % 14 == 0 && cfg->coarse_w % 14 == 0,
                "Needs to be multiple of 14 for backbone");  // roma_models.py:58-59
-  ROMA_REQUIRE(cfg->coarse_h % 8 == 0 && cfg->coarse_w % 8 == 0, "roma_create: coarse resolution must be a multiple of 8 (VGG pyramid)");
-  ROMA_REQUIRE(cfg->upsample_h % 8 == 0 && cfg->upsample_w % 8 == 0 && cfg->upsample_h >= 0,
-               "roma_create: upsample resolution must be a multiple of 8");
+  // no multiple-of-8 requirement (the reference has none either, e.g. 518 / 574 / 602): the VGG pyramid takes the
+  // floor-divided sizes of its 2x2 max-pools and every decoder resize goes to those sizes (model.hip)
+  ROMA_REQUIRE(cfg->coarse_h >= 16 && cfg->coarse_w >= 16, "roma_create: coarse resolution too small for the stride-16 pyramid");
+  ROMA_REQUIRE(cfg->upsample_h >= 0 && cfg->upsample_w >= 0 && (cfg->upsample_h == 0 || (cfg->upsample_h >= 16 && cfg->upsample_w >= 16)),
+               "roma_create: bad upsample resolution");
   ROMA_REQUIRE(cfg->max_batch >= 1, "roma_create: max_batch must be >= 1");
   if (dt_code(cfg->precision) < 0) return ROMA_ERR_ARG;  // ROMA_F32 or this build's 16-bit format
   int ndev = 0;
@@ -413,8 +415,22 @@ int roma_op_multinomial(const float* weights, long n, long k, unsigned long long
 int roma_op_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, void* stream) {
   return nchw_to_nhwc_launch(in, out, B, C, H, W, S(stream));
 }
-int roma_op_tiny_pos_embed(const float* corr_volume, float* out, int B, int H1, int W1, int H0, int W0, void* stream) {
-  return tiny_pos_embed_launch(corr_volume, out, B, H1, W1, H0, W0, S(stream));
+int roma_op_tiny_pos_embed(const float* corr_volume, float* out, int B, int H1, int W1, int H0, int W0, int exact_softmax,
+                           void* stream) {
+  return tiny_pos_embed_launch(corr_volume, out, B, H1, W1, H0, W0, exact_softmax, S(stream));
+}
+int roma_op_gray_instnorm(const float* in, float* out, int B, int H, int W, int C, float eps, void* stream) {
+  return gray_instnorm_launch(in, out, B, H, W, C, eps, S(stream));
+}
+int roma_op_conv2d_nhwc(const float* in, const float* w, const float* bias, const float* res, float* out, int B, int H, int W,
+                        int Cin, int Cout, int K, int stride, int pad, int relu, void* stream) {
+  return conv2d_nhwc_launch(in, w, bias, res, out, B, H, W, Cin, Cout, K, stride, pad, relu, S(stream));
+}
+int roma_op_avgpool_nhwc(const float* in, float* out, int B, int H, int W, int C, int k, void* stream) {
+  return avgpool_nhwc_launch(in, out, B, H, W, C, k, S(stream));
+}
+int roma_op_add3(const float* a, const float* b, const float* c, float* out, long n, void* stream) {
+  return add3_launch(a, b, c, out, n, S(stream));
 }
 int roma_op_tiny_matcher_input(const float* f0, const float* f1, const float* warp, int warp_channels, float* d, int B, int H,
                                int W, int H1, int W1, int C, int Cp, void* stream) {

@@ -44,6 +44,10 @@ struct GemmArgs {
   long sNx = 0, sNy = 0;
   float inv_t = 0.f, diag_add = 0.f;
   int m_alg = 0;  // set by gemm_launch with qkv_pad: the caller's (algorithmic) M, for the FLOP count of the profile scope
+  // un-padded problem width / depth for the FLOP count of the profile scope (0 = N / K): the refiner 1x1 convolutions run
+  // on channel counts padded to whole 128-byte rows (1137 -> 1152, 569 -> 576, 1377 -> 1408); the roofline figure counts
+  // the reference's channels, not the zero padding
+  int n_alg = 0, k_alg = 0;
   int dbg = 0;  // tuning experiments only (ROMA_GEMM_DBG): 1 = skip output stores, 2 = skip the K loop
 };
 

@@ -518,7 +518,8 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   snprintf(pname, sizeof pname, "gemm_kernel<%s,%s,%d,%d,%d,%d,%s>", sizeof(TIN) == 4 ? "f32" : ROMA_H16_NAME,
            sizeof(TOUT) == 4 ? "f32" : ROMA_H16_NAME, WM, WN, TM, TN, CONV ? "conv3x3" : "dense");
   // algorithmic FLOPs: the caller's M (a.M may have been padded to npad tokens per image for the QKV epilogue)
-  ProfScope ps(pname, 2.0 * (double)(a.m_alg > 0 ? a.m_alg : a.M) * a.N * a.K * a.batch * (a.lower_only ? 0.5 : 1.0), "flop", stream);
+  ProfScope ps(pname, 2.0 * (double)(a.m_alg > 0 ? a.m_alg : a.M) * (a.n_alg > 0 ? a.n_alg : a.N) * (a.k_alg > 0 ? a.k_alg : a.K) * a.batch *
+                          (a.lower_only ? 0.5 : 1.0), "flop", stream);
   // the > 64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: one flag per device ordinal
   static bool attr_set[64] = {false};
   int dev = 0;

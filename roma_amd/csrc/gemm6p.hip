@@ -266,7 +266,7 @@ static int launch6p(const GemmArgs& a, hipStream_t stream, const char* epi_name)
   const long gx = std::min<long>(((nblk + 7) / 8) * 8, 256);
   char pname[96];
   snprintf(pname, sizeof pname, "gemm6p_kernel<" ROMA_H16_NAME ",%s,dense,%s>", sizeof(TOUT) == 4 ? "f32" : ROMA_H16_NAME, epi_name);
-  ProfScope ps(pname, 2.0 * (double)a.M * a.N * a.K, "flop", stream);
+  ProfScope ps(pname, 2.0 * (double)a.M * (a.n_alg > 0 ? a.n_alg : a.N) * (a.k_alg > 0 ? a.k_alg : a.K), "flop", stream);  // un-padded channels
   static bool attr_set[64] = {false};
   int dev = 0;
   ROMA_CHECK_HIP(hipGetDevice(&dev));

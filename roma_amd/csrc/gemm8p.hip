@@ -426,7 +426,7 @@ static int launch8p(const GemmArgs& a, hipStream_t stream, const char* epi_name)
   const long gx = std::min<long>(((nblk + 7) / 8) * 8, 256);
   char pname[96];
   snprintf(pname, sizeof pname, "gemm8p_kernel<" ROMA_H16_NAME ",%s,%s,%s>", sizeof(TOUT) == 4 ? "f32" : ROMA_H16_NAME, CONV ? "conv3x3" : "dense", epi_name);
-  ProfScope ps(pname, 2.0 * (double)(a.m_alg > 0 ? a.m_alg : a.M) * a.N * a.K, "flop", stream);
+  ProfScope ps(pname, 2.0 * (double)(a.m_alg > 0 ? a.m_alg : a.M) * (a.n_alg > 0 ? a.n_alg : a.N) * (a.k_alg > 0 ? a.k_alg : a.K), "flop", stream);
   static bool attr_set[64] = {false};
   int dev = 0;
   ROMA_CHECK_HIP(hipGetDevice(&dev));

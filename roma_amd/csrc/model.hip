@@ -815,7 +815,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         RUN(im2col3x3_c3_launch(imB, off(col1, (long)B * H * W * 32), B, H, W, act_dt, st));
         GemmArgs g;
         g.A = col1; g.lda = 32; g.W = vgg[0].w; g.ldw = vgg[0].ldw; g.C = t0; g.ldc = 64;
-        g.M = nimg * H * W; g.N = 64; g.K = 32; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = vgg[0].b; g.act = ACT_RELU;
+        g.M = nimg * H * W; g.N = 64; g.K = 32; g.k_alg = 27; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = vgg[0].b; g.act = ACT_RELU;
         RUN(gemm_launch(g, st));
       }
       auto conv = [&](int li, const void* in, void* out, int h, int w) -> int {
@@ -870,7 +870,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       {
         GemmArgs g;
         g.A = col; g.lda = patch.ldw; g.W = patch.w; g.ldw = patch.ldw; g.C = pt; g.ldc = 1024;
-        g.M = nimg * T; g.N = 1024; g.K = patch.ldw; g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = patch.b;
+        g.M = nimg * T; g.N = 1024; g.K = patch.ldw; g.k_alg = 588; g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = patch.b;
         RUN(gemm_launch(g, st));
       }
       RUN(assemble_tokens_launch(pt, cls_tok, pos_emb, x, nimg, T, 1024, st));
@@ -1022,6 +1022,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           GemmArgs g;
           g.A = dalt; g.lda = r.Cp; g.W = r.pw[b].w; g.ldw = r.pw[b].ldw; g.C = dcur; g.ldc = r.Cp;
           g.M = (int)M; g.N = r.Cp; g.K = r.Cp; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = r.pw[b].b;
+          g.n_alg = g.k_alg = r.C;  // FLOPs of the reference's C x C convolution, not of the padded one
           RUN(gemm_launch(g, st));
           if (int rc = CK(tp + "_blk" + std::to_string(b), dcur, (size_t)M * r.Cp * esz)) return rc;
         }

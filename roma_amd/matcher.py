@@ -11,6 +11,7 @@ non-GPU device raises.
 from __future__ import annotations
 
 import ctypes as C
+from collections import OrderedDict
 import math
 import os
 from typing import Optional, Union
@@ -68,6 +69,8 @@ def _pil_to_normalised(im, hw):
 class RegressionMatcher:
     """Drop-in for romatch.models.matcher.RegressionMatcher (inference surface)."""
 
+    HANDLE_CACHE = 2  # library handles (resolution configurations) kept alive per matcher
+
     def __init__(self, weights, dinov2_weights, h=560, w=560, sample_mode="threshold_balanced", upsample_preds=False,
                  symmetric=False, sample_thresh=0.05, name=None, attenuate_cert=None, upsample_res=None,
                  device=None, amp_dtype=torch.float16, max_batch=8):
@@ -107,6 +110,10 @@ class RegressionMatcher:
         self._dinov2_weights = dinov2_weights
         self._handle = None
         self._built = None
+        # a call whose tensors have another resolution than the configured one needs its own handle (weights re-packed,
+        # workspace re-planned: ~1.3 GB of uploads).  The last HANDLE_CACHE configurations are kept, so alternating
+        # between two resolutions (e.g. landscape / portrait inputs) rebuilds nothing.
+        self._cache = OrderedDict()
         self._ensure_handle()
 
     # ------------------------------------------------------------------ handle management
@@ -124,11 +131,16 @@ class RegressionMatcher:
             return
         if (self._handle is not None and key[2] == (0, 0) and self._built[:2] + self._built[3:] == key[:2] + key[3:]):
             return  # upsample_preds switched off: the handle planned for the upsample pass also runs coarse-only
-        self._release()
+        if key in self._cache:  # a configuration used before: switch, no rebuild
+            self._cache.move_to_end(key)
+            self._handle, self._built = self._cache[key], key
+            return
+        while len(self._cache) >= self.HANDLE_CACHE:  # evict the least recently used handle
+            _, old = self._cache.popitem(last=False)
+            self._lib.roma_destroy(old)
+        self._handle = self._built = None
         lib = self._lib
         uh, uw = key[2]
-        if uh % 8 or uw % 8:
-            raise ValueError("upsample_res must be a multiple of 8 (VGG19 feature pyramid)")
         cfg = _lib.RomaConfig(key[0], key[1], uh, uw, int(bool(self.symmetric)), int(bool(self.upsample_preds)),
                               int(bool(self.attenuate_cert)), key[3], self.max_batch, self.device.index)
         h = C.c_void_p()
@@ -149,11 +161,14 @@ class RegressionMatcher:
             raise
         self._handle = h
         self._built = key
+        self._cache[key] = h
 
     def _release(self):
-        if getattr(self, "_handle", None) is not None:
-            self._lib.roma_destroy(self._handle)
-            self._handle = None
+        for h in getattr(self, "_cache", {}).values():
+            self._lib.roma_destroy(h)
+        if getattr(self, "_cache", None) is not None:
+            self._cache.clear()
+        self._handle = self._built = None
 
     def __del__(self):
         try:

@@ -208,6 +208,53 @@ class XFeatStandIn(torch.nn.Module):
         self.train(False)
 
 
+class XFeatArch(torch.nn.Module):
+    """The layer list of the real XFeat backbone (verlab/accelerated_features modules/model.py, XFeatModel - restated from
+    the published model definition, the hub checkpoint itself is unobtainable offline): every block is a stack of
+    BasicLayer = Conv2d(bias=False) + BatchNorm2d(affine=False) + ReLU (the same BasicLayer as romatch/models/tiny.py:14-28),
+    skip1 = AvgPool2d(4, 4) + Conv2d(1, 24, 1), block_fusion ends in a plain 1 x 1 convolution.  Seeded weights and
+    non-trivial BatchNorm running statistics (numpy PCG64), eval mode.  Exercises everything the device replay of the
+    backbone has to handle: stride-2 and 1 x 1 / padding-0 layers, BatchNorm folding, 1 -> 4 ... 128 -> 128 channels."""
+
+    def __init__(self, seed: int = 0):
+        super().__init__()
+        nn = torch.nn
+
+        class BasicLayer(nn.Module):
+            def __init__(self, cin, cout, kernel_size=3, stride=1, padding=1):
+                super().__init__()
+                self.layer = nn.Sequential(nn.Conv2d(cin, cout, kernel_size, padding=padding, stride=stride, bias=False),
+                                           nn.BatchNorm2d(cout, affine=False), nn.ReLU(inplace=True))
+
+            def forward(self, x):
+                return self.layer(x)
+
+        B = BasicLayer
+        self.norm = nn.InstanceNorm2d(1)
+        self.skip1 = nn.Sequential(nn.AvgPool2d(4, stride=4), nn.Conv2d(1, 24, 1, stride=1, padding=0))
+        self.block1 = nn.Sequential(B(1, 4, stride=1), B(4, 8, stride=2), B(8, 8, stride=1), B(8, 24, stride=2))
+        self.block2 = nn.Sequential(B(24, 24, stride=1), B(24, 24, stride=1))
+        self.block3 = nn.Sequential(B(24, 64, stride=2), B(64, 64, stride=1), B(64, 64, 1, padding=0))
+        self.block4 = nn.Sequential(B(64, 64, stride=2), B(64, 64, stride=1), B(64, 64, stride=1))
+        self.block5 = nn.Sequential(B(64, 128, stride=2), B(128, 128, stride=1), B(128, 128, stride=1), B(128, 64, 1, padding=0))
+        self.block_fusion = nn.Sequential(B(64, 64, stride=1), B(64, 64, stride=1), nn.Conv2d(64, 64, 1, padding=0))
+        self.heatmap_head = nn.Identity()
+        self.keypoint_head = nn.Identity()
+        self.fine_matcher = nn.Identity()
+        rng = _Rng(9300 + seed)
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+                    m.weight.copy_(rng.normal(tuple(m.weight.shape), std=math.sqrt(2.0 / fan_in)))
+                    if m.bias is not None:
+                        m.bias.copy_(rng.normal(tuple(m.bias.shape), std=0.1))
+                elif isinstance(m, nn.BatchNorm2d):
+                    m.running_mean.copy_(rng.normal(tuple(m.running_mean.shape), std=0.2))
+                    m.running_var.copy_(rng.uniform(tuple(m.running_var.shape), 0.5, 1.5))
+        self.train(False)
+
+
 def make_tiny_state_dict(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
     """Matcher weights of TinyRoMa (tiny.py:49-62): 4 x BasicLayer (3x3 conv without bias, BatchNorm affine=False) + a 1x1
     conv with bias, for the coarse (130 -> 256 -> 3) and the fine (50 -> 64 -> 3) matcher; same keys as the reference."""

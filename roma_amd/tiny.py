@@ -42,6 +42,63 @@ def _pack_conv3x3(w: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, cin_p:
     return out.reshape(cout, 9 * cin_p).float().contiguous(), (-mean.double() * inv).float().contiguous()
 
 
+# ---------------------------------------------------------------------------------------------------- backbone compiler
+def _leaves(m):
+    """Leaf modules of a Sequential-like tree in execution order (containers whose forward is "run the children in
+    registration order": nn.Sequential, XFeat's BasicLayer whose only child is a Sequential)."""
+    kids = list(m.children())
+    if not kids:
+        yield m
+        return
+    for k in kids:
+        yield from _leaves(k)
+
+
+def _compile_stack(m, dev):
+    """One XFeat block -> a list of device ops.  Every Conv2d absorbs the BatchNorm2d (running statistics, affine or not)
+    and the ReLU that follow it; weights are re-laid-out to [K*K*Cin][Cout] for roma_op_conv2d_nhwc.  Anything that is
+    not Conv2d / BatchNorm2d / ReLU / AvgPool2d / Identity is refused (no silent fallback to the torch module)."""
+    nn = torch.nn
+    ops = []
+    for leaf in _leaves(m):
+        if isinstance(leaf, nn.Conv2d):
+            k, st, pd = leaf.kernel_size, leaf.stride, leaf.padding
+            if (k[0] != k[1] or k[0] not in (1, 3) or st[0] != st[1] or st[0] not in (1, 2) or pd[0] != pd[1] or pd[0] not in (0, 1)
+                    or leaf.dilation != (1, 1) or leaf.groups != 1 or leaf.padding_mode != "zeros" or leaf.out_channels % 4):
+                raise NotImplementedError(f"TinyRoMa backbone: unsupported convolution {leaf}")
+            w = leaf.weight.detach().double().cpu()
+            b = leaf.bias.detach().double().cpu() if leaf.bias is not None else torch.zeros(leaf.out_channels, dtype=torch.float64)
+            ops.append(dict(op="conv", w=w, b=b, k=k[0], s=st[0], p=pd[0], relu=0, cin=leaf.in_channels, cout=leaf.out_channels))
+        elif isinstance(leaf, nn.BatchNorm2d):
+            if not ops or ops[-1]["op"] != "conv" or ops[-1]["relu"]:
+                raise NotImplementedError("TinyRoMa backbone: BatchNorm2d must directly follow a convolution")
+            inv = torch.rsqrt(leaf.running_var.detach().double().cpu() + leaf.eps)
+            g = leaf.weight.detach().double().cpu() * inv if leaf.affine else inv
+            sh = leaf.bias.detach().double().cpu() if leaf.affine else torch.zeros_like(inv)
+            c = ops[-1]
+            c["w"] = c["w"] * g[:, None, None, None]
+            c["b"] = (c["b"] - leaf.running_mean.detach().double().cpu()) * g + sh
+        elif isinstance(leaf, nn.ReLU):
+            if not ops or ops[-1]["op"] != "conv":
+                raise NotImplementedError("TinyRoMa backbone: ReLU must follow a convolution")
+            ops[-1]["relu"] = 1
+        elif isinstance(leaf, nn.AvgPool2d):
+            k = leaf.kernel_size if isinstance(leaf.kernel_size, int) else leaf.kernel_size[0]
+            st = leaf.stride if isinstance(leaf.stride, int) else leaf.stride[0]
+            if k != st or leaf.padding not in (0, (0, 0)):
+                raise NotImplementedError(f"TinyRoMa backbone: unsupported pooling {leaf}")
+            ops.append(dict(op="avgpool", k=k))
+        elif isinstance(leaf, nn.Identity):
+            continue
+        else:
+            raise NotImplementedError(f"TinyRoMa backbone: no device operator for {type(leaf).__name__}")
+    for c in ops:
+        if c["op"] == "conv":  # [Cout, Cin, K, K] -> [(ky K + kx) Cin + ci][Cout]
+            c["w"] = c["w"].permute(2, 3, 1, 0).reshape(-1, c["cout"]).float().contiguous().to(dev)
+            c["b"] = c["b"].float().contiguous().to(dev)
+    return ops
+
+
 class TinyRoMa:
     """Same constructor arguments and public methods as the reference class (tiny.py:36-66, 101-112, 144-180, 198-265)."""
 
@@ -50,16 +107,20 @@ class TinyRoMa:
         if xfeat is None:
             raise ValueError("TinyRoMa: pass the XFeat backbone as xfeat= (the reference loads it from torch.hub; there is no "
                              "network here)")
-        if exact_softmax:
-            raise NotImplementedError("TinyRoMa(exact_softmax=True): only the inference default (low-resolution softmax, "
-                                      "tiny.py:123-137) is built")
         self._device = torch.device(device)
         if self._device.type != "cuda":
             raise _lib.RomaHipError("roma_amd.TinyRoMa needs a HIP device; there is no CPU fallback")
         for name in ("heatmap_head", "keypoint_head", "fine_matcher"):  # tiny.py:43
             if hasattr(xfeat, name):
                 delattr(xfeat, name)
-        self.xfeat = [xfeat.to(self._device).train(False)]
+        self.xfeat = [xfeat.train(False)]
+        # the backbone runs on the device through roma_op_* (forward_single): the module is walked once, here
+        nrm = getattr(xfeat, "norm", None)
+        if not isinstance(nrm, torch.nn.InstanceNorm2d) or nrm.affine or nrm.track_running_stats or nrm.num_features != 1:
+            raise NotImplementedError("TinyRoMa backbone: xfeat.norm must be InstanceNorm2d(1) (no affine, no running statistics)")
+        self._norm_eps = float(nrm.eps)
+        self._prog = {name: _compile_stack(getattr(xfeat, name), self._device)
+                      for name in ("skip1", "block1", "block2", "block3", "block4", "block5", "block_fusion")}
         self.freeze_xfeat = freeze_xfeat
         self.sample_mode = sample_mode
         self.sample_thresh = 0.05
@@ -86,6 +147,7 @@ class TinyRoMa:
         xs = {k[len("xfeat.0."):]: v for k, v in sd.items() if k.startswith("xfeat.0.")}
         if xs:
             self.xfeat[0].load_state_dict(xs, strict=False)
+            self._prog = {name: _compile_stack(getattr(self.xfeat[0], name), self._device) for name in self._prog}
         dev = self._device
         w = {}
         for name, cin, cin_p in (("coarse_matcher", 130, 160), ("fine_matcher", 50, 64)):
@@ -106,27 +168,88 @@ class TinyRoMa:
     def device(self):
         return self._device
 
-    # ------------------------------------------------------------------ backbone (the caller's torch module, tiny.py:71-99)
+    # ------------------------------------------------------------------ backbone on the device (tiny.py:71-99)
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+
+    def _run_stack(self, name, x, res_last=None):
+        """x [B,H,W,C] channels-last f32 through the compiled layers of xfeat.<name>; `res_last` is added to the output of
+        the last layer (x1 + skip1(x), tiny.py:89)."""
+        lib, dev, stream = self._lib, self._device, self._stream()
+        ops = self._prog[name]
+        for n, o in enumerate(ops):
+            B, H, W, Cc = x.shape
+            if o["op"] == "avgpool":
+                out = torch.empty((B, H // o["k"], W // o["k"], Cc), device=dev, dtype=torch.float32)
+                _lib.check(lib.roma_op_avgpool_nhwc(_P(x), _P(out), B, H, W, Cc, o["k"], stream))
+            else:
+                if Cc != o["cin"]:
+                    raise RuntimeError(f"TinyRoMa backbone: {name} expects {o['cin']} input channels, got {Cc}")
+                Ho, Wo = (H + 2 * o["p"] - o["k"]) // o["s"] + 1, (W + 2 * o["p"] - o["k"]) // o["s"] + 1
+                out = torch.empty((B, Ho, Wo, o["cout"]), device=dev, dtype=torch.float32)
+                res = res_last if n == len(ops) - 1 else None
+                if res is not None and tuple(res.shape) != tuple(out.shape):
+                    raise RuntimeError("TinyRoMa backbone: skip connection and block output differ in shape")
+                _lib.check(lib.roma_op_conv2d_nhwc(_P(x), _P(o["w"]), _P(o["b"]), _P(res), _P(out), B, H, W, Cc, o["cout"], o["k"],
+                                                   o["s"], o["p"], o["relu"], stream))
+            x = out
+        return x
+
+    def _images_nhwc(self, x):
+        """NCHW image batch -> channels-last f32 on the device, resized to multiples of 32 (preprocess_tensor, tiny.py:72-79)."""
+        x = x.detach().to(self._device, torch.float32).contiguous()
+        B, Cc, H, W = x.shape
+        lib, stream = self._lib, self._stream()
+        with torch.cuda.device(self._device):
+            t = torch.empty((B, H, W, Cc), device=self._device, dtype=torch.float32)
+            _lib.check(lib.roma_op_nchw_to_nhwc(_P(x), _P(t), B, Cc, H, W, stream))
+            _H, _W = (H // 32) * 32, (W // 32) * 32
+            if (_H, _W) != (H, W):
+                r = torch.empty((B, _H, _W, Cc), device=self._device, dtype=torch.float32)
+                _lib.check(lib.roma_op_resize_bilinear(_P(t), _P(r), B, H, W, _H, _W, Cc, stream))
+                t = r
+        return t
+
     def preprocess_tensor(self, x):
+        """tiny.py:72-79 (bilinear resize to multiples of 32 on the device); returns (NCHW tensor, rh, rw) like the reference."""
         H, W = x.shape[-2:]
         _H, _W = (H // 32) * 32, (W // 32) * 32
-        rh, rw = H / _H, W / _W
-        return torch.nn.functional.interpolate(x, (_H, _W), mode="bilinear", align_corners=False), rh, rw
+        return self._images_nhwc(x).permute(0, 3, 1, 2), H / _H, W / _W
+
+    def _forward_single_nhwc(self, t):
+        """t [B,H,W,C] channels-last pre-processed images -> (x2 [B,H/4,W/4,24], feats [B,H/8,W/8,64]) channels-last."""
+        lib, dev = self._lib, self._device
+        with torch.cuda.device(dev):
+            stream = self._stream()
+            B, H, W, Cc = t.shape
+            g = torch.empty((B, H, W, 1), device=dev, dtype=torch.float32)
+            _lib.check(lib.roma_op_gray_instnorm(_P(t), _P(g), B, H, W, Cc, self._norm_eps, stream))  # x.mean(1) -> norm
+            x1 = self._run_stack("block1", g)
+            x2 = self._run_stack("block2", self._run_stack("skip1", g, res_last=x1))  # block2(x1 + skip1(x))
+            x3 = self._run_stack("block3", x2)
+            x4 = self._run_stack("block4", x3)
+            x5 = self._run_stack("block5", x4)
+            _, h3, w3, c3 = x3.shape
+            ups = []
+            for xx in (x4, x5):  # F.interpolate(..., mode="bilinear") to x3's size (tiny.py:94-95)
+                u = torch.empty((B, h3, w3, xx.shape[-1]), device=dev, dtype=torch.float32)
+                _lib.check(lib.roma_op_resize_bilinear(_P(xx), _P(u), B, xx.shape[1], xx.shape[2], h3, w3, xx.shape[-1], stream))
+                ups.append(u)
+            sm = torch.empty_like(x3)
+            _lib.check(lib.roma_op_add3(_P(x3), _P(ups[0]), _P(ups[1]), _P(sm), sm.numel(), stream))
+            feats = self._run_stack("block_fusion", sm)
+        return x2, feats
 
     @torch.no_grad()
     def forward_single(self, x):
-        xf = self.xfeat[0]
-        Fn = torch.nn.functional
-        x = x.mean(dim=1, keepdim=True)
-        x = xf.norm(x)
-        x1 = xf.block1(x)
-        x2 = xf.block2(x1 + xf.skip1(x))
-        x3 = xf.block3(x2)
-        x4 = xf.block4(x3)
-        x5 = xf.block5(x4)
-        x4 = Fn.interpolate(x4, (x3.shape[-2], x3.shape[-1]), mode="bilinear")
-        x5 = Fn.interpolate(x5, (x3.shape[-2], x3.shape[-1]), mode="bilinear")
-        return x2, xf.block_fusion(x3 + x4 + x5)
+        """tiny.py:81-99 on the device; x [B,C,H,W] (already pre-processed) -> (x2, feats) as NCHW views."""
+        x = x.detach().to(self._device, torch.float32).contiguous()
+        B, Cc, H, W = x.shape
+        with torch.cuda.device(self._device):
+            t = torch.empty((B, H, W, Cc), device=self._device, dtype=torch.float32)
+            _lib.check(self._lib.roma_op_nchw_to_nhwc(_P(x), _P(t), B, Cc, H, W, self._stream()))
+        x2, feats = self._forward_single_nhwc(t)
+        return x2.permute(0, 3, 1, 2), feats.permute(0, 3, 1, 2)
 
     # ------------------------------------------------------------------ device side
     def _nhwc(self, x, stream):
@@ -156,10 +279,16 @@ class TinyRoMa:
         Returns the reference's `corresps` dict (NCHW tensors)."""
         if self._w is None:
             raise RuntimeError("TinyRoMa: load_state_dict() first")
+        with torch.cuda.device(self._device):
+            stream = C.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
+            a_c, b_c, a_f, b_f = (self._nhwc(t, stream) for t in (f0_c, f1_c, f0_f, f1_f))
+        return self._forward_from_nhwc(a_f, a_c, b_f, b_c, H1, W1)
+
+    def _forward_from_nhwc(self, a_f, a_c, b_f, b_c, H1, W1):
+        """the same on channels-last device tensors (what the on-device backbone produces)"""
         lib, dev = self._lib, self._device
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            a_c, b_c, a_f, b_f = (self._nhwc(t, stream) for t in (f0_c, f1_c, f0_f, f1_f))
             B, Hc, Wc, Cc = a_c.shape
             _, Hc1, Wc1, _ = b_c.shape
             _, Hf, Wf, Cf = a_f.shape
@@ -170,7 +299,7 @@ class TinyRoMa:
             _lib.check(lib.roma_op_gemm(_P(b_c), Cc, _P(a_c), Cc, _P(cv), n0, n1, n0, Cc, B, n1 * Cc, n0 * Cc, n1 * n0, None, None, None,
                                         0, 0, 1.0 / math.sqrt(Cc), F32, F32, stream))
             cw = torch.empty((B, Hc, Wc, 2), device=dev, dtype=torch.float32)
-            _lib.check(lib.roma_op_tiny_pos_embed(_P(cv), _P(cw), B, Hc1, Wc1, Hc, Wc, stream))
+            _lib.check(lib.roma_op_tiny_pos_embed(_P(cv), _P(cw), B, Hc1, Wc1, Hc, Wc, int(bool(self.exact_softmax)), stream))
             # coarse matcher
             cp = self._w["coarse_matcher"]["cin_p"]
             d = torch.empty((B, Hc, Wc, cp), device=dev, dtype=torch.float32)
@@ -194,17 +323,10 @@ class TinyRoMa:
     @torch.no_grad()
     def forward(self, batch):
         """tiny.py:267-303."""
-        im0, im1 = batch["im_A"].to(self._device), batch["im_B"].to(self._device)
-        im0, _, _ = self.preprocess_tensor(im0)
-        im1, _, _ = self.preprocess_tensor(im1)
-        if im0.shape[-2:] == im1.shape[-2:]:
-            xf, xc = self.forward_single(torch.cat([im0, im1], dim=0))
-            f0_c, f1_c = xc.chunk(2)
-            f0_f, f1_f = xf.chunk(2)
-        else:
-            f0_f, f0_c = self.forward_single(im0)
-            f1_f, f1_c = self.forward_single(im1)
-        return self.forward_from_features(f0_f, f0_c, f1_f, f1_c, im1.shape[-2], im1.shape[-1])
+        t0, t1 = self._images_nhwc(batch["im_A"]), self._images_nhwc(batch["im_B"])  # preprocess_tensor (tiny.py:269-270)
+        f0_f, f0_c = self._forward_single_nhwc(t0)
+        f1_f, f1_c = self._forward_single_nhwc(t1)
+        return self._forward_from_nhwc(f0_f, f0_c, f1_f, f1_c, t1.shape[1], t1.shape[2])
 
     def _finish(self, B, H0, W0):
         """tiny.py:222-242 from the channels-last fine matches of the last forward."""

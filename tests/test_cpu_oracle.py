@@ -39,6 +39,18 @@ def test_oracle_ops_vs_reference_golden():
         assert torch.allclose(O.local_correlation(f0, f1, r, warp, sample_mode="nearest"), ref, atol=1e-6), name
 
 
+def test_oracle_match_vs_reference_golden_odd_resolution(weights0):
+    """Multiples of 14 that are not multiples of 8 (floor-divided VGG pyramid): oracle == unmodified reference."""
+    from oracle import roma_oracle as O
+    from roma_amd import synthetic
+    sd, dsd = weights0
+    g = np.load(os.path.join(GOLDEN, "match_odd.npz"))
+    inp = synthetic.make_inputs(1, (126, 154), (182, 198), seed=5)
+    w, c = O.match(inp["im_A"], inp["im_B"], sd, dsd, inp["im_A_high_res"], inp["im_B_high_res"])
+    assert float((w - torch.from_numpy(g["warp"])).abs().max()) == 0.0
+    assert float((c - torch.from_numpy(g["certainty"])).abs().max()) == 0.0
+
+
 def test_oracle_match_vs_reference_golden_tiny(weights0):
     """Full match() of the oracle == the unmodified reference's output (112 -> 168, symmetric)."""
     from oracle import roma_oracle as O
@@ -170,6 +182,25 @@ def test_tiny_oracle_vs_reference_golden():
             assert torch.equal(cor[lvl]["flow"], torch.from_numpy(g[f"{tag}_flow{lvl}"])), (tag, lvl)
             assert torch.equal(cor[lvl]["certainty"], torch.from_numpy(g[f"{tag}_cert{lvl}"])), (tag, lvl)
         w, c = T.match(a, b, xf, sd)
+        assert float((w - torch.from_numpy(g[tag + "_warp"])).abs().max()) < 1e-5
+        assert float((c - torch.from_numpy(g[tag + "_cert"])).abs().max()) < 1e-5
+
+
+def test_tiny_oracle_vs_reference_golden_xfeat_architecture():
+    """The same with a backbone of the real XFeat layer list (roma_amd.synthetic.XFeatArch) and the exact_softmax=True
+    branch of pos_embed (tiny.py:139-141): tests/golden/tiny_xfeat_reference.npz."""
+    from oracle import tiny_oracle as T
+    from roma_amd import synthetic
+    g = np.load(os.path.join(GOLDEN, "tiny_xfeat_reference.npz"))
+    sd, xf = synthetic.make_tiny_state_dict(0), synthetic.XFeatArch(0)
+    for tag, exact in (("x", False), ("e", True), ("y", False)):
+        a, b = torch.from_numpy(g[tag + "_im_A"]), torch.from_numpy(g[tag + "_im_B"])
+        ff, fc = torch.from_numpy(g[tag + "_feat_fine"]), torch.from_numpy(g[tag + "_feat_coarse"])
+        cor = T.forward_from_features(ff[:1], fc[:1], ff[1:], fc[1:], sd, (b.shape[-2] // 32) * 32, (b.shape[-1] // 32) * 32, exact)
+        for lvl in (8, 4):
+            assert torch.equal(cor[lvl]["flow"], torch.from_numpy(g[f"{tag}_flow{lvl}"])), (tag, lvl)
+            assert torch.equal(cor[lvl]["certainty"], torch.from_numpy(g[f"{tag}_cert{lvl}"])), (tag, lvl)
+        w, c = T.match(a, b, xf, sd, exact)
         assert float((w - torch.from_numpy(g[tag + "_warp"])).abs().max()) < 1e-5
         assert float((c - torch.from_numpy(g[tag + "_cert"])).abs().max()) < 1e-5
 

@@ -47,6 +47,39 @@ def test_tiny_match_vs_reference_golden(tiny_model):
     assert dw < TOL and dc < TOL
 
 
+def test_resolutions_not_multiples_of_8_vs_reference_golden(built_lib, weights0):
+    """roma_models.py:58-59 only asks for multiples of 14 (518, 574, 602, ...): coarse 126 x 154 -> upsample 182 x 198, where
+    every level of the VGG pyramid has the floor-divided size of its max-pool (63 x 77, 31 x 38, 15 x 19 / 91 x 99, 45 x 49,
+    22 x 24) and the decoder resizes go to those sizes.  f32 against the unmodified reference (tests/golden/match_odd.npz,
+    tools/make_goldens.py odd) at 1e-3; the 16-bit modes must run and stay finite; the next multiple of 14 above 560 that
+    is not a multiple of 8 (574) builds and runs."""
+    from roma_amd import roma_model, synthetic
+    sd, dsd = weights0
+    g = np.load(os.path.join(GOLDEN, "match_odd.npz"))
+    inp = _to_dev(synthetic.make_inputs(1, (126, 154), (182, 198), seed=5))
+    kw = dict(im_A_high_res=inp["im_A_high_res"], im_B_high_res=inp["im_B_high_res"])
+    m = roma_model((126, 154), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=torch.float32,
+                   symmetric=True, upsample_res=(182, 198), max_batch=1)
+    warp, cert = m.match(inp["im_A"], inp["im_B"], **kw)
+    torch.cuda.synchronize()
+    assert warp.shape == (1, 182, 396, 4) and cert.shape == (1, 182, 396)
+    dw = np.abs(warp.cpu().numpy() - g["warp"]).max()
+    dc = np.abs(cert.cpu().numpy() - g["certainty"]).max()
+    print(f"odd: max|dwarp|={dw:.3e} max|dcert|={dc:.3e}")
+    assert dw < TOL and dc < TOL
+    for amp in (torch.bfloat16, torch.float16):
+        mh = roma_model((126, 154), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=amp,
+                        symmetric=True, upsample_res=(182, 198), max_batch=1)
+        w16, c16 = mh.match(inp["im_A"], inp["im_B"], **kw)
+        assert torch.isfinite(w16).all() and torch.isfinite(c16).all()
+        assert float((c16 - cert).abs().mean()) < 0.05
+    big = roma_model((574, 574), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=torch.bfloat16,
+                     symmetric=True, upsample_res=(602, 602), max_batch=1)
+    ib = _to_dev(synthetic.make_inputs(1, 574, 602, seed=2))
+    wb, cb = big.match(ib["im_A"], ib["im_B"], im_A_high_res=ib["im_A_high_res"], im_B_high_res=ib["im_B_high_res"])
+    assert wb.shape == (1, 602, 1204, 4) and torch.isfinite(wb).all() and torch.isfinite(cb).all()
+
+
 def test_tiny_stages_vs_oracle(tiny_model, weights0):
     """Stage-by-stage comparison (debug capture) so that a regression names the kernel that broke."""
     from oracle import roma_oracle as O
@@ -243,6 +276,35 @@ def test_stream_split_bit_identical_1000_runs(built_lib, weights0, fuse):
         if not (torch.equal(w1, w2) and torch.equal(c1, c2)):
             bad.append((it, float((c1 - c2).abs().max()), float((w1 - w2).abs().max())))
     assert not bad, (len(bad), bad[:5])
+
+
+def test_handle_cache_keeps_two_resolutions(built_lib, weights0):
+    """Tensors of another resolution than the configured one get their own library handle (matcher.py:822-826 only warns);
+    the matcher keeps the last two, so alternating between two resolutions rebuilds nothing and results repeat exactly."""
+    import warnings
+    from roma_amd import roma_model, synthetic
+    sd, dsd = weights0
+    m = roma_model((112, 112), False, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=torch.float32,
+                   symmetric=True, max_batch=1)
+    a = _to_dev(synthetic.make_inputs(1, (112, 112), None, seed=7))
+    b = _to_dev(synthetic.make_inputs(1, (112, 168), None, seed=8))
+    c = _to_dev(synthetic.make_inputs(1, (168, 112), None, seed=9))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wa0, _ = m.match(a["im_A"], a["im_B"])
+        h_a = m._handle.value
+        wb0, _ = m.match(b["im_A"], b["im_B"])
+        h_b = m._handle.value
+        assert h_a != h_b and len(m._cache) == 2
+        for _ in range(2):  # alternate: both handles are reused, nothing is rebuilt
+            wa, _ = m.match(a["im_A"], a["im_B"])
+            assert m._handle.value == h_a and torch.equal(wa, wa0)
+            wb, _ = m.match(b["im_A"], b["im_B"])
+            assert m._handle.value == h_b and torch.equal(wb, wb0)
+        m.match(c["im_A"], c["im_B"])  # a third configuration evicts the least recently used one (a)
+        assert len(m._cache) == 2 and h_b in [h.value for h in m._cache.values()]
+        wa, _ = m.match(a["im_A"], a["im_B"])  # rebuilt: same result
+        assert torch.equal(wa, wa0)
 
 
 def test_non_square_and_pil_inputs(built_lib, weights0, tmp_path):

@@ -1,6 +1,8 @@
 """Tiny RoMa on the device (roma_amd.TinyRoMa: csrc/tiny.hip + the GEMM / convolution kernels) against the reference's own
 TinyRoMa output (tests/golden/tiny_reference.npz, made by tools/make_goldens.py tinyroma with the seeded stand-in XFeat
-backbone).  fp32, north-star tolerance 1e-3 max-abs on warp and certainty."""
+backbone; tests/golden/tiny_xfeat_reference.npz with a backbone of the real XFeat layer list).  The backbone itself runs
+on the device too (forward_single replayed through roma_op_gray_instnorm / conv2d_nhwc / avgpool_nhwc / resize_bilinear /
+add3): no torch arithmetic anywhere in match().  fp32, north-star tolerance 1e-3 max-abs on warp and certainty."""
 import os
 
 import numpy as np
@@ -37,8 +39,8 @@ def test_tiny_from_reference_features(built_lib, tag):
 
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_tiny_match_end_to_end(built_lib, tag):
-    """TinyRoMa.match with the stand-in backbone running as the caller's torch module on the GPU (its convolutions are
-    not ours): warp and certainty at the resolution of image A; 'b' (100 x 150) exercises the resize to multiples of 32."""
+    """TinyRoMa.match with the stand-in backbone replayed on the device: warp and certainty at the resolution of image A;
+    'b' (100 x 150) exercises the resize to multiples of 32."""
     g = np.load(os.path.join(GOLDEN, "tiny_reference.npz"))
     m = _model()
     a, b = torch.from_numpy(g[tag + "_im_A"]).cuda(), torch.from_numpy(g[tag + "_im_B"]).cuda()
@@ -48,8 +50,47 @@ def test_tiny_match_end_to_end(built_lib, tag):
     dc = float((cert.cpu() - torch.from_numpy(g[tag + "_cert"])).abs().max())
     print(f"tiny match {tag}: max|dwarp| = {dw:.2e}, max|dcert| = {dc:.2e}")
     assert dw < TOL and dc < TOL
-    w1, c1 = m.match(a[:1], b[:1], batched=True)  # pairs are independent (the torch backbone may pick another conv algorithm
-    assert float((w1 - warp[:1]).abs().max()) < 1e-4 and float((c1 - cert[:1]).abs().max()) < 1e-4  # for another batch size)
+    w1, c1 = m.match(a[:1], b[:1], batched=True)  # pairs are independent and every kernel is batch-size invariant
+    assert torch.equal(w1, warp[:1]) and torch.equal(c1, cert[:1])
+
+
+@pytest.mark.parametrize("tag,exact", [("x", False), ("e", True), ("y", False)])
+def test_tiny_xfeat_architecture_backbone_on_device(built_lib, tag, exact):
+    """Backbone of the real XFeat architecture (BasicLayer stacks with BatchNorm, stride-2 and 1 x 1 layers, AvgPool skip)
+    replayed on the device: forward_single's two feature maps against the reference's, then both correspondence levels and
+    match(); 'e' = the exact_softmax=True branch of pos_embed (tiny.py:139-141), 'y' = 100 x 150 (resize to multiples of 32)."""
+    from roma_amd import TinyRoMa, synthetic
+    g = np.load(os.path.join(GOLDEN, "tiny_xfeat_reference.npz"))
+    m = TinyRoMa(xfeat=synthetic.XFeatArch(0), weights=synthetic.make_tiny_state_dict(0), device="cuda:0", exact_softmax=exact)
+    a, b = torch.from_numpy(g[tag + "_im_A"]).cuda(), torch.from_numpy(g[tag + "_im_B"]).cuda()
+    xa, rh, rw = m.preprocess_tensor(a)
+    xb, _, _ = m.preprocess_tensor(b)
+    assert xa.shape[-2] % 32 == 0 and xa.shape[-1] % 32 == 0 and abs(rh - a.shape[-2] / xa.shape[-2]) < 1e-12
+    fine, coarse = m.forward_single(torch.cat([xa, xb], dim=0))
+    ef = float((fine.cpu() - torch.from_numpy(g[tag + "_feat_fine"])).abs().max())
+    ec = float((coarse.cpu() - torch.from_numpy(g[tag + "_feat_coarse"])).abs().max())
+    sc = float(torch.from_numpy(g[tag + "_feat_coarse"]).abs().max())
+    print(f"xfeat-arch backbone {tag}: max|d fine| = {ef:.2e}, max|d coarse| = {ec:.2e} (range {sc:.1f})")
+    assert ef < 1e-4 * max(1.0, sc) and ec < 1e-4 * max(1.0, sc)
+    cor = m.forward({"im_A": a, "im_B": b})
+    for lvl in (8, 4):
+        df = float((cor[lvl]["flow"].cpu() - torch.from_numpy(g[f"{tag}_flow{lvl}"])).abs().max())
+        dc = float((cor[lvl]["certainty"].cpu() - torch.from_numpy(g[f"{tag}_cert{lvl}"])).abs().max())
+        assert df < TOL and dc < TOL, (tag, lvl, df, dc)
+    warp, cert = m.match(a, b)
+    dw = float((warp.cpu() - torch.from_numpy(g[tag + "_warp"])).abs().max())
+    dc = float((cert.cpu() - torch.from_numpy(g[tag + "_cert"])).abs().max())
+    print(f"xfeat-arch match {tag}: max|dwarp| = {dw:.2e}, max|dcert| = {dc:.2e}")
+    assert dw < TOL and dc < TOL
+
+
+def test_tiny_backbone_refuses_layers_it_cannot_replay(built_lib):
+    """No silent fallback to the caller's torch module: an unsupported layer is an error at construction."""
+    from roma_amd import TinyRoMa, synthetic
+    xf = synthetic.XFeatStandIn(0)
+    xf.block2 = torch.nn.Sequential(torch.nn.Conv2d(24, 24, 3, padding=1), torch.nn.GELU())
+    with pytest.raises(NotImplementedError):
+        TinyRoMa(xfeat=xf, weights=synthetic.make_tiny_state_dict(0), device="cuda:0")
 
 
 def test_tiny_match_demo_size(built_lib):

@@ -9,6 +9,8 @@ fixtures are what travels to the GPU box.  Usage:
     python tools/make_goldens.py tiny          # match() 112 -> 168, B=1 symmetric (+ stage tensors)
     python tools/make_goldens.py small         # match() 224 -> 336, B=2, non-symmetric and symmetric coarse-only
     python tools/make_goldens.py full          # match() 560 -> 864, B=1 symmetric (sub-sampled)
+    python tools/make_goldens.py odd           # match() 126 x 154 -> 182 x 198: multiples of 14 that are not multiples of 8
+    python tools/make_goldens.py mega          # match() 672 -> 1344, B=1 symmetric (tests/test_mega1500.py geometry; sub-sampled)
     python tools/make_goldens.py full8         # match() 560 -> 864, B=8 symmetric, bench.py's rank-0 workload (sub-sampled)
     python tools/make_goldens.py full_coarse   # match() 560 coarse-only, B=1 symmetric (BASELINE config 2 geometry)
     python tools/make_goldens.py full8_indoor  # same geometry, seeds 2 / 3 (BASELINE config 5 "indoor")
@@ -17,6 +19,7 @@ fixtures are what travels to the GPU box.  Usage:
     python tools/make_goldens.py keypoints_ties  # the same with duplicate keypoints: every tied pair is returned
     python tools/make_goldens.py vis           # RegressionMatcher.visualize_warp on a seeded warp + images
     python tools/make_goldens.py tinyroma      # TinyRoMa.match / forward with the seeded stand-in XFeat backbone
+    python tools/make_goldens.py tinyroma_xfeat  # the same with a backbone of the real XFeat architecture; exact_softmax=True
 """
 import json
 import os
@@ -122,7 +125,8 @@ def ops_nearest():
 def _run_reference(cfg_name, coarse, up, B, symmetric, upsample_preds, seed_w, seed_in, capture=True):
     sd = synthetic.make_matcher_state_dict(seed_w)
     dsd = synthetic.make_dinov2_state_dict(seed_w)
-    m = build_reference_matcher(sd, dsd, (coarse, coarse), (up, up), symmetric=symmetric,
+    hw = lambda v: (v, v) if isinstance(v, int) else tuple(v)  # noqa: E731
+    m = build_reference_matcher(sd, dsd, hw(coarse), hw(up), symmetric=symmetric,
                                 upsample_preds=upsample_preds)
     inp = synthetic.make_inputs(B, coarse, up if upsample_preds else None, seed=seed_in)
     stages = {}
@@ -206,6 +210,38 @@ def full():
                 min_top2_gap=float(st["cls16_top2gap"].min()), ref_seconds=dt,
                 threads=torch.get_num_threads(), torch=torch.__version__)
     json.dump(meta, open(os.path.join(GOLD, "match_full.json"), "w"), indent=1)
+    print(meta)
+
+
+def odd():
+    """Resolutions that are multiples of 14 but NOT of 8 (roma_models.py:58-59 accepts them; the VGG pyramid then has the
+    floor-divided sizes of its max-pools, and every resize in the decoder goes to those sizes): coarse 126 x 154 ->
+    upsample 182 x 198 (no multiple-of-anything requirement on the upsample side), B = 1 symmetric, non-square."""
+    warp, cert, stages, dt = _run_reference("odd", (126, 154), (182, 198), 1, True, True, 0, 5)
+    np.savez_compressed(os.path.join(GOLD, "match_odd.npz"), warp=np32(warp), certainty=np32(cert),
+                        cls16_argmax=stages["cls16_argmax"], cls16_top2gap=stages["cls16_top2gap"],
+                        gm_flow16=stages["gm_flow16"], gm_cert16=stages["gm_cert16"])
+    meta = dict(coarse=[126, 154], up=[182, 198], B=1, symmetric=True, upsample_preds=True, seed_w=0, seed_in=5,
+                min_top2_gap=float(stages["cls16_top2gap"].min()), ref_seconds=dt, torch=torch.__version__)
+    json.dump(meta, open(os.path.join(GOLD, "match_odd.json"), "w"), indent=1)
+    print(meta)
+
+
+def mega():
+    """The geometry of the reference's accuracy tests (tests/test_mega1500.py:12-21: coarse 672, upsample 1344), B = 1
+    symmetric fp32 on the synthetic weights: sub-sampled outputs + row checksums + the coarse match."""
+    torch.set_num_threads(os.cpu_count())
+    warp, cert, st, dt = _run_reference("mega", 672, 1344, 1, True, True, 0, 7)
+    w, c = np32(warp), np32(cert)
+    out = dict(warp_sub=w[:, ::8, ::8], cert_sub=c[:, ::8, ::8],
+               warp_rowsum=w.sum(axis=(2, 3), dtype=np.float64), cert_rowsum=c.sum(axis=2, dtype=np.float64),
+               cls16_argmax=st["cls16_argmax"], cls16_top2gap=st["cls16_top2gap"], gm_cert16=st["gm_cert16"],
+               gm_flow16=st["gm_flow16"])
+    np.savez_compressed(os.path.join(GOLD, "match_mega.npz"), **out)
+    meta = dict(coarse=672, up=1344, B=1, symmetric=True, seed_w=0, seed_in=7, subsample=8,
+                min_top2_gap=float(st["cls16_top2gap"].min()), ref_seconds=dt,
+                threads=torch.get_num_threads(), torch=torch.__version__)
+    json.dump(meta, open(os.path.join(GOLD, "match_mega.json"), "w"), indent=1)
     print(meta)
 
 
@@ -372,6 +408,43 @@ def tinyroma_golden():
     print("tiny_reference.npz", {k: v.shape for k, v in out.items()}, missing)
 
 
+def tinyroma_xfeat_golden():
+    """The reference's TinyRoMa with a backbone of the real XFeat ARCHITECTURE (roma_amd.synthetic.XFeatArch: BasicLayer
+    stacks with BatchNorm, stride-2 and 1 x 1 layers; seeded weights), for the device replay of forward_single
+    (tiny.py:81-99) and for the exact_softmax=True branch of pos_embed (tiny.py:139-141).  Per case: the backbone features
+    of both images, both correspondence levels and match()."""
+    install_stubs()
+    import types
+    if "torchvision.transforms" not in sys.modules:
+        tv = sys.modules.get("torchvision") or types.ModuleType("torchvision")
+        tr = types.ModuleType("torchvision.transforms")
+        tr.ToTensor = lambda: (lambda im: torch.from_numpy(np.array(im)).permute(2, 0, 1).float() / 255)
+        tv.transforms = tr
+        sys.modules["torchvision"] = tv
+        sys.modules["torchvision.transforms"] = tr
+    from romatch.models.tiny import TinyRoMa
+    from roma_amd import synthetic
+    sd = synthetic.make_tiny_state_dict(0)
+    out = {}
+    for tag, (h, w, exact, seed) in {"x": (96, 128, False, 6), "e": (96, 128, True, 6), "y": (100, 150, False, 7)}.items():
+        model = TinyRoMa(xfeat=synthetic.XFeatArch(0), freeze_xfeat=True, exact_softmax=exact)
+        model.load_state_dict(sd, strict=True)
+        model.train(False)
+        inp = synthetic.make_tiny_inputs(1, h, w, seed=seed)
+        ia, ib = inp["im_A"], inp["im_B"]
+        with torch.inference_mode():
+            x = torch.cat([model.preprocess_tensor(ia)[0], model.preprocess_tensor(ib)[0]], dim=0)
+            fine, coarse = model.forward_single(x)
+            corr = model.forward({"im_A": ia, "im_B": ib})
+            warp, cert = model.match(ia, ib, batched=True)
+        out.update({f"{tag}_im_A": np32(ia), f"{tag}_im_B": np32(ib), f"{tag}_feat_fine": np32(fine), f"{tag}_feat_coarse": np32(coarse),
+                    f"{tag}_flow8": np32(corr[8]["flow"]), f"{tag}_cert8": np32(corr[8]["certainty"]),
+                    f"{tag}_flow4": np32(corr[4]["flow"]), f"{tag}_cert4": np32(corr[4]["certainty"]),
+                    f"{tag}_warp": np32(warp), f"{tag}_cert": np32(cert)})
+    np.savez_compressed(os.path.join(GOLD, "tiny_xfeat_reference.npz"), **out)
+    print("tiny_xfeat_reference.npz", {k: v.shape for k, v in out.items()})
+
+
 def vis_golden():
     """Reference RegressionMatcher.visualize_warp (matcher.py:936-986) on a seeded smooth symmetric warp, tensor images
     of the warp's resolution, and the non-symmetric form with images of a different resolution."""
@@ -398,4 +471,4 @@ def vis_golden():
 
 if __name__ == "__main__":
     for what in sys.argv[1:]:
-        {"contract": contract, "ops": ops, "ops_nearest": ops_nearest, "tiny": tiny, "small": small, "full": full, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden, "keypoints_ties": keypoints_ties_golden, "vis": vis_golden, "tinyroma": tinyroma_golden}[what]()
+        {"contract": contract, "ops": ops, "ops_nearest": ops_nearest, "tiny": tiny, "small": small, "full": full, "odd": odd, "mega": mega, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden, "keypoints_ties": keypoints_ties_golden, "vis": vis_golden, "tinyroma": tinyroma_golden, "tinyroma_xfeat": tinyroma_xfeat_golden}[what]()
