@@ -555,6 +555,13 @@ static int launch_shape(const GemmArgs& a, hipStream_t stream) {
   if constexpr (!CONV) {
     if (a.N > 128 && a.N <= 160) return launch_cfg<TIN, TOUT, 4, 1, 1, 5, false>(a, stream);  // 128 x 160: one n-tile
   }
+  // Small-M problems (a single pair: M = 3 202 token rows): N = 1024 gives 26 x 8 = 208 tiles of 128 x 128 for 256 CUs -
+  // 48 CUs idle and ONE wave per SIMD on the rest, so every DMA / LDS / MFMA latency is exposed (370 TFLOP/s,
+  // profiles/r02_final_bench_coarse.json).  128 x 64 tiles double the workgroups; three fit a CU (48 KiB of LDS each), so
+  // all of them are resident at once and a CU interleaves the waves of 1-2 tiles.  ROMA_GEMM_SMALLM=0 switches it off (A/B).
+  static const bool smallm_env = !(getenv("ROMA_GEMM_SMALLM") && atoi(getenv("ROMA_GEMM_SMALLM")) == 0);
+  const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
+  if (smallm_env && !a.lower_only && tiles128 < 320) return launch_cfg<TIN, TOUT, 4, 1, 1, 2, CONV>(a, stream);  // 128 x 64
   return launch_cfg<TIN, TOUT, 2, 2, 2, 2, CONV>(a, stream);                      // 128 x 128
 }
 
