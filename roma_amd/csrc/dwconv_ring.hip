@@ -1,0 +1,246 @@
+// Depthwise 5x5 (+folded BN, ReLU) for the WIDE ConvRefiner scales (C = 576 / 1152 / 1408; 16-bit storage) - the
+// "wave-private ring" form of dwconv5x5_kernel (elementwise.hip).  romatch/models/matcher.py:106-122.
+//
+// What bounds the register-prefetch kernel (elementwise.hip) is not bytes and not FMAs: at 254 VGPRs it runs two waves
+// per SIMD, each with ONE input row (8 x 8-byte loads per lane) in flight, i.e. 32 KiB per CU - against an HBM latency of
+// 2-3 us under load that is ~4 TB/s by Little's law - and its waves issue only 42 % of their cycles
+// (profiles/r02_pmc_sq_summary.json).  The LDS-DMA ring of round 1 fixed the depth but bought a workgroup barrier per
+// row (the four waves shared the ring) and lost.  Here every WAVE owns its own ring:
+//
+//   * a wave = 64 channels (one 128-byte line per pixel) x 16 output columns x a strip of rows; lane = (4 channels,
+//     4 columns).  Per input row it needs 20 pixels x 128 B = 2 560 B: three `global_load_lds_dwordx4` (16 B per lane,
+//     whole cache lines, the halo columns fetched once per wave instead of once per lane);
+//   * the ring holds NR = 10 rows per wave (30 KiB; 120 KiB per workgroup), the DMA runs nine rows ahead: ~90 KiB in flight
+//     per CU.  Only the issuing wave reads its slots, so the one thing that orders a read behind its DMA is that wave's own
+//     counted `s_waitcnt vmcnt` - NO barrier anywhere in the kernel, the waves drift freely;
+//   * ONE workgroup (four waves) per CU, one wave per SIMD: 100 weight + 80 accumulator registers plus the unrolled row
+//     loop need ~330 registers (at the 256 of two waves per SIMD hipcc spills 101 of them, and every scratch reload is a
+//     VMEM operation that drains the counted DMA queue); the deep ring, not occupancy, hides the memory latency here;
+//   * pixels sit in the ring at slot s(x) = x + x / 4 (every fifth 128-byte slot stays empty): the two 16-lane halves of
+//     a `ds_read_b64` group read pixels 4 apart, i.e. 5 slots = an odd number of 128-byte rows apart - opposite halves of
+//     the 64 banks, conflict free;
+//   * the 25 x 4 tap weights live in registers for the whole strip; the five rolling accumulator rows are renamed instead
+//     of moved (the row loop is unrolled by five), the taps run column-major so that only four converted columns are live;
+//   * arithmetic and its order per accumulator are those of dwconv5x5_kernel: results are bit-identical (tests).
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "elementwise.h"
+#include "gemm.h"  // DT_*
+
+namespace roma {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+#define ROMA_LDS __attribute__((address_space(3)))
+typedef ROMA_LDS unsigned char lds_u8;
+
+__device__ __attribute__((aligned(256))) unsigned int g_dwr_zero_page[64];  // source of every out-of-image / empty-slot piece
+
+constexpr int DWR_NR = 10;             // ring rows per wave
+constexpr int DWR_ROWB = 3072;         // bytes per ring row: 24 slots x 128 B (20 pixels + 4 empty slots)
+constexpr int DWR_PXW = 16;            // output columns per wave
+static_assert(3 * (DWR_NR - 1) + 4 * (DWR_NR - 1) <= 63, "vmcnt is a 6-bit counter");
+static_assert(4 * DWR_NR * DWR_ROWB <= 160 * 1024, "one workgroup per CU");
+
+#define ROMA_DWR_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+__device__ __forceinline__ void dwr_glds16(const char* src, lds_u8* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (ROMA_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+// one input row t (phase PH = t mod 5): read it from the ring, feed the five rolling output rows, finish row t - 4
+template <int PH>
+__device__ __forceinline__ void dwr_row(f32x2 (&acc)[5][4][2], const f32x4 (&wreg)[25], f32x2 bias0, f32x2 bias1, unsigned rd,
+                                        bool store, bf16_t* orow, long Cp, int npx) {
+  unsigned long long cr[8];
+  asm volatile(
+      "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:128\n\tds_read_b64 %2, %8 offset:256\n\t"
+      "ds_read_b64 %3, %8 offset:384\n\tds_read_b64 %4, %8 offset:640\n\tds_read_b64 %5, %8 offset:768\n\t"
+      "ds_read_b64 %6, %8 offset:896\n\tds_read_b64 %7, %8 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(cr[0]), "=&v"(cr[1]), "=&v"(cr[2]), "=&v"(cr[3]), "=&v"(cr[4]), "=&v"(cr[5]), "=&v"(cr[6]), "=&v"(cr[7])
+      : "v"(rd)
+      : "memory");
+  f32x2 v[8][2];
+#define ROMA_DWR_CVT(J)                                                  \
+  {                                                                      \
+    const uint32_t lo_ = (uint32_t)cr[J], hi_ = (uint32_t)(cr[J] >> 32); \
+    v[J][0] = f32x2{h16_lo(lo_), h16_hi(lo_)};                           \
+    v[J][1] = f32x2{h16_lo(hi_), h16_hi(hi_)};                           \
+  }
+  ROMA_DWR_CVT(0) ROMA_DWR_CVT(1) ROMA_DWR_CVT(2)
+#pragma unroll
+  for (int kx = 0; kx < 5; ++kx) {
+    ROMA_DWR_CVT(kx + 3)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {  // output row t - 4 + k lives in accumulator set (PH + 1 + k) % 5; tap row ky = 4 - k
+      const f32x4 wx = wreg[(4 - k) * 5 + kx];
+      const f32x2 w0 = f32x2{wx[0], wx[1]}, w1 = f32x2{wx[2], wx[3]};
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        acc[(PH + 1 + k) % 5][px][0] = v[px + kx][0] * w0 + acc[(PH + 1 + k) % 5][px][0];
+        acc[(PH + 1 + k) % 5][px][1] = v[px + kx][1] * w1 + acc[(PH + 1 + k) % 5][px][1];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef ROMA_DWR_CVT
+  constexpr int DONE = (PH + 1) % 5;  // the accumulator set of output row t - 4
+  if (store) {
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      // always four stores per row and wave (the counted vmcnt waits rely on it): a column beyond the image is clamped to
+      // this lane's first column, i.e. that column's value is stored a second time
+      const int pc = px < npx ? px : 0;
+      uint2 u;
+      u.x = pack_bf16x2(fmaxf(acc[DONE][pc][0][0], 0.f), fmaxf(acc[DONE][pc][0][1], 0.f));
+      u.y = pack_bf16x2(fmaxf(acc[DONE][pc][1][0], 0.f), fmaxf(acc[DONE][pc][1][1], 0.f));
+      *reinterpret_cast<uint2*>(orow + (long)pc * Cp) = u;
+    }
+  }
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+    acc[DONE][px][0] = bias0;
+    acc[DONE][px][1] = bias1;
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void dwconv5x5_ring_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                                const float* __restrict__ w, const float* __restrict__ bias,
+                                                                int B, int H, int W, int Cp, int SY, int nchunk, int nxg,
+                                                                long ntask, long nblocks) {
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[4 * DWR_NR * DWR_ROWB];
+  const long per_xcd = (nblocks + 7) / 8;  // each XCD owns a contiguous band of tasks (the row halos hit its own L2)
+  const long lb = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long task = lb * 4 + wv;
+  if (lb >= nblocks || task >= ntask) return;  // (no barriers in this kernel: a wave may leave on its own)
+  const int chunk = (int)(task % nchunk);
+  long r = task / nchunk;
+  const int xg = (int)(r % nxg);
+  r /= nxg;
+  const int yt = (H + SY - 1) / SY;
+  const int ys = (int)(r % yt) * SY;
+  const int b = (int)(r / yt);
+  const int sy = min(SY, H - ys);
+  const int T = sy + 4;  // input rows ys - 2 .. ys + sy + 1
+
+  const int cg = lane & 15, xq = lane >> 4;
+  const int c = chunk * 64 + cg * 4;
+  const int xb = xg * DWR_PXW + xq * 4;   // first output column of this lane
+  const int x0 = xg * DWR_PXW - 2;        // image column of ring pixel 0
+  const int npx = min(4, W - xb);         // valid output columns of this lane (<= 0: the lane only helps with the DMA)
+
+  // ---- tap weights and bias of this lane's 4 channels: registers for the whole strip
+  f32x4 wreg[25];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) wreg[t] = *reinterpret_cast<const f32x4*>(w + (long)t * Cp + c);
+  const f32x4 bx = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+  for (int t = 0; t < 25; ++t) asm volatile("" : "+v"(wreg[t]));  // retire these loads here, keep them in registers
+  const f32x2 bias0 = f32x2{bx[0], bx[1]}, bias1 = f32x2{bx[2], bx[3]};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this wave in flight before the counted DMA stream starts
+
+  // ---- DMA descriptors: piece p = 64 i + lane of a row -> ring slot p >> 3 (slot s holds pixel s - s / 5, s % 5 == 4
+  // stays empty), 16-byte part p & 7 of the pixel's 128-byte channel line
+  const char* zsrc = reinterpret_cast<const char*>(g_dwr_zero_page);
+  const char* inb = reinterpret_cast<const char*>(in + ((long)b * H * W) * Cp) + (long)chunk * 128;
+  long poff[3];
+  bool pok[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int p = 64 * i + lane, s = p >> 3, part = p & 7;
+    const int x = x0 + s - s / 5;
+    pok[i] = (s % 5 != 4) && x >= 0 && x < W;
+    poff[i] = (long)(pok[i] ? x : 0) * Cp * 2 + part * 16;
+  }
+  lds_u8* const myring = (lds_u8*)ring + wv * (DWR_NR * DWR_ROWB);
+#define ROMA_DWR_ISSUE(RROW, SLOT)                                                         \
+  {                                                                                        \
+    const int yy_ = ys - 2 + (RROW);                                                       \
+    const bool rok_ = (RROW) < T && yy_ >= 0 && yy_ < H;                                   \
+    const char* rb_ = inb + (long)(rok_ ? yy_ : 0) * W * Cp * 2;                           \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i)                                          \
+        dwr_glds16((rok_ && pok[i]) ? rb_ + poff[i] : zsrc, myring + (SLOT) * DWR_ROWB + i * 1024); \
+  }
+
+  f32x2 acc[5][4][2];
+#pragma unroll
+  for (int s5 = 0; s5 < 5; ++s5)
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      acc[s5][px][0] = bias0;
+      acc[s5][px][1] = bias1;
+    }
+  const unsigned ring_lds = (unsigned)(size_t)myring;
+  const unsigned rd0 = ring_lds + (unsigned)(xq * 5 * 128 + cg * 8);
+  bf16_t* const obase = out + ((long)b * H * W) * Cp + c;
+
+  // ---- prologue: rows 0 .. NR - 2 in flight
+#pragma unroll
+  for (int rr = 0; rr < DWR_NR - 1; ++rr) ROMA_DWR_ISSUE(rr, rr);
+
+  int slot = 0;        // ring slot of input row t
+  int fill = DWR_NR - 1;  // ring slot the next DMA goes to (= slot of row t - 1)
+  // Row t is complete once at most the operations issued AFTER its DMA are outstanding: the DMA of rows t + 1 .. t + NR - 1
+  // (3 each) and the 4 output stores of every iteration s in [t - NR + 1, t - 1] that had an output row (s >= 4).
+#define ROMA_DWR_STEP(PH)                                                                                    \
+  {                                                                                                          \
+    const int t = t0 + (PH);                                                                                 \
+    if (t >= T) break;                                                                                       \
+    ROMA_DWR_ISSUE(t + DWR_NR - 1, fill);                                                                    \
+    const int kst = min(max(t - 4, 0), DWR_NR - 1);                                                          \
+    switch (kst) { /* vmcnt is a 6-bit counter: 27 + 4 * 9 = 63 is its largest value */                      \
+      case 0: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1)); break;                                                     \
+      case 1: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 4); break;                                                 \
+      case 2: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 8); break;                                                 \
+      case 3: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 12); break;                                                \
+      case 4: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 16); break;                                                \
+      case 5: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 20); break;                                                \
+      case 6: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 24); break;                                                \
+      case 7: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 28); break;                                                \
+      case 8: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 32); break;                                                \
+      default: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 36); break;                                               \
+    }                                                                                                        \
+    const int o = t - 4;                                                                                     \
+    dwr_row<PH>(acc, wreg, bias0, bias1, rd0 + (unsigned)slot * DWR_ROWB, o >= 0 && npx > 0,                  \
+                obase + ((long)(ys + max(o, 0)) * W + xb) * Cp, (long)Cp, npx);                              \
+    fill = slot;                                                                                             \
+    slot = slot + 1 == DWR_NR ? 0 : slot + 1;                                                                \
+  }
+#pragma nounroll
+  for (int t0 = 0; t0 < T; t0 += 5) {
+    ROMA_DWR_STEP(0) ROMA_DWR_STEP(1) ROMA_DWR_STEP(2) ROMA_DWR_STEP(3) ROMA_DWR_STEP(4)
+  }
+#undef ROMA_DWR_STEP
+#undef ROMA_DWR_ISSUE
+  ROMA_DWR_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
+}
+
+int g_dw_ring = -1;  // roma_tuning("dw_ring", v): 1 = this kernel for the shapes it takes (default), 0 = dwconv5x5_kernel, -1 = env ROMA_DW_RING
+
+// 0 = launched, 1 = not this kernel's problem, < 0 = error
+int dwconv5x5_ring_try_launch(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp, int dt,
+                              hipStream_t s) {
+  static const int env = getenv("ROMA_DW_RING") ? atoi(getenv("ROMA_DW_RING")) : 1;
+  if (!(g_dw_ring >= 0 ? g_dw_ring : env)) return 1;
+  if (dt != DT_BF16 || Cp % 64 != 0 || Cp < 256 || H < 1 || W < 1) return 1;
+  if ((long)H * W * Cp * 2 >= (1l << 31)) return 1;  // (per-image byte offsets stay far below this in the model)
+  if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (reinterpret_cast<uintptr_t>(out) & 7) != 0) return 1;
+  const int nchunk = Cp / 64;
+  const int nxg = (W + DWR_PXW - 1) / DWR_PXW;
+  const int nstrip = (H + 35) / 36;
+  const int SY = (H + nstrip - 1) / nstrip;
+  const long ntask = (long)B * ((H + SY - 1) / SY) * nxg * nchunk;
+  const long nblocks = (ntask + 3) / 4;
+  ROMA_REQUIRE(nblocks < (1l << 30), "dwconv5x5: grid too large");
+  ProfScope ps("dwconv5x5_kernel<" ROMA_H16_NAME ">", 2.0 * (double)B * H * W * Cp * 2.0, "byte", s);
+  hipLaunchKernelGGL(dwconv5x5_ring_kernel, dim3((unsigned)(((nblocks + 7) / 8) * 8)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out,
+                     w, bias, B, H, W, Cp, SY, nchunk, nxg, ntask, nblocks);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace roma

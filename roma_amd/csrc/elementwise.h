@@ -73,6 +73,11 @@ int refiner_input_launch(const RefinerInputArgs& a, hipStream_t s);
 // depthwise 5x5 (pad 2) + folded BN + ReLU, NHWC.  w: [25][Cp], bias [Cp]
 int dwconv5x5_launch(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp,
                      int dt, hipStream_t s);
+// wide 16-bit problems (Cp % 64 == 0, Cp >= 256): the wave-private LDS-DMA ring form (dwconv_ring.hip), bit-identical to the
+// kernel above.  0 = launched, 1 = not its problem, < 0 = error.  g_dw_ring: roma_tuning("dw_ring") A/B switch.
+int dwconv5x5_ring_try_launch(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp, int dt,
+                              hipStream_t s);
+extern int g_dw_ring;
 
 // out_conv (C->3, f32) fused with the flow / certainty update (matcher.py:177-178, 496-506)
 int refiner_out_launch(const void* d, long ldd, int dt, const float* w /*[3][Cp]*/, const float* b /*[3]*/,

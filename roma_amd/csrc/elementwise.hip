@@ -1065,6 +1065,11 @@ __global__ __launch_bounds__(256, 2) void dwconv5x5_kernel(const T* in, T* out, 
 int dwconv5x5_launch(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp,
                      int dt, hipStream_t s) {
   ROMA_REQUIRE(Cp % 4 == 0, "dwconv5x5: padded channel count must be a multiple of 4");
+  ROMA_REQUIRE(in != out, "dwconv5x5: in and out must not alias");
+  {  // wide 16-bit problems: the wave-private LDS-DMA ring form (dwconv_ring.hip), bit-identical
+    const int rc = dwconv5x5_ring_try_launch(in, out, w, bias, B, H, W, Cp, dt, s);
+    if (rc <= 0) return rc;
+  }
   const int CG = Cp / 4;
   const int nchunk = (CG + 63) / 64;
   const int GC = (CG + nchunk - 1) / nchunk;  // channel groups (of 4) per workgroup, <= 64

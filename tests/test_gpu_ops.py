@@ -528,6 +528,30 @@ def test_dwconv5x5(lib, dt, B, H, W, Cp):
     assert torch.allclose(out.cpu().double(), ref, atol=tol, rtol=tol)
 
 
+@pytest.mark.parametrize("Cp,B,H,W", [(576, 2, 40, 36), (576, 1, 3, 50), (1152, 2, 27, 30), (1408, 1, 40, 40), (576, 1, 75, 17),
+                                      (256, 3, 1, 5), (576, 1, 109, 216)])
+def test_dwconv5x5_ring_is_bit_identical(lib, Cp, B, H, W):
+    """dwconv_ring.hip (wave-private LDS-DMA ring, one wave per SIMD, no barriers) against dwconv5x5_kernel: same
+    arithmetic in the same order per accumulator, so the outputs must agree bit for bit - image borders, widths that are
+    not multiples of the 16-column wave tile, strips shorter than the ring depth, several strips per image, B > 1; run
+    three times (the kernel's correctness rests on counted vmcnt waits: timing-dependent hazards)."""
+    x, w, b = rnd(B, H, W, Cp, seed=1).bfloat16().cuda(), rnd(25, Cp, seed=2, std=0.2).cuda(), rnd(Cp, seed=3).cuda()
+    outs = {}
+    try:
+        for mode in (0, 1, 1, 1):
+            lib.roma_tuning(b"dw_ring", mode)
+            out = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=torch.bfloat16)
+            ok(lib, lib.roma_op_dwconv5x5(P(x), P(out), P(w), P(b), B, H, W, Cp, BF16, None))
+            torch.cuda.synchronize()
+            if mode in outs:
+                assert torch.equal(out.view(torch.int16), outs[mode].view(torch.int16))
+            outs[mode] = out
+    finally:
+        lib.roma_tuning(b"dw_ring", -1)
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), float((outs[0].float() - outs[1].float()).abs().max())
+
+
 @pytest.mark.parametrize("Cp,B,H,W", [(24, 2, 13, 10), (24, 1, 75, 301), (24, 1, 290, 150), (144, 2, 13, 10), (144, 1, 41, 59),
                                       (144, 1, 262, 31), (144, 5, 70, 280), (24, 3, 3, 200), (144, 2, 1, 30)])
 def test_refiner_block_fused(lib, Cp, B, H, W):
