@@ -10,17 +10,18 @@
 //   * a wave = 64 channels (one 128-byte line per pixel) x 16 output columns x a strip of rows; lane = (4 channels,
 //     4 columns).  Per input row it needs 20 pixels x 128 B = 2 560 B: three `global_load_lds_dwordx4` (16 B per lane,
 //     whole cache lines, the halo columns fetched once per wave instead of once per lane);
-//   * the ring holds NR = 10 rows per wave (30 KiB; 120 KiB per workgroup), the DMA runs nine rows ahead: ~90 KiB in flight
-//     per CU.  Only the issuing wave reads its slots, so the one thing that orders a read behind its DMA is that wave's own
-//     counted `s_waitcnt vmcnt` - NO barrier anywhere in the kernel, the waves drift freely;
-//   * ONE workgroup (four waves) per CU, one wave per SIMD: 100 weight + 80 accumulator registers plus the unrolled row
-//     loop need ~330 registers (at the 256 of two waves per SIMD hipcc spills 101 of them, and every scratch reload is a
-//     VMEM operation that drains the counted DMA queue); the deep ring, not occupancy, hides the memory latency here;
+//   * the ring holds NR = 6 rows per wave (18 KiB; 72 KiB per workgroup, two workgroups per CU) and the DMA runs five
+//     rows ahead: ~100 KiB in flight per CU.  Only the issuing wave reads its slots, so the one thing that orders a read
+//     behind its DMA is that wave's own counted `s_waitcnt vmcnt` - NO barrier anywhere, the waves drift freely;
 //   * pixels sit in the ring at slot s(x) = x + x / 4 (every fifth 128-byte slot stays empty): the two 16-lane halves of
 //     a `ds_read_b64` group read pixels 4 apart, i.e. 5 slots = an odd number of 128-byte rows apart - opposite halves of
 //     the 64 banks, conflict free;
-//   * the 25 x 4 tap weights live in registers for the whole strip; the five rolling accumulator rows are renamed instead
-//     of moved (the row loop is unrolled by five), the taps run column-major so that only four converted columns are live;
+//   * the 25 x 4 tap weights of a lane stay in registers for the whole strip, the taps run column-major so that only four
+//     converted columns are live: 100 weight + 80 accumulator registers + the row pipeline = ~215 VGPRs, two waves per SIMD.
+//     The five rolling accumulator rows are rotated with moves.  Renaming them instead (the row loop unrolled by five) was
+//     built first: hipcc's allocation then needs ~330 registers - at two waves per SIMD it spilled 100-325 of them (every
+//     scratch reload is a VMEM operation that drains the counted DMA queue), and at one wave per SIMD the kernel ran
+//     0.54 ms against the 0.45 ms of dwconv5x5_kernel at 16 x 216 x 216 x 576 (profiles/r03_v5_dwconv_ring.log);
 //   * arithmetic and its order per accumulator are those of dwconv5x5_kernel: results are bit-identical (tests).
 #include <stdlib.h>
 
@@ -37,11 +38,12 @@ typedef ROMA_LDS unsigned char lds_u8;
 
 __device__ __attribute__((aligned(256))) unsigned int g_dwr_zero_page[64];  // source of every out-of-image / empty-slot piece
 
-constexpr int DWR_NR = 10;             // ring rows per wave
-constexpr int DWR_ROWB = 3072;         // bytes per ring row: 24 slots x 128 B (20 pixels + 4 empty slots)
-constexpr int DWR_PXW = 16;            // output columns per wave
+constexpr int DWR_ROWB = 3072;                   // bytes per ring row: 24 slots x 128 B (20 pixels + 4 empty slots)
+constexpr int DWR_PXW = 16;                      // output columns per wave
+constexpr int DWR_NR = 6;                        // ring rows per wave
+constexpr int DWR_RING = 4 * DWR_NR * DWR_ROWB;  // 72 KiB per workgroup
 static_assert(3 * (DWR_NR - 1) + 4 * (DWR_NR - 1) <= 63, "vmcnt is a 6-bit counter");
-static_assert(4 * DWR_NR * DWR_ROWB <= 160 * 1024, "one workgroup per CU");
+static_assert(2 * DWR_RING <= 160 * 1024, "two workgroups per CU");
 
 #define ROMA_DWR_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
@@ -49,8 +51,8 @@ __device__ __forceinline__ void dwr_glds16(const char* src, lds_u8* lds_wave_bas
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (ROMA_LDS void*)lds_wave_base, 16, 0, 0);
 }
 
-// one input row t (phase PH = t mod 5): read it from the ring, feed the five rolling output rows, finish row t - 4
-template <int PH>
+// one input row t: read it from the ring, feed the five rolling output rows (acc[k] = output row t - 4 + k, tap row
+// ky = 4 - k), finish and store row t - 4, rotate
 __device__ __forceinline__ void dwr_row(f32x2 (&acc)[5][4][2], const f32x4 (&wreg)[25], f32x2 bias0, f32x2 bias1, unsigned rd,
                                         bool store, bf16_t* orow, long Cp, int npx) {
   unsigned long long cr[8];
@@ -74,64 +76,70 @@ __device__ __forceinline__ void dwr_row(f32x2 (&acc)[5][4][2], const f32x4 (&wre
     ROMA_DWR_CVT(kx + 3)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {  // output row t - 4 + k lives in accumulator set (PH + 1 + k) % 5; tap row ky = 4 - k
+    for (int k = 0; k < 5; ++k) {
       const f32x4 wx = wreg[(4 - k) * 5 + kx];
       const f32x2 w0 = f32x2{wx[0], wx[1]}, w1 = f32x2{wx[2], wx[3]};
 #pragma unroll
       for (int px = 0; px < 4; ++px) {
-        acc[(PH + 1 + k) % 5][px][0] = v[px + kx][0] * w0 + acc[(PH + 1 + k) % 5][px][0];
-        acc[(PH + 1 + k) % 5][px][1] = v[px + kx][1] * w1 + acc[(PH + 1 + k) % 5][px][1];
+        acc[k][px][0] = v[px + kx][0] * w0 + acc[k][px][0];
+        acc[k][px][1] = v[px + kx][1] * w1 + acc[k][px][1];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef ROMA_DWR_CVT
-  constexpr int DONE = (PH + 1) % 5;  // the accumulator set of output row t - 4
   if (store) {
 #pragma unroll
     for (int px = 0; px < 4; ++px) {
-      // always four stores per row and wave (the counted vmcnt waits rely on it): a column beyond the image is clamped to
-      // this lane's first column, i.e. that column's value is stored a second time
-      const int pc = px < npx ? px : 0;
-      uint2 u;
-      u.x = pack_bf16x2(fmaxf(acc[DONE][pc][0][0], 0.f), fmaxf(acc[DONE][pc][0][1], 0.f));
-      u.y = pack_bf16x2(fmaxf(acc[DONE][pc][1][0], 0.f), fmaxf(acc[DONE][pc][1][1], 0.f));
-      *reinterpret_cast<uint2*>(orow + (long)pc * Cp) = u;
+      if (px < npx) {  // (exec-masked: the instruction is issued for the wave as long as one lane owns column px)
+        uint2 u;
+        u.x = pack_bf16x2(fmaxf(acc[0][px][0][0], 0.f), fmaxf(acc[0][px][0][1], 0.f));
+        u.y = pack_bf16x2(fmaxf(acc[0][px][1][0], 0.f), fmaxf(acc[0][px][1][1], 0.f));
+        *reinterpret_cast<uint2*>(orow + (long)px * Cp) = u;
+      }
     }
   }
 #pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      acc[k][px][0] = acc[k + 1][px][0];
+      acc[k][px][1] = acc[k + 1][px][1];
+    }
+#pragma unroll
   for (int px = 0; px < 4; ++px) {
-    acc[DONE][px][0] = bias0;
-    acc[DONE][px][1] = bias1;
+    acc[4][px][0] = bias0;
+    acc[4][px][1] = bias1;
   }
 }
 
-__global__ __launch_bounds__(256, 1) void dwconv5x5_ring_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void dwconv5x5_ring_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
                                                                 const float* __restrict__ w, const float* __restrict__ bias,
                                                                 int B, int H, int W, int Cp, int SY, int nchunk, int nxg,
-                                                                long ntask, long nblocks) {
-  __shared__ __attribute__((aligned(1024))) unsigned char ring[4 * DWR_NR * DWR_ROWB];
-  const long per_xcd = (nblocks + 7) / 8;  // each XCD owns a contiguous band of tasks (the row halos hit its own L2)
+                                                                long nblocks) {
+  constexpr int NR = DWR_NR;
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[DWR_RING];  // the DMA target: read with inline asm only
+  const long per_xcd = (nblocks + 7) / 8;  // each XCD owns a contiguous band of blocks (the row halos hit its own L2)
   const long lb = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (lb >= nblocks) return;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long task = lb * 4 + wv;
-  if (lb >= nblocks || task >= ntask) return;  // (no barriers in this kernel: a wave may leave on its own)
-  const int chunk = (int)(task % nchunk);
-  long r = task / nchunk;
-  const int xg = (int)(r % nxg);
-  r /= nxg;
+  // block -> (image, strip, group of 4 column tiles, 64-channel chunk), chunk fastest: the four waves take the four
+  // neighbouring column tiles of one chunk (together they read whole rows of 64 + 4 pixels)
+  const int nxg4 = (nxg + 3) / 4;
+  const int chunk = (int)(lb % nchunk);
+  long r = lb / nchunk;
+  const int xg = (int)(r % nxg4) * 4 + wv;
+  r /= nxg4;
   const int yt = (H + SY - 1) / SY;
   const int ys = (int)(r % yt) * SY;
   const int b = (int)(r / yt);
+  if (xg >= nxg) return;  // a column tile beyond the image (last group of four): no barriers, a wave may leave on its own
   const int sy = min(SY, H - ys);
   const int T = sy + 4;  // input rows ys - 2 .. ys + sy + 1
 
   const int cg = lane & 15, xq = lane >> 4;
   const int c = chunk * 64 + cg * 4;
-  const int xb = xg * DWR_PXW + xq * 4;   // first output column of this lane
-  const int x0 = xg * DWR_PXW - 2;        // image column of ring pixel 0
-  const int npx = min(4, W - xb);         // valid output columns of this lane (<= 0: the lane only helps with the DMA)
 
   // ---- tap weights and bias of this lane's 4 channels: registers for the whole strip
   f32x4 wreg[25];
@@ -143,20 +151,27 @@ __global__ __launch_bounds__(256, 1) void dwconv5x5_ring_kernel(const bf16_t* __
   const f32x2 bias0 = f32x2{bx[0], bx[1]}, bias1 = f32x2{bx[2], bx[3]};
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this wave in flight before the counted DMA stream starts
 
+  const int xb = xg * DWR_PXW + xq * 4;   // first output column of this lane
+  const int x0 = xg * DWR_PXW - 2;        // image column of ring pixel 0
+  const int npx = min(4, W - xb);         // valid output columns of this lane (<= 0: the lane only helps with the DMA)
+  // the counted waits assume 4 store instructions per row; in a tile with fewer than 4 valid columns some of them have no
+  // active lane and may be skipped, so such a tile waits conservatively (only the DMA may stay in flight)
+  const bool edge = W - xg * DWR_PXW < 4;
+
   // ---- DMA descriptors: piece p = 64 i + lane of a row -> ring slot p >> 3 (slot s holds pixel s - s / 5, s % 5 == 4
   // stays empty), 16-byte part p & 7 of the pixel's 128-byte channel line
   const char* zsrc = reinterpret_cast<const char*>(g_dwr_zero_page);
   const char* inb = reinterpret_cast<const char*>(in + ((long)b * H * W) * Cp) + (long)chunk * 128;
-  long poff[3];
+  unsigned poff[3];  // byte offset inside an image row (< 2^31: checked by the launcher)
   bool pok[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int p = 64 * i + lane, s = p >> 3, part = p & 7;
     const int x = x0 + s - s / 5;
     pok[i] = (s % 5 != 4) && x >= 0 && x < W;
-    poff[i] = (long)(pok[i] ? x : 0) * Cp * 2 + part * 16;
+    poff[i] = (unsigned)((pok[i] ? x : 0) * Cp * 2 + part * 16);
   }
-  lds_u8* const myring = (lds_u8*)ring + wv * (DWR_NR * DWR_ROWB);
+  lds_u8* const myring = (lds_u8*)ring + wv * (NR * DWR_ROWB);
 #define ROMA_DWR_ISSUE(RROW, SLOT)                                                         \
   {                                                                                        \
     const int yy_ = ys - 2 + (RROW);                                                       \
@@ -180,41 +195,29 @@ __global__ __launch_bounds__(256, 1) void dwconv5x5_ring_kernel(const bf16_t* __
 
   // ---- prologue: rows 0 .. NR - 2 in flight
 #pragma unroll
-  for (int rr = 0; rr < DWR_NR - 1; ++rr) ROMA_DWR_ISSUE(rr, rr);
+  for (int rr = 0; rr < NR - 1; ++rr) ROMA_DWR_ISSUE(rr, rr);
 
-  int slot = 0;        // ring slot of input row t
-  int fill = DWR_NR - 1;  // ring slot the next DMA goes to (= slot of row t - 1)
+  int slot = 0;       // ring slot of input row t
+  int fill = NR - 1;  // ring slot the next DMA goes to (= slot of row t - 1)
   // Row t is complete once at most the operations issued AFTER its DMA are outstanding: the DMA of rows t + 1 .. t + NR - 1
   // (3 each) and the 4 output stores of every iteration s in [t - NR + 1, t - 1] that had an output row (s >= 4).
-#define ROMA_DWR_STEP(PH)                                                                                    \
-  {                                                                                                          \
-    const int t = t0 + (PH);                                                                                 \
-    if (t >= T) break;                                                                                       \
-    ROMA_DWR_ISSUE(t + DWR_NR - 1, fill);                                                                    \
-    const int kst = min(max(t - 4, 0), DWR_NR - 1);                                                          \
-    switch (kst) { /* vmcnt is a 6-bit counter: 27 + 4 * 9 = 63 is its largest value */                      \
-      case 0: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1)); break;                                                     \
-      case 1: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 4); break;                                                 \
-      case 2: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 8); break;                                                 \
-      case 3: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 12); break;                                                \
-      case 4: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 16); break;                                                \
-      case 5: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 20); break;                                                \
-      case 6: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 24); break;                                                \
-      case 7: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 28); break;                                                \
-      case 8: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 32); break;                                                \
-      default: ROMA_DWR_WAIT_VM(3 * (DWR_NR - 1) + 36); break;                                               \
-    }                                                                                                        \
-    const int o = t - 4;                                                                                     \
-    dwr_row<PH>(acc, wreg, bias0, bias1, rd0 + (unsigned)slot * DWR_ROWB, o >= 0 && npx > 0,                  \
-                obase + ((long)(ys + max(o, 0)) * W + xb) * Cp, (long)Cp, npx);                              \
-    fill = slot;                                                                                             \
-    slot = slot + 1 == DWR_NR ? 0 : slot + 1;                                                                \
-  }
+#define ROMA_DWR_WAIT_CASE(K) \
+  case K: ROMA_DWR_WAIT_VM(3 * (NR - 1) + 4 * K); break;
 #pragma nounroll
-  for (int t0 = 0; t0 < T; t0 += 5) {
-    ROMA_DWR_STEP(0) ROMA_DWR_STEP(1) ROMA_DWR_STEP(2) ROMA_DWR_STEP(3) ROMA_DWR_STEP(4)
+  for (int t = 0; t < T; ++t) {
+    ROMA_DWR_ISSUE(t + NR - 1, fill);
+    const int kst = edge ? 0 : min(max(t - 4, 0), NR - 1);
+    switch (kst) {
+      ROMA_DWR_WAIT_CASE(0) ROMA_DWR_WAIT_CASE(1) ROMA_DWR_WAIT_CASE(2) ROMA_DWR_WAIT_CASE(3) ROMA_DWR_WAIT_CASE(4)
+      default: ROMA_DWR_WAIT_VM(3 * (NR - 1) + 4 * (NR - 1)); break;
+    }
+    const int o = t - 4;
+    dwr_row(acc, wreg, bias0, bias1, rd0 + (unsigned)slot * DWR_ROWB, o >= 0 && npx > 0,
+            obase + ((long)(ys + max(o, 0)) * W + xb) * Cp, (long)Cp, npx);
+    fill = slot;
+    slot = slot + 1 == NR ? 0 : slot + 1;
   }
-#undef ROMA_DWR_STEP
+#undef ROMA_DWR_WAIT_CASE
 #undef ROMA_DWR_ISSUE
   ROMA_DWR_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
 }
@@ -227,18 +230,18 @@ int dwconv5x5_ring_try_launch(const void* in, void* out, const float* w, const f
   static const int env = getenv("ROMA_DW_RING") ? atoi(getenv("ROMA_DW_RING")) : 1;
   if (!(g_dw_ring >= 0 ? g_dw_ring : env)) return 1;
   if (dt != DT_BF16 || Cp % 64 != 0 || Cp < 256 || H < 1 || W < 1) return 1;
-  if ((long)H * W * Cp * 2 >= (1l << 31)) return 1;  // (per-image byte offsets stay far below this in the model)
+  if ((long)W * Cp * 2 >= (1l << 31)) return 1;  // 32-bit byte offsets inside an image row
   if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (reinterpret_cast<uintptr_t>(out) & 7) != 0) return 1;
+  if ((reinterpret_cast<uintptr_t>(w) & 15) != 0 || (reinterpret_cast<uintptr_t>(bias) & 15) != 0) return 1;
   const int nchunk = Cp / 64;
   const int nxg = (W + DWR_PXW - 1) / DWR_PXW;
   const int nstrip = (H + 35) / 36;
   const int SY = (H + nstrip - 1) / nstrip;
-  const long ntask = (long)B * ((H + SY - 1) / SY) * nxg * nchunk;
-  const long nblocks = (ntask + 3) / 4;
+  const long nblocks = (long)B * ((H + SY - 1) / SY) * ((nxg + 3) / 4) * nchunk;
   ROMA_REQUIRE(nblocks < (1l << 30), "dwconv5x5: grid too large");
   ProfScope ps("dwconv5x5_kernel<" ROMA_H16_NAME ">", 2.0 * (double)B * H * W * Cp * 2.0, "byte", s);
-  hipLaunchKernelGGL(dwconv5x5_ring_kernel, dim3((unsigned)(((nblocks + 7) / 8) * 8)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out,
-                     w, bias, B, H, W, Cp, SY, nchunk, nxg, ntask, nblocks);
+  hipLaunchKernelGGL(dwconv5x5_ring_kernel, dim3((unsigned)(((nblocks + 7) / 8) * 8)), dim3(256), 0, s, (const bf16_t*)in,
+                     (bf16_t*)out, w, bias, B, H, W, Cp, SY, nchunk, nxg, nblocks);
   ROMA_LAUNCH_CHECK();
   return 0;
 }
