@@ -235,8 +235,22 @@ int dwconv5x5_ring_try_launch(const void* in, void* out, const float* w, const f
   if ((reinterpret_cast<uintptr_t>(w) & 15) != 0 || (reinterpret_cast<uintptr_t>(bias) & 15) != 0) return 1;
   const int nchunk = Cp / 64;
   const int nxg = (W + DWR_PXW - 1) / DWR_PXW;
-  const int nstrip = (H + 35) / 36;
-  const int SY = (H + nstrip - 1) / nstrip;
+  // strip height: a strip of SY rows reads SY + 4 input rows and pays ~3 rows of pipeline fill; 512 workgroups are resident
+  // (two per CU) and take the blocks in rounds - pick the split of H that minimises rounds x (SY + 7)
+  int SY = H;
+  {
+    long best = -1;
+    const long per_strip = (long)B * ((nxg + 3) / 4) * nchunk;
+    for (int ns = (H + 47) / 48; ns <= std::max(1, H / 6); ++ns) {
+      const int sy = (H + ns - 1) / ns;
+      const long nb = per_strip * ((H + sy - 1) / sy);
+      const long cost = ((nb + 511) / 512) * (sy + 7);
+      if (best < 0 || cost < best) {
+        best = cost;
+        SY = sy;
+      }
+    }
+  }
   const long nblocks = (long)B * ((H + SY - 1) / SY) * ((nxg + 3) / 4) * nchunk;
   ROMA_REQUIRE(nblocks < (1l << 30), "dwconv5x5: grid too large");
   ProfScope ps("dwconv5x5_kernel<" ROMA_H16_NAME ">", 2.0 * (double)B * H * W * Cp * 2.0, "byte", s);

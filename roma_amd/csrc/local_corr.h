@@ -25,6 +25,7 @@ struct LocalCorrArgs {
   int* ws = nullptr;
   long ws_bytes = 0;
   int force_gather = 0;
+  int pxmax = 0;               // set by the launcher: largest rectangle (pixels) the tile kernel's LDS stage holds
 };
 extern int g_lc_mode;  // roma_tuning("lc_mode")
 

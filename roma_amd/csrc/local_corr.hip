@@ -181,8 +181,12 @@ constexpr int LC_PITCH = 144;            // bytes per staged pixel: 128 B of cha
 // CU (a unit-scale warp needs 13^2 / 15^2 pixels, so zoom factors up to ~2 (r = 2) / ~1.75 (r = 3) still fit; stronger
 // zooms go to the gather list); r > 3 -> 704 pixels = 110 592 B, one per CU (r = 7: 23^2 = 529 pixels at unit scale).
 // (Three per CU with a 288-pixel stage was tried: 168 VGPRs do not hold the prefetch registers, ~35 spilled.)
-template <int R> struct LcGeom {
-  static constexpr int PXMAX = R <= 3 ? 448 : 704;
+// MFMA form (16-bit features): the accumulators of the all-pairs product are 64 x PXMAX / 256 registers per lane, so with two
+// workgroups per CU (r <= 3) the stage is capped at 320 slots = 10 blocks of 32 (80 accumulator registers next to the 60
+// staging-prefetch registers); its rectangle rows keep their natural pitch (the matrix-core reads go down the slots, the
+// 144-byte slot pitch alone makes them conflict free), so 320 slots hold zooms up to ~1.35 (r = 2) / ~1.2 (r = 3).
+template <int R, bool MFMA = false> struct LcGeom {
+  static constexpr int PXMAX = R <= 3 ? (MFMA ? 320 : 448) : 704;
   static constexpr int NSLOT = PXMAX + LC_TQ * LC_TQ;
   static constexpr int STAGE = NSLOT * LC_PITCH;
   static constexpr int NPRE = (NSLOT * 8 + 255) / 256;  // 16-byte pieces per thread per chunk
@@ -231,12 +235,19 @@ template <> struct LcDot<bf16_t> {  // 64 channels per 128-byte chunk, packed pa
   }
 };
 
-template <int R, typename T, typename TOUT>
+// MFMA = true (16-bit features): instead of (2r+2)^2 dot products per query, each re-reading its f1 pixel from LDS (4 MB
+// of LDS reads per tile at C = 512, r = 3), the tile computes the ALL-PAIRS product  D[rectangle slot][query] =
+// sum_c f1[slot][c] f0[query][c]  on v_mfma_f32_32x32x16 straight from the same 144-byte-pitch stage (every staged row is
+// read once per 32 queries: ~0.3 MB), and every lane - a query - then picks the (2r+2)^2 entries of its own window out of
+// its accumulators.  Wave w owns the 32 queries of tile half w & 1 and the 32-slot blocks (w >> 1), (w >> 1) + 2, ...
+template <int R, typename T, typename TOUT, bool MFMA>
 __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(const LocalCorrArgs a) {
   constexpr int P = 2 * R + 2, KW = 2 * R + 1, K = KW * KW;
   constexpr int NR = (P + 3) / 4;  // patch rows per wave
+  constexpr int NBW = MFMA ? ((LcGeom<R, MFMA>::PXMAX + 31) / 32 + 1) / 2 : 1;  // 32-slot blocks per wave (5 ; 11)
+  static_assert(!MFMA || sizeof(T) == 2, "the MFMA form takes 16-bit features");
   constexpr int CC = LcDot<T>::CC;
-  constexpr int LC_STAGE = LcGeom<R>::STAGE, LC_PXMAX = LcGeom<R>::PXMAX, NPRE = LcGeom<R>::NPRE;
+  constexpr int LC_STAGE = LcGeom<R, MFMA>::STAGE, LC_PXMAX = LcGeom<R, MFMA>::PXMAX, NPRE = LcGeom<R, MFMA>::NPRE;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   // [0, LC_STAGE): staged pixels (f1 rectangle, then the 64 f0 rows); later reused for the D exchange
   int* qx0 = reinterpret_cast<int*>(lds + LC_STAGE);       // [64]
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
   }
   __syncthreads();
   const int bx0 = tinfo[0], by0 = tinfo[1], bw = tinfo[2], bh = tinfo[3];
-  const int bwp = lc_row_pitch(bw, bh, LC_PXMAX);  // slots per staged rectangle row (>= bw, see lc_row_pitch)
+  const int bwp = MFMA ? bw : lc_row_pitch(bw, bh, LC_PXMAX);  // slots per staged rectangle row (>= bw, see lc_row_pitch)
   const long npx = (long)bwp * bh;
   const int simg = (b + a.f1_shift) % a.nimg;
   TOUT* outp = reinterpret_cast<TOUT*>(a.out);
@@ -302,18 +313,26 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
   // ---- coherent tile: stage the rectangle + the f0 rows chunk by chunk, dots from LDS
   const T* f1p = reinterpret_cast<const T*>(a.f1) + (long)simg * HW * a.ld1;
   const T* f0p = reinterpret_cast<const T*>(a.f0) + (long)b * HW * a.ld0;
-  float acc[NR][P];
+  float acc[MFMA ? 1 : NR][MFMA ? 1 : P];
+  f32x16 macc[NBW];
+  if constexpr (MFMA) {
 #pragma unroll
-  for (int i = 0; i < NR; ++i)
+    for (int i = 0; i < NBW; ++i)
 #pragma unroll
-    for (int j = 0; j < P; ++j) acc[i][j] = 0.f;
+      for (int e = 0; e < 16; ++e) macc[i][e] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+      for (int j = 0; j < P; ++j) acc[i][j] = 0.f;
+  }
   const int nslots = (int)npx + LC_TQ * LC_TQ;  // staged rows: f1 rectangle then the tile's f0 rows
   const int my_x = x0 - R - bx0, my_y = y0 - R - by0;  // patch origin inside the rectangle (may be negative: clipped)
   char* f0slot = lds + ((int)npx + lane) * LC_PITCH;
 
   // staging is split (issue early / write late): the global loads of chunk c + 1 are issued before the dots of chunk c
   // and written to LDS after them, so HBM latency hides under the LDS / VALU work of this workgroup too
-  constexpr bool PREFETCH = LcGeom<R>::PREFETCH;
+  constexpr bool PREFETCH = LcGeom<R, MFMA>::PREFETCH;
   constexpr int NP = PREFETCH ? NPRE : 1;
   uint4 pre[NP];
   // per-piece source of chunk 0 as a 32-bit byte offset from its image base (one feature map of one image is far below
@@ -375,7 +394,25 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
           if (poff[k] != 0xffffffffu) pre[k] = *reinterpret_cast<const uint4*>(((from_f0 >> k) & 1u ? f0b : f1b) + poff[k] + coff);
       }
     }
-    if constexpr (sizeof(T) == 2 && R <= 3) {
+    if constexpr (MFMA) {
+      // all-pairs on the matrix core: first operand = 32 rectangle slots (rows), second = this wave's 32 queries (columns);
+      // both fragments are the 16 bytes (8 channels) at (32 ks + 16 h) of a staged 128-byte row.  Blocks beyond the
+      // rectangle are skipped (wave-uniform); the last block may run into the staged f0 rows: finite values, never extracted.
+      const int l31 = lane & 31, hh = lane >> 5;
+      const char* arow = lds + ((int)npx + 32 * (wave & 1) + l31) * LC_PITCH + hh * 16;
+      const char* brow = lds + (32 * (wave >> 1) + l31) * LC_PITCH + hh * 16;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 af = *reinterpret_cast<const uint4*>(arow + ks * 32);
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+          if ((2 * i + (wave >> 1)) * 32 < (int)npx) {
+            const uint4 bf = *reinterpret_cast<const uint4*>(brow + i * (64 * LC_PITCH) + ks * 32);
+            macc[i] = mfma_h16_32x32x16(bf, af, macc[i]);
+          }
+        }
+      }
+    } else if constexpr (sizeof(T) == 2 && R <= 3) {
       // Branch-free per lane: a patch position outside the rectangle reads slot 0 (always staged) and its dot is discarded
       // by a select.  With per-position `if`s every one of the 8 x 16-byte LDS reads of a dot sat in its own exec-masked
       // block and was waited for on its own (149 s_waitcnt for 124 reads in the ISA): the kernel ran at LDS LATENCY,
@@ -422,12 +459,41 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
   }
   // ---- exchange the integer-patch dots through LDS: D[q][r][j] (f32), then the bilinear combination per output tap
   float* Dl = reinterpret_cast<float*>(lds);  // [64][P*P]   (64 * 256 * 4 B = 64 KiB at r = 7)
+  if constexpr (MFMA) {
+    // window entries outside the (clipped) rectangle are zero: clear, then every lane scatters the entries of its query's
+    // window out of its accumulators.  Register e of block nb holds slot 32 nb + 8 (e >> 2) + 4 hh + (e & 3) for query
+    // 32 (wave & 1) + l31 (the C / D layout of the 32 x 32 MFMA); slot -> rectangle (row, column) incrementally.
+    for (int i = tid; i < LC_TQ * LC_TQ * P * P / 4; i += 256) reinterpret_cast<f32x4*>(Dl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int q = 32 * (wave & 1) + l31;
+    const int wx0 = qx0[q] - R - bx0, wy0 = qy0[q] - R - by0;  // window origin inside the rectangle
+    float* dq = Dl + q * (P * P);
 #pragma unroll
-  for (int ri = 0; ri < NR; ++ri) {
-    const int r = wave + 4 * ri;
-    if (r < P) {
+    for (int i = 0; i < NBW; ++i) {
+      const int s0 = (2 * i + (wave >> 1)) * 32 + 4 * hh;
+      if ((2 * i + (wave >> 1)) * 32 < (int)npx) {
+        int py = s0 / bwp, px = s0 - py * bwp;
 #pragma unroll
-      for (int j = 0; j < P; ++j) Dl[lane * (P * P) + r * P + j] = acc[ri][j];
+        for (int e = 0; e < 16; ++e) {
+          const int rr = py - wy0, jj = px - wx0;
+          if (py < bh && px < bw && rr >= 0 && rr < P && jj >= 0 && jj < P) dq[rr * P + jj] = macc[i][e];
+          px += (e & 3) == 3 ? 5 : 1;  // next slot of this lane: +1 inside a run of 4, +5 to the next run (8 apart)
+          while (px >= bwp) {
+            px -= bwp;
+            ++py;
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) {
+      const int r = wave + 4 * ri;
+      if (r < P) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) Dl[lane * (P * P) + r * P + j] = acc[ri][j];
+      }
     }
   }
   __syncthreads();
@@ -485,7 +551,7 @@ __global__ __launch_bounds__(64) void local_corr_classify_kernel(const LocalCorr
     }
     const long bw = max(min(xhi + R + 1, a.W - 1) - max(xlo - R, 0) + 1, 0);
     const long bh = max(min(yhi + R + 1, a.H - 1) - max(ylo - R, 0) + 1, 0);
-    coherent = bw * bh <= LcGeom<R>::PXMAX && !a.force_gather;
+    coherent = bw * bh <= a.pxmax && !a.force_gather;
   }
   const unsigned long long mc = __ballot(valid && coherent), mg = __ballot(valid && !coherent);
   int basec = 0, baseg = 0;
@@ -589,9 +655,9 @@ static int check_common(const LocalCorrArgs& a, int ce) {
   return 0;
 }
 
-int g_lc_mode = -1;  // roma_tuning("lc_mode"): -1 / 0 = tiled + work list (default), 1 = every tile to the gather list, 2 = legacy per-pixel launch
+int g_lc_mode = -1;  // roma_tuning("lc_mode"): -1 / 0 = tiled (MFMA all-pairs for 16-bit features) + work list (default), 1 = every tile to the gather list, 2 = legacy per-pixel launch, 3 = tiled with the VALU dot kernel of round 2
 
-template <int R, typename T, typename TOUT>
+template <int R, typename T, typename TOUT, bool MFMA>
 static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   LocalCorrArgs a = a0;
   const int tiles = a.B * ((a.H + LC_TQ - 1) / LC_TQ) * ((a.W + LC_TQ - 1) / LC_TQ);
@@ -605,19 +671,20 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   }
   a.force_gather = g_lc_mode == 1 ? 1 : 0;
   ROMA_CHECK_HIP(hipMemsetAsync(a.ws, 0, 4 * sizeof(int), stream));
-  const size_t lds_tile = (size_t)LcGeom<R>::STAGE + 4 * 64 * 4 + 32;
+  const size_t lds_tile = (size_t)LcGeom<R, MFMA>::STAGE + 4 * 64 * 4 + 32;
+  a.pxmax = LcGeom<R, MFMA>::PXMAX;  // what the classifier calls a coherent tile: its rectangle fits this kernel's stage
   static bool attr_set[64] = {false};
   int dev = 0;
   ROMA_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_tile_kernel<R, T, TOUT>),
+    ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_tile_kernel<R, T, TOUT, MFMA>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL((local_corr_classify_kernel<R>), dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, stream, a);
   ROMA_LAUNCH_CHECK();
   // (capping this launch at 1024 workgroups - the kernel strides over the list - changes nothing either way: measured)
-  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT>), dim3((unsigned)tiles), dim3(256), lds_tile, stream, a);
+  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT, MFMA>), dim3((unsigned)tiles), dim3(256), lds_tile, stream, a);
   ROMA_LAUNCH_CHECK();
   hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
                      stream, a);
@@ -643,10 +710,14 @@ static int launch_window_r(const LocalCorrArgs& a, hipStream_t stream) {
   // per-pixel kernel
   if constexpr (R == 2 || R == 3 || R == 7) {
     if (mode != 2 && a.C % cc == 0) {
-      if (a.in_dt == DT_F32 && a.out_dt == DT_F32) return launch_tiled<R, float, float>(a, stream);
-      if (a.in_dt == DT_F32) return launch_tiled<R, float, bf16_t>(a, stream);
-      if (a.out_dt == DT_F32) return launch_tiled<R, bf16_t, float>(a, stream);
-      return launch_tiled<R, bf16_t, bf16_t>(a, stream);
+      if (a.in_dt == DT_F32 && a.out_dt == DT_F32) return launch_tiled<R, float, float, false>(a, stream);
+      if (a.in_dt == DT_F32) return launch_tiled<R, float, bf16_t, false>(a, stream);
+      if (mode == 3) {  // A/B: the VALU (v_dot2) tile kernel of round 2 for 16-bit features
+        if (a.out_dt == DT_F32) return launch_tiled<R, bf16_t, float, false>(a, stream);
+        return launch_tiled<R, bf16_t, bf16_t, false>(a, stream);
+      }
+      if (a.out_dt == DT_F32) return launch_tiled<R, bf16_t, float, true>(a, stream);
+      return launch_tiled<R, bf16_t, bf16_t, true>(a, stream);
     }
   }
 #define ROMA_LC(T, TOUT) hipLaunchKernelGGL((local_corr_window_kernel<R, T, TOUT>), grid, dim3(256), lds, stream, a)

@@ -6,8 +6,9 @@
              ~12 of 40 tokens): each query needs its own (2r+2)^2 x C patch, (2r+2)^2 x the algorithmic bytes from
              L2 / Infinity Cache whatever the kernel does -> the tiles go to the per-query gather work list
 
-Modes (roma_tuning "lc_mode"): 0 = tiled + work list (default), 1 = every tile forced onto the gather work list (isolates
-the list kernel against the per-pixel kernel on identical work), 2 = the per-pixel kernel of round 1.
+Modes (roma_tuning "lc_mode"): 0 = tiled (16-bit features: all-pairs on the matrix core, round 3) + work list (default),
+3 = tiled with the v_dot2 kernel of round 2, 1 = every tile forced onto the gather work list (isolates the list kernel
+against the per-pixel kernel on identical work), 2 = the per-pixel kernel of round 1.
 Reports ms and ALGORITHMIC GB/s = (f0 + f1 read once + warp + outputs) / time.
 
     gpurun --timeout 300 -- 'python tools/bench_local_corr.py > gpurun_out/bench_local_corr.log 2>&1'
@@ -51,7 +52,8 @@ def run(r, c, h, w, B, regime, dt):
     es = 2.0 if dt == BF16 else 4.0
     alg_bytes = B * h * w * (2.0 * c * es + 8.0 + K * es)
     res = {}
-    for mode in (0, 1, 2):
+    names = {0: "tiled", 3: "tiled_valu_round2", 1: "all_to_gather_list", 2: "per_pixel"}
+    for mode in (0, 3, 1, 2):
         lib.roma_tuning(b"lc_mode", mode)
 
         def call():
@@ -69,9 +71,10 @@ def run(r, c, h, w, B, regime, dt):
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / 3)
         ms = statistics.median(ts)
-        res[("tiled", "all_to_gather_list", "per_pixel")[mode]] = {"ms": ms, "algorithmic_GBs": alg_bytes / (ms * 1e-3) / 1e9}
+        res[names[mode]] = {"ms": round(ms, 4), "algorithmic_GBs": round(alg_bytes / (ms * 1e-3) / 1e9)}
         res["out_" + str(mode)] = out.float().clone()
     res.pop("out_1")
+    res.pop("out_3")
     d = float((res.pop("out_0") - res.pop("out_2")).abs().max())
     lib.roma_tuning(b"lc_mode", -1)
     print(json.dumps({"r": r, "C": c, "hw": [h, w], "B": B, "dtype": "bf16" if dt == BF16 else "f32", "warp": regime,
