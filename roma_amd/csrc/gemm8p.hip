@@ -458,8 +458,11 @@ int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
   if (a.K % 64 != 0 || a.K < 4 * 64 || a.K > 32704) return 1;
   const bool conv = a.conv_c > 0;
   if (conv && (a.conv_c % 64 != 0 || a.conv_c > 512)) return 1;
-  // shapes gemm.hip would run on 256 x 256 tiles
-  const bool big_m = (long)a.M >= 8192;
+  // shapes gemm.hip would run on 256 x 256 tiles; for a single pair (M = 3 202 token rows, BASELINE config 2) the wide
+  // launches (qkv, fc1: N >= 2048, 150-210 tiles of 256 x 256) are still better off on this kernel's pipelined loop with
+  // part of the CUs idle than on gemm.hip's 128 x 128 loop at one wave per SIMD (ROMA_GEMM8P_MINM: A/B)
+  static const long minm_env = getenv("ROMA_GEMM8P_MINM") ? atol(getenv("ROMA_GEMM8P_MINM")) : 2048;
+  const bool big_m = (long)a.M >= 8192 || ((long)a.M >= minm_env && a.N >= 2048 && !conv);
   if (!big_m) return 1;
   bool tile256 = false;
   if (a.N >= 384) {

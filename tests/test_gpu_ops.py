@@ -102,7 +102,8 @@ def test_gemm_bf16(lib, M, N, K):
 
 
 # ------------------------------------------------------------------ big-M bf16 shapes (persistent 8-wave 256 x 256 tiles)
-@pytest.mark.parametrize("M,N,K", [(8192 + 37, 640, 192), (8448, 512, 64), (70000, 1024, 128), (9000, 768, 1024), (25616, 1024, 4096)])
+@pytest.mark.parametrize("M,N,K", [(8192 + 37, 640, 192), (8448, 512, 64), (70000, 1024, 128), (9000, 768, 1024), (25616, 1024, 4096),
+                                   (3202, 4096, 1024), (3202, 3072, 1024)])  # single-pair token rows on the 8-phase kernel (N >= 2048)
 def test_gemm_big_m_bf16(lib, M, N, K):
     """The persistent 8-wave kernel with the carried last k-group: ragged last m-tile, partial n-tile (640), a single
     K slab, several tiles per persistent workgroup (70000 x 1024), long K.  Run twice (timing-dependent races)."""
