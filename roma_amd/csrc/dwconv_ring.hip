@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void dwconv5x5_ring_kernel(const bf16_t* __
   ROMA_DWR_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
 }
 
-int g_dw_ring = -1;  // roma_tuning("dw_ring", v): 1 = this kernel for the shapes it takes (default), 0 = dwconv5x5_kernel, -1 = env ROMA_DW_RING
+int g_dw_ring = -1;  // roma_tuning("dw_ring", v): 1 = this kernel for the large launches it is faster on (default), 2 = for every shape it takes, 0 = dwconv5x5_kernel, -1 = env ROMA_DW_RING
 
 // 0 = launched, 1 = not this kernel's problem, < 0 = error
 int dwconv5x5_ring_try_launch(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp, int dt,
@@ -253,6 +253,11 @@ int dwconv5x5_ring_try_launch(const void* in, void* out, const float* w, const f
   }
   const long nblocks = (long)B * ((H + SY - 1) / SY) * ((nxg + 3) / 4) * nchunk;
   ROMA_REQUIRE(nblocks < (1l << 30), "dwconv5x5: grid too large");
+  // Coarse tasks (a wave = 64 channels x 16 columns x a whole strip) need a large problem: below ~4 rounds of the 512
+  // resident workgroups the finer-grained register-prefetch kernel wins (16 x 140 x 140 x 576: 0.206 vs 0.223 ms,
+  // 16 x 70 x 70 x 1152: 0.130 vs 0.140; 16 x 216 x 216 x 576: 0.443 vs 0.430, 16 x 108 x 108 x 1152: 0.251 vs 0.218 -
+  // profiles/r03_v7_visit.log), so the pass-1 refiners stay on it.  ROMA_DW_RING=2 forces this kernel (tests, A/B).
+  if ((g_dw_ring >= 0 ? g_dw_ring : env) != 2 && nblocks < 2000) return 1;
   ProfScope ps("dwconv5x5_kernel<" ROMA_H16_NAME ">", 2.0 * (double)B * H * W * Cp * 2.0, "byte", s);
   hipLaunchKernelGGL(dwconv5x5_ring_kernel, dim3((unsigned)(((nblocks + 7) / 8) * 8)), dim3(256), 0, s, (const bf16_t*)in,
                      (bf16_t*)out, w, bias, B, H, W, Cp, SY, nchunk, nxg, nblocks);

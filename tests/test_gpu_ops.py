@@ -541,7 +541,7 @@ def test_dwconv5x5_ring_is_bit_identical(lib, Cp, B, H, W):
     x, w, b = rnd(B, H, W, Cp, seed=1).bfloat16().cuda(), rnd(25, Cp, seed=2, std=0.2).cuda(), rnd(Cp, seed=3).cuda()
     outs = {}
     try:
-        for mode in (0, 1, 1, 1):
+        for mode in (0, 2, 2, 2):  # 2 = the ring kernel for every shape it takes (1, the default, keeps small launches on the old kernel)
             lib.roma_tuning(b"dw_ring", mode)
             out = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=torch.bfloat16)
             ok(lib, lib.roma_op_dwconv5x5(P(x), P(out), P(w), P(b), B, H, W, Cp, BF16, None))
@@ -551,8 +551,8 @@ def test_dwconv5x5_ring_is_bit_identical(lib, Cp, B, H, W):
             outs[mode] = out
     finally:
         lib.roma_tuning(b"dw_ring", -1)
-    assert torch.isfinite(outs[1].float()).all()
-    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), float((outs[0].float() - outs[1].float()).abs().max())
+    assert torch.isfinite(outs[2].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16)), float((outs[0].float() - outs[2].float()).abs().max())
 
 
 @pytest.mark.parametrize("Cp,B,H,W", [(24, 2, 13, 10), (24, 1, 75, 301), (24, 1, 290, 150), (144, 2, 13, 10), (144, 1, 41, 59),
