@@ -572,10 +572,11 @@ __global__ __launch_bounds__(64) void local_corr_classify_kernel(const LocalCorr
 // wave.  The launch covers every tile of the call; blocks beyond the list exit at once.  (Persistent workgroups pulling
 // work with atomics were measured 1.6x slower: a single counter word saturates at ~90 dequeues / us, and pulling whole
 // tiles instead serialises 16 latency-bound rounds per workgroup.)
-template <int R, typename T, typename TOUT>
-__global__ __launch_bounds__(256) void local_corr_list_kernel(const LocalCorrArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float f0s[];  // [4 waves][C]
-  const int li = blockIdx.x >> 4, rnd = blockIdx.x & 15;
+template <int R, typename T, typename TOUT, int NW>
+__global__ __launch_bounds__(64 * NW) void local_corr_list_kernel(const LocalCorrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float f0s[];  // [NW waves][C]
+  constexpr int RPT = 64 / NW;  // workgroups ("rounds") per tile: NW = 4 -> 16, NW = 8 -> 8
+  const int li = blockIdx.x / RPT, rnd = blockIdx.x % RPT;
   // both scalar loads are issued before either is waited for (the list has one slot per tile of the call, so the second
   // address is valid whatever the count is): one L2 round trip at the head of every workgroup instead of two dependent ones
   const int nlist = a.ws[0];
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(256) void local_corr_list_kernel(const LocalCorrArg
   const int b = tile / tpi;
   const int trem = tile - b * tpi;
   const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-  const int q = rnd * 4 + wave;
+  const int q = rnd * NW + wave;
   const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
   const bool act = gy < a.H && gx < a.W;
   const long pix = (long)b * a.H * a.W + (long)gy * a.W + gx;
@@ -686,8 +687,15 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   // (capping this launch at 1024 workgroups - the kernel strides over the list - changes nothing either way: measured)
   hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT, MFMA>), dim3((unsigned)tiles), dim3(256), lds_tile, stream, a);
   ROMA_LAUNCH_CHECK();
-  hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
-                     stream, a);
+  // gather list: one query per wave.  Every workgroup starts with two dependent scalar loads (list length, its tile): with
+  // four queries per workgroup that header is 10-20 % of its life, so eight waves share one (ROMA_LC_LISTW=4: the old form)
+  static const int listw_env = getenv("ROMA_LC_LISTW") ? atoi(getenv("ROMA_LC_LISTW")) : 8;
+  if (listw_env == 4)
+    hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT, 4>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
+                       stream, a);
+  else
+    hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT, 8>), dim3((unsigned)tiles * 8u), dim3(512), (size_t)8 * a.C * sizeof(float),
+                       stream, a);
   ROMA_LAUNCH_CHECK();
   if (own_ws) ROMA_CHECK_HIP(hipFreeAsync(a.ws, stream));
   return 0;

@@ -87,11 +87,20 @@ def test_conv1_1_from_f32_image_f16(lib16):
 def test_dwconv5x5_f16(lib16, Cp, B, H, W):
     x, w, b = rnd(B, Cp, H, W, seed=1).half(), rnd(Cp, 1, 5, 5, seed=2, std=0.2), rnd(Cp, seed=3)
     ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=2, groups=Cp)).permute(0, 2, 3, 1)
-    out = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=torch.float16)
     wp = w.reshape(Cp, 25).T.contiguous().cuda()
-    ok(lib16, lib16.roma_op_dwconv5x5(P(x.permute(0, 2, 3, 1).contiguous().cuda()), P(out), P(wp), P(b.cuda()), B, H, W, Cp, F16, None))
-    torch.cuda.synchronize()
-    err = (out.cpu().double() - ref).abs()
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    outs = []
+    try:
+        for mode in (0, 2):  # register-prefetch kernel / wave-private ring kernel (dwconv_ring.hip): bit-identical
+            lib16.roma_tuning(b"dw_ring", mode)
+            out = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=torch.float16)
+            ok(lib16, lib16.roma_op_dwconv5x5(P(xin), P(out), P(wp), P(b.cuda()), B, H, W, Cp, F16, None))
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        lib16.roma_tuning(b"dw_ring", -1)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    err = (outs[1].cpu().double() - ref).abs()
     assert bool((err <= 2.5e-3 * (1.0 + ref.abs())).all()), float(err.max())
 
 

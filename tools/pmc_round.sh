@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 export ROMA_STREAMS=1   # per-launch traffic of the full-batch launches, like bench.py's instrumented roofline pass
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o pmc -- python "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > "$OUT/pmc_$C.log" 2>&1
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o pmc -- python "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-other-configs > "$OUT/pmc_$C.log" 2>&1
   ls "$OUT/pmc_$C" | head
 done
 cd "$REPO"

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 export ROMA_STREAMS=1   # counters per full-batch launch, like the instrumented roofline pass
 cd /tmp
 CNT="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
-timeout 900 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/pmc_sq" -o pmc -- python "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > "$OUT/pmc_sq.log" 2>&1
+timeout 900 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/pmc_sq" -o pmc -- python "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-other-configs > "$OUT/pmc_sq.log" 2>&1
 tail -3 "$OUT/pmc_sq.log"
 cd "$REPO"
 python - <<'PY'

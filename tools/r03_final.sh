@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round-3 closing GPU visit: the ONE script that regenerates the committed r03_final_* artefacts.
+#   full GPU suite, default bench (two streams; parity; configs 2 / 5 / f16; coherent-warp leg; checked CPU baseline),
+#   single-stream bench, rocprofv3 kernel stats of the bench, HBM traffic (PMC) and SQ counter passes.
+set -u
+OUT=$PWD/gpurun_out/final
+REPO=$PWD
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+echo "== full GPU suite"
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -30 > "$OUT/pytest_gpu.log"; tail -5 "$OUT/pytest_gpu.log"
+cp gpurun_out/parity_report.json "$OUT/" 2>/dev/null
+echo "== bench (default)"
+timeout 900 python bench.py --steps 20 --warmup 3 > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"; tail -1 "$OUT/bench_bf16.err" | cut -c1-200; cut -c1-300 "$OUT/bench_bf16.json"
+echo "== bench, one stream"
+timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-other-configs --streams 1 > "$OUT/bench_bf16_1stream.json" 2> "$OUT/bench_bf16_1stream.err"; cut -c1-240 "$OUT/bench_bf16_1stream.json"
+echo "== gather-list kernel: 4 vs 8 waves per workgroup"
+for lw in 8 4; do
+  ROMA_LC_LISTW=$lw timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-other-configs > "$OUT/bench_listw$lw.json" 2> "$OUT/bench_listw$lw.err"
+  python -c "
+import json; r=json.load(open('$OUT/bench_listw$lw.json')); k=r['kernels']
+print('listw $lw', round(r['value'],2), 'pairs/s', {n:round(v['ms_per_step'],3) for n,v in k.items() if n.startswith('local_corr')})"
+done
+echo "== kernel trace of the bench"
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-other-configs --streams 1 > "$OUT/prof.log" 2>&1
+cd "$REPO"
+for f in $(find "$OUT/prof" -name "*kernel_stats.csv"); do head -14 "$f" | cut -c1-170; cp "$f" "$OUT/bench_bf16_kernel_stats.csv"; done
+find "$OUT/prof" -name "*kernel_trace.csv" -delete; find "$OUT/prof" -name "*agent_info.csv" -delete
+echo "== PMC: HBM traffic"
+bash tools/pmc_round.sh > "$OUT/pmc_round.log" 2>&1; tail -8 "$OUT/pmc_round.log" | cut -c1-200
+cp gpurun_out/pmc_summary.json "$OUT/" 2>/dev/null
+echo "== PMC: SQ"
+bash tools/pmc_sq_round.sh > "$OUT/pmc_sq_round.log" 2>&1; tail -14 "$OUT/pmc_sq_round.log" | cut -c1-200
+cp gpurun_out/pmc_sq_summary.json "$OUT/" 2>/dev/null
+echo "== done"
