@@ -687,10 +687,11 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   // (capping this launch at 1024 workgroups - the kernel strides over the list - changes nothing either way: measured)
   hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT, MFMA>), dim3((unsigned)tiles), dim3(256), lds_tile, stream, a);
   ROMA_LAUNCH_CHECK();
-  // gather list: one query per wave.  Every workgroup starts with two dependent scalar loads (list length, its tile): with
-  // four queries per workgroup that header is 10-20 % of its life, so eight waves share one (ROMA_LC_LISTW=4: the old form)
-  static const int listw_env = getenv("ROMA_LC_LISTW") ? atoi(getenv("ROMA_LC_LISTW")) : 8;
-  if (listw_env == 4)
+  // gather list: one query per wave, four per workgroup.  (Eight waves per workgroup - to share the two dependent scalar
+  // loads at the head of every workgroup - were measured SLOWER on the benchmark model's incoherent warps: 1.86 vs 1.60 ms
+  // at r = 2, 0.96 vs 0.91 at r = 3, profiles/r03_final_visit.log; ROMA_LC_LISTW=8 keeps the variant for A/B.)
+  static const int listw_env = getenv("ROMA_LC_LISTW") ? atoi(getenv("ROMA_LC_LISTW")) : 4;
+  if (listw_env != 8)
     hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT, 4>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
                        stream, a);
   else

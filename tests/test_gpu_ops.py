@@ -555,6 +555,36 @@ def test_dwconv5x5_ring_is_bit_identical(lib, Cp, B, H, W):
     assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16)), float((outs[0].float() - outs[2].float()).abs().max())
 
 
+def test_dwconv5x5_ring_repeated_launches_under_load(lib):
+    """The ring kernel's only ordering between a wave's LDS-DMA and its LDS reads is a counted s_waitcnt: 200 launches of a
+    benchmark-sized problem (16 x 108 x 108 x 1152: ~2 300 workgroups, 4.5 rounds), back to back with a GEMM on a second
+    stream competing for the memory system, must all reproduce the register-prefetch kernel's output bit for bit."""
+    B, H, W, Cp = 16, 108, 108, 1152
+    x, w, b = rnd(B, H, W, Cp, seed=11).bfloat16().cuda(), rnd(25, Cp, seed=12, std=0.2).cuda(), rnd(Cp, seed=13).cuda()
+    A, Wg = rnd(8192, 1024, seed=14).bfloat16().cuda(), rnd(1024, 1024, seed=15, std=0.03).bfloat16().cuda()
+    Cg = torch.empty(8192, 1024, device="cuda", dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    try:
+        lib.roma_tuning(b"dw_ring", 0)
+        ref = torch.empty((B, H, W, Cp), device="cuda", dtype=torch.bfloat16)
+        ok(lib, lib.roma_op_dwconv5x5(P(x), P(ref), P(w), P(b), B, H, W, Cp, BF16, None))
+        torch.cuda.synchronize()
+        lib.roma_tuning(b"dw_ring", 1)
+        out = torch.empty_like(ref)
+        bad = 0
+        for it in range(200):
+            if it % 4 == 0:
+                ok(lib, lib.roma_op_gemm(P(A), 1024, P(Wg), 1024, P(Cg), 1024, 8192, 1024, 1024, 1, 0, 0, 0, None, None, None, 0, 0, 1.0,
+                                         BF16, BF16, C.c_void_p(side.cuda_stream)))
+            out.fill_(float("nan"))
+            ok(lib, lib.roma_op_dwconv5x5(P(x), P(out), P(w), P(b), B, H, W, Cp, BF16, None))
+            bad += int(not torch.equal(out.view(torch.int16), ref.view(torch.int16)))
+        torch.cuda.synchronize()
+    finally:
+        lib.roma_tuning(b"dw_ring", -1)
+    assert bad == 0, f"{bad} of 200 launches differ"
+
+
 @pytest.mark.parametrize("Cp,B,H,W", [(24, 2, 13, 10), (24, 1, 75, 301), (24, 1, 290, 150), (144, 2, 13, 10), (144, 1, 41, 59),
                                       (144, 1, 262, 31), (144, 5, 70, 280), (24, 3, 3, 200), (144, 2, 1, 30)])
 def test_refiner_block_fused(lib, Cp, B, H, W):
