@@ -47,7 +47,11 @@ def main(argv):
     objs = [a for a in argv if not a.startswith("--")] or sorted(glob.glob(os.path.join(ROOT, "roma_amd", "csrc", "build", "*.o")))
     n = 0
     for obj in objs:
-        for k in kernels(obj):
+        try:
+            ks = kernels(obj)
+        except RuntimeError:  # host-only object (api.o): no gfx950 code object inside
+            continue
+        for k in ks:
             if only_spills and k["spill"] == 0:
                 continue
             n += 1
