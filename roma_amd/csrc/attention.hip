@@ -306,6 +306,210 @@ __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_bf16_kernel(const 
 
 #undef ROMA_ATTN_FETCH
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Version 2 of the 16-bit kernel (the default; roma_tuning("attn_v", 1) keeps the kernel above for A/B).
+//
+// The kernel above is bound by its VALU work, not by the matrix cores: per 64-key tile and wave, 16 MFMAs (512 cycles)
+// stand beside ~165 plain VALU instructions + 33 v_exp (profiles/r03_pmc_sq_summary.json: MFMA busy 0.37, the waves wait
+// on instruction issue 0.44).  Three of its four O(tile) VALU passes are removed here:
+//   * "s - m" (32 v_sub): the running reference m_ref enters the score MFMAs through their C operand - a 16-register
+//     block holding -m_ref - so the accumulators come out as q.k - m_ref and go straight into v_exp;
+//   * "o *= alpha" (16 v_pk_mul) and the per-tile alpha: m_ref is only moved when some query of the wave has a score more
+//     than THR = 2^8 above it (or on the first tile).  Until then P = 2^(s - m_ref) <= 256 - well inside bf16 / f16 -
+//     and numerator and denominator carry the same factor 2^(-m_ref), which cancels in O / l.  The decision is taken
+//     after the previous tile's P.V is complete and before this tile's P is exponentiated, so everything at the old
+//     reference (O, l) is scaled exactly once and nothing at the new one is;
+//   * (the row sums were also tried on the matrix cores - l as one more row block of the P.V product, an A fragment whose
+//     row 0 is all ones: 4 more MFMAs and 16 more registers per tile for 32 v_add less.  Slower at both head sizes,
+//     5.37 -> 5.48 ms and 1.10 -> 1.14 ms per step (profiles/r03_v9_attention.log): with the three passes above gone the
+//     loop is no longer short of VALU slots.  Not kept.)
+// The K / V tiles are double buffered in LDS (one barrier per tile instead of two).  Also measured and not kept: all V^T
+// fragments of a tile requested before the softmax instead of one right before each MFMA - no change at three workgroups
+// per CU (5.239 vs 5.248 ms, profiles/r03_v11_attention.log), and slower when the 32 extra registers cost the third workgroup (v2 / v1 = 0.956 instead of 0.907, profiles/r03_v10_attention.log).
+// K / V addressing is a uniform tile pointer + a per-thread 32-bit offset (the kernel above rebuilt 64-bit addresses
+// every tile and spilled 8-10 registers at its 128-register cap).
+__device__ __forceinline__ float attn_max_halves(float t) {  // max of lane i and lane i ^ 32, in both
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#else
+  return t;
+#endif
+}
+
+template <int HD, typename TOUT, bool EXP2>
+__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_h16_v2_kernel(const AttnArgs a) {
+  constexpr int KV = 64;
+  constexpr int KS = HD + 8, VS = KV + 4;  // LDS row pitches, as above
+  constexpr int KT = KV / 32, DT = HD / 32, NS = HD / 16;
+  constexpr float THR = EXP2 ? 8.f : 5.5f;  // the same factor (2^8 ~ e^5.5) in either exponent domain
+  // two tile buffers: tile t + 1 is staged while tile t is computed - ONE barrier per tile (36 / 70 KiB per workgroup)
+  __shared__ __attribute__((aligned(16))) bf16_t Ksb[2][KV * KS];
+  __shared__ __attribute__((aligned(16))) bf16_t Vsb[2][HD * VS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  int qt, head, b;
+  if (!attn_decode_block(a, qt, head, b)) return;
+  const long bh = (long)b * a.heads + head;
+  const int qi = qt * 128 + wave * 32 + l31;
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (bh * a.npad) * HD;
+  const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (bh * a.npad) * HD;
+  const bf16_t* Vt = reinterpret_cast<const bf16_t*>(a.vt) + (bh * HD) * a.npad;
+
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+  u32x4_t qf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const u32x4_t*>(Q + (long)qi * HD + 16 * s + 8 * h);
+
+  f32x16 o[DT], cneg;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[d][r] = 0.f;
+    cneg[r] = 0.f;
+  }
+  float m_ref = 0.f, l_run = 0.f;
+
+  // tile = 64 keys: K rows are one contiguous 64 x HD block; V^T is HD rows of 64 consecutive keys
+  constexpr int NKC = KV * (HD / 8) / 256, NVC = HD * (KV / 8) / 256;  // 16-byte pieces per thread
+  unsigned voff[NVC];  // element offset of this thread's V^T pieces inside the (b, head) slab (< 2^31: HD * npad elements)
+#pragma unroll
+  for (int i = 0; i < NVC; ++i) {
+    const int idx = tid + 256 * i;
+    voff[i] = (unsigned)(idx / (KV / 8)) * (unsigned)a.npad + (unsigned)(idx % (KV / 8)) * 8u;
+  }
+  u32x4_t kreg[NKC], vreg[NVC];
+#define ROMA_ATTN_FETCH2(KV0)                                                                      \
+  {                                                                                                \
+    const bf16_t* kt_ = K + (long)(KV0) * HD; /* uniform */                                        \
+    const bf16_t* vt_ = Vt + (KV0);                                                                \
+    _Pragma("unroll") for (int i = 0; i < NKC; ++i)                                                \
+        kreg[i] = *reinterpret_cast<const u32x4_t*>(kt_ + (unsigned)(tid * 8 + 2048 * i));         \
+    _Pragma("unroll") for (int i = 0; i < NVC; ++i)                                                \
+        vreg[i] = *reinterpret_cast<const u32x4_t*>(vt_ + voff[i]);                                \
+  }
+#define ROMA_ATTN_STAGE(BUF)                                                                        \
+  {                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < NKC; ++i) {                                              \
+      const int idx = tid + 256 * i;                                                               \
+      const int row = idx / (HD / 8), c8 = idx % (HD / 8);                                         \
+      *reinterpret_cast<u32x4_t*>(&Ksb[BUF][row * KS + c8 * 8]) = kreg[i];                         \
+    }                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NVC; ++i) {                                              \
+      const int idx = tid + 256 * i;                                                               \
+      const int row = idx / (KV / 8), c8 = idx % (KV / 8);                                         \
+      *reinterpret_cast<u32x2_t*>(&Vsb[BUF][row * VS + c8 * 8]) = u32x2_t{vreg[i].x, vreg[i].y};   \
+      *reinterpret_cast<u32x2_t*>(&Vsb[BUF][row * VS + c8 * 8 + 4]) = u32x2_t{vreg[i].z, vreg[i].w}; \
+    }                                                                                              \
+  }
+  ROMA_ATTN_FETCH2(0);
+  ROMA_ATTN_STAGE(0);
+  ROMA_ATTN_FETCH2(min(KV, a.npad - KV));  // (unconditional fetches: a conditional one made hipcc keep the registers in scratch;
+  __syncthreads();                         //  past the end they re-read the last tile)
+  int cur = 0;
+  for (int kv0 = 0; kv0 < a.N; kv0 += KV, cur ^= 1) {
+    // stage tile t + 1 into the other buffer: every wave finished reading it (tile t - 1) before the barrier that ended
+    // the previous iteration; its loads were issued a whole tile ago
+    ROMA_ATTN_STAGE(cur ^ 1);
+    ROMA_ATTN_FETCH2(min(kv0 + 2 * KV, a.npad - KV));
+    const bf16_t* const Ks = Ksb[cur];
+    const bf16_t* const Vs = Vsb[cur];
+    f32x16 s[KT];
+    // the two 32-key chains interleaved: consecutive MFMAs never depend on each other
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(&Ks[(32 * kt + l31) * KS + 16 * st + 8 * h]);
+        s[kt] = mfma_h16_32x32x16(kf, qf[st], st == 0 ? cneg : s[kt]);  // scores relative to m_ref
+      }
+    }
+    if (kv0 + KV > a.N) {  // only the last tile has keys >= N to mask (uniform branch)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (key >= a.N) s[kt][r] = -INFINITY;
+        }
+    }
+    float tm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // four independent v_max3 chains, not one of 17
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tm[(2 * kt + (r >> 3)) & 3] = fmaxf(tm[(2 * kt + (r >> 3)) & 3], s[kt][r]);
+    float tmax = attn_max_halves(fmaxf(fmaxf(tm[0], tm[1]), fmaxf(tm[2], tm[3])));
+    const bool first = kv0 == 0;
+    if (__builtin_amdgcn_ballot_w64(first || tmax > THR) != 0) {  // wave-uniform: move the reference (rare after tile 0)
+      const float delta = first ? tmax : fmaxf(tmax, 0.f);
+      if (!first) {  // O and l are still zero on the first tile (and alpha could overflow there)
+        const float alpha = EXP2 ? __builtin_amdgcn_exp2f(-delta) : __expf(-delta);
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        l_run *= alpha;
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
+      m_ref += delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cneg[r] = -m_ref;
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = EXP2 ? __builtin_amdgcn_exp2f(s[kt][r]) : __expf(s[kt][r]);
+    {  // row sums: four independent chains (one 32-deep chain of dependent adds is ~1.7 x slower to issue)
+      float ls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ls[r & 3] += s[kt][r];
+      l_run += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x4_t pk;
+        pk.x = pack_bf16x2(s[kt][8 * u + 0], s[kt][8 * u + 1]);
+        pk.y = pack_bf16x2(s[kt][8 * u + 2], s[kt][8 * u + 3]);
+        pk.z = pack_bf16x2(s[kt][8 * u + 4], s[kt][8 * u + 5]);
+        pk.w = pack_bf16x2(s[kt][8 * u + 6], s[kt][8 * u + 7]);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const bf16_t* vrow = &Vs[(32 * d + l31) * VS + 32 * kt + 16 * u + 4 * h];
+          const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(vrow);
+          const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(vrow + 8);
+          o[d] = mfma_h16_32x32x16(u32x4_t{lo.x, lo.y, hi.x, hi.y}, pk, o[d]);
+        }
+      }
+    __syncthreads();
+  }
+  float l = l_run;
+  l += __shfl_xor(l, 32);
+  const float inv = 1.f / l;
+  if (qi < a.N) {
+    TOUT* O = reinterpret_cast<TOUT*>(a.out) + ((long)b * a.N + qi) * a.ldo + head * HD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = o[d][4 * rg + j] * inv;
+        ElemIO<TOUT>::st4(O + 32 * d + 8 * rg + 4 * h, v);
+      }
+  }
+}
+#undef ROMA_ATTN_STAGE
+#undef ROMA_ATTN_FETCH2
+
+int g_attn_version = -1;  // roma_tuning("attn_v", v): 2 = attn_h16_v2_kernel (default), 1 = attn_bf16_kernel, -1 = env ROMA_ATTN_V
 int g_attn_xcd_map = -1;  // roma_tuning("attn_xcd", v): 1 = per-XCD bands of (b, head) (default), 0 = plain order, -1 = env ROMA_ATTN_XCD
 
 int attention_launch(const AttnArgs& a_in, hipStream_t stream) {
@@ -322,9 +526,14 @@ int attention_launch(const AttnArgs& a_in, hipStream_t stream) {
   snprintf(pname, sizeof pname, "attn_%s_kernel<%d>", a.in_dt == DT_F32 ? "f32" : ROMA_H16_NAME, a.hd);
   ProfScope ps(pname, 4.0 * (double)a.B * a.heads * (double)a.N * a.N * a.hd, "flop", stream);
 #define ROMA_ATTN(KERNEL, HDV, TOUT) hipLaunchKernelGGL((KERNEL<HDV, TOUT>), grid, dim3(256), 0, stream, a)
+  static const int ver_env = getenv("ROMA_ATTN_V") ? atoi(getenv("ROMA_ATTN_V")) : 2;
+  const int ver = g_attn_version >= 0 ? g_attn_version : ver_env;
+#define ROMA_ATTNV2(HDV, TOUT, E2) hipLaunchKernelGGL((attn_h16_v2_kernel<HDV, TOUT, E2>), grid, dim3(256), 0, stream, a);
 #define ROMA_ATTNB(HDV, TOUT)                                                                         \
   {                                                                                                   \
-    if (a.exp2_domain) hipLaunchKernelGGL((attn_bf16_kernel<HDV, TOUT, true>), grid, dim3(256), 0, stream, a);  \
+    if (ver >= 2) {                                                                                   \
+      if (a.exp2_domain) ROMA_ATTNV2(HDV, TOUT, true) else ROMA_ATTNV2(HDV, TOUT, false)              \
+    } else if (a.exp2_domain) hipLaunchKernelGGL((attn_bf16_kernel<HDV, TOUT, true>), grid, dim3(256), 0, stream, a);  \
     else hipLaunchKernelGGL((attn_bf16_kernel<HDV, TOUT, false>), grid, dim3(256), 0, stream, a);     \
   }
   if (a.in_dt == DT_F32) {
@@ -336,6 +545,7 @@ int attention_launch(const AttnArgs& a_in, hipStream_t stream) {
   }
 #undef ROMA_ATTN
 #undef ROMA_ATTNB
+#undef ROMA_ATTNV2
   ROMA_LAUNCH_CHECK();
   return 0;
 }

@@ -304,6 +304,59 @@ def test_attention_bf16(lib, B, heads, hd, N):
     _attention_case(lib, B, heads, hd, N, BF16)
 
 
+def _attention_direct(lib, q, k, v, N, version):
+    """roma_op_attention on hand-built operands: q [B,h,N,hd] (already scaled by 1/sqrt(hd)), k, v [B,h,N,hd]; bf16"""
+    B, heads, _, hd = q.shape
+    npad = (N + 127) // 128 * 128
+    qd = torch.zeros((B, heads, npad, hd), device="cuda", dtype=torch.bfloat16)
+    kd = torch.zeros_like(qd)
+    vtd = torch.zeros((B, heads, hd, npad), device="cuda", dtype=torch.bfloat16)
+    qd[:, :, :N], kd[:, :, :N] = q.cuda(), k.cuda()
+    vtd[:, :, :, :N] = v.transpose(2, 3).cuda()
+    out = torch.empty((B * N, heads * hd), device="cuda", dtype=torch.bfloat16)
+    lib.roma_tuning(b"attn_v", version)
+    try:
+        ok(lib, lib.roma_op_attention(P(qd), P(kd), P(vtd), P(out), B, heads, N, npad, hd, BF16, BF16, None))
+        torch.cuda.synchronize()
+    finally:
+        lib.roma_tuning(b"attn_v", -1)
+    return out.cpu().double().reshape(B, N, heads, hd).transpose(1, 2)
+
+
+@pytest.mark.parametrize("hd,N", [(64, 1601), (128, 1600), (64, 40)])
+def test_attention_deferred_rescale(lib, hd, N):
+    """attn_h16_v2_kernel moves its softmax reference only when a score exceeds it by 2^8 (or on the first tile).  Random
+    data never takes that branch after tile 0, so force it: for a third of the queries one LATE key (and for another third
+    one key of the first tile, so that the reference starts far above everything that follows) scores >> all others.
+    Checked against an f64 softmax of the same bf16 operands, and against the always-rescaling kernel (attn_v = 1)."""
+    B, heads = 2, 3
+    g = torch.Generator().manual_seed(5)
+    q = (torch.randn(B, heads, N, hd, generator=g) / math.sqrt(hd)).to(torch.bfloat16)
+    k = torch.randn(B, heads, N, hd, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, heads, N, hd, generator=g).to(torch.bfloat16)
+    late, early = N - 7, 3
+    qn = q.float() / q.float().norm(dim=-1, keepdim=True)
+    kf = k.float()
+    sel_late = torch.arange(N) % 3 == 0
+    sel_early = torch.arange(N) % 3 == 1
+    # one key per (b, head) can only align with one direction: use the mean direction of the selected queries, scaled up
+    kf[:, :, late] = 40.0 * math.sqrt(hd) * qn[:, :, sel_late].mean(dim=2) / qn[:, :, sel_late].mean(dim=2).norm(dim=-1, keepdim=True)
+    kf[:, :, early] = 40.0 * math.sqrt(hd) * qn[:, :, sel_early].mean(dim=2) / qn[:, :, sel_early].mean(dim=2).norm(dim=-1, keepdim=True)
+    k = kf.to(torch.bfloat16)
+    sc = q.double() @ k.double().transpose(2, 3)
+    # the construction must really cross the threshold (e^5.5) at the late tile for some queries, in both directions
+    if N > 64:
+        jump = sc[:, :, :, late] - sc[:, :, :, : (late // 64) * 64].amax(dim=-1)
+        assert float(jump.max()) > 8.0 and float((-jump).max()) > 8.0, (float(jump.max()), float(jump.min()))
+    ref = torch.softmax(sc, dim=-1) @ v.double()
+    o2 = _attention_direct(lib, q, k, v, N, 2)
+    o1 = _attention_direct(lib, q, k, v, N, 1)
+    e2, e1 = float((o2 - ref).abs().max()), float((o1 - ref).abs().max())
+    assert e2 < 3e-2 and e1 < 3e-2, (e2, e1)  # |O| <= max |v| ~ 4; bf16 P and V
+    assert e2 <= 1.5 * e1 + 4e-3, (e2, e1)
+    assert torch.isfinite(o2).all()
+
+
 def test_layernorm(lib):
     x, w, b = rnd(37, 1024, seed=1, std=3.0) + 0.5, rnd(1024, seed=2), rnd(1024, seed=3)
     out = torch.empty((37, 1024), device="cuda")
