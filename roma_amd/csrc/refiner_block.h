@@ -13,4 +13,8 @@ namespace roma {
 bool refiner_block_supported(int Cp, int dt);
 int refiner_block_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
                          const float* pw_b, int B, int H, int W, int Cp, int dt, hipStream_t s);
+// C = 24 only: the wave-private form (refiner_block24w.hip); 0 = launched, 1 = not taken (caller uses the workgroup kernel)
+int refiner_block24_wave_try_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
+                                    const float* pw_b, int B, int H, int W, int dt, hipStream_t s);
+extern int g_rb24_wave;
 }  // namespace roma

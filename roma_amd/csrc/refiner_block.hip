@@ -420,7 +420,11 @@ int refiner_block_launch(const void* in, void* out, const float* dw_w, const flo
   ROMA_REQUIRE(ldpw % 8 == 0, "refiner_block: 1x1 weight rows must be 16-byte aligned");
   ProfScope ps(Cp == 24 ? "refiner_block_kernel<24>" : "refiner_block_kernel<144>", 2.0 * (double)B * H * W * Cp * 2.0,
                "byte", s);
-  if (Cp == 24) return launch_cp<24>(in, out, dw_w, dw_b, pw, ldpw, pw_b, B, H, W, s);
+  if (Cp == 24) {
+    const int rc = refiner_block24_wave_try_launch(in, out, dw_w, dw_b, pw, ldpw, pw_b, B, H, W, dt, s);
+    if (rc <= 0) return rc;
+    return launch_cp<24>(in, out, dw_w, dw_b, pw, ldpw, pw_b, B, H, W, s);
+  }
   return launch_cp<144>(in, out, dw_w, dw_b, pw, ldpw, pw_b, B, H, W, s);
 }
 

@@ -1,0 +1,331 @@
+// Fused depthwise-5x5 (+folded BN, ReLU) -> 1x1 convolution for the stride-1 ConvRefiner (C = 24) - the "wave-private"
+// form of refiner_block_kernel<24> (refiner_block.hip).  romatch/models/matcher.py:106-122.
+//
+// refiner_block_kernel<24> shares everything across its four waves - the input ring, the depthwise-output tile Xt, the
+// output tile Ot - and pays two workgroup barriers per image row for it; its waves issue 45 % of their cycles and wait 36 %
+// (profiles/r03_pmc_sq_summary.json).  With 24 channels a single wave can own ALL channels of its pixels, so nothing has to
+// be shared (the recipe of dwconv5x5_ring_kernel, which issues 55 % of its cycles with no barrier at all):
+//
+//   * a wave = 40 output columns x all 24 channels x a strip of rows; lane = (4 channels, 4 columns): 6 channel groups x
+//     10 column quads = 60 lanes (the workgroup kernel: 216 of 256);
+//   * per input row the wave needs 44 pixels x 48 B: three `global_load_lds_dwordx4` into its own NR = 4 row ring.  After
+//     every 4 pixels (12 pieces) one 16-byte piece of the row stays empty, so that the column
+//     quads of a `ds_read_b64` half-wave start 52 dwords apart (0, 52, 40, 28, 16 mod 64 - five disjoint 12-dword runs;
+//     the natural 48-dword pitch puts quad 4 on quad 0's banks);
+//   * the depthwise output row goes to a wave-private Xt[40 pixels][32 k] (bf16, 80-byte rows as in the workgroup kernel),
+//     two 32-pixel MFMA blocks (the second one 8 pixels + zeros) x 2 k-steps against the 1x1 weights held in registers,
+//     bias in the accumulator init; the result is packed into a wave-private Ot[40][24] and leaves as 120 contiguous
+//     16-byte pieces, two stores per lane;
+//   * the only thing that orders anything is the wave's own counted `s_waitcnt vmcnt` (3 DMA + 2 stores per row) and the
+//     in-order LDS pipeline: NO barrier after the weights have been staged, the waves drift freely, and a wave whose tile is
+//     off the image simply leaves.
+//   * arithmetic and its order are those of refiner_block_kernel<24>: results are bit-identical (tests).
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "gemm.h"  // DT_*
+#include "refiner_block.h"
+
+namespace roma {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+#define ROMA_LDS __attribute__((address_space(3)))
+typedef ROMA_LDS unsigned char lds_u8;
+typedef ROMA_LDS float lds_f32;
+typedef ROMA_LDS f32x4 lds_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef ROMA_LDS u32x4_t lds_u32x4;
+typedef ROMA_LDS u32x2_t lds_u32x2;
+
+__device__ __attribute__((aligned(256))) unsigned int g_rbw_zero_page[64];  // source of every out-of-image / gap piece
+
+constexpr int RBW_C = 24;
+constexpr int RBW_NR = 4;         // ring rows per wave (the DMA runs three rows ahead)
+constexpr int RBW_ROWB = 3072;    // bytes per ring row: 192 pieces of 16 B (44 pixels x 3 + 10 gaps = 142 used)
+constexpr int RBW_PXW = 40;       // output columns per wave
+constexpr int RBW_XROW = 80;      // bytes per Xt pixel row: 32 k x 2 B + 16 (conflict-free 16-byte MFMA fragment reads)
+constexpr int RBW_XT = 64 * RBW_XROW;   // two 32-pixel MFMA blocks; rows 40 .. 63 stay zero
+constexpr int RBW_OT = 2048;      // 40 pixels x 48 B = 1920, rounded
+constexpr int RBW_RING = 4 * RBW_NR * RBW_ROWB;           // 48 KiB per workgroup
+constexpr int RBW_WORK = 4 * (RBW_XT + RBW_OT);           // 28 KiB
+constexpr int RBW_WSM = 26 * RBW_C * 4;                   // depthwise taps + bias, f32
+static_assert(RBW_RING + RBW_WORK + RBW_WSM <= 80 * 1024, "two workgroups per CU");
+static_assert(3 * (RBW_NR - 1) + 2 * (RBW_NR - 1) <= 63, "vmcnt is a 6-bit counter");
+
+#define ROMA_RBW_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+__device__ __forceinline__ void rbw_glds16(const char* src, lds_u8* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (ROMA_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                                      const float* __restrict__ dww, const float* __restrict__ dwb,
+                                                                      const bf16_t* __restrict__ pw, long ldpw,
+                                                                      const float* __restrict__ pwb, int B, int H, int W, int SY,
+                                                                      int nxg, long ntasks) {
+  constexpr int NR = RBW_NR, CP = RBW_C;
+  // Distinct LDS objects on purpose (refiner_block.hip): `ring` is the DMA target and is read with inline asm only; the
+  // others are ordinary code, which the compiler then does not order behind the in-flight DMA.  (Ot as a slice of the Xt
+  // object got an `s_waitcnt vmcnt(0)` in front of its first write of every row - the whole DMA queue drained; as an
+  // object of its own it does not.  tests/test_cpu_oracle.py audits the loop for it.)
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[RBW_RING];
+  __shared__ __attribute__((aligned(16))) unsigned char xtb[4 * RBW_XT];
+  __shared__ __attribute__((aligned(16))) unsigned char otb[4 * RBW_OT];
+  __shared__ __attribute__((aligned(16))) float wsmb[26 * RBW_C];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  lds_f32* const wsm = (lds_f32*)wsmb;  // [26][24]
+  lds_u8* const Xt = (lds_u8*)xtb + wv * RBW_XT;
+  lds_u8* const Ot = (lds_u8*)otb + wv * RBW_OT;
+
+  // ---- one-time staging: the tap table (shared, read-only afterwards) and this wave's zeroed Xt
+  for (int i = tid; i < 26 * (CP / 4); i += 256)
+    *(lds_f32x4*)(wsm + i * 4) =
+        *reinterpret_cast<const f32x4*>(i < 25 * (CP / 4) ? dww + (long)i * 4 : dwb + (long)(i - 25 * (CP / 4)) * 4);
+  for (int i = lane; i < RBW_XT / 16; i += 64) *(lds_u32x4*)(Xt + i * 16) = u32x4_t{0u, 0u, 0u, 0u};
+  __syncthreads();  // the only barrier of the kernel
+
+  // ---- this wave's task: (image, strip, 40-column tile), tiles fastest (neighbouring waves read neighbouring columns);
+  // each XCD owns a contiguous band of workgroups (the row halos hit its own L2)
+  const long nwg = (ntasks + 3) / 4, wg_per_xcd = (nwg + 7) / 8;
+  const long lw = (long)(blockIdx.x % 8) * wg_per_xcd + blockIdx.x / 8;
+  const long task = lw * 4 + wv;
+  if (lw >= nwg || task >= ntasks) return;  // (no barriers below: a wave may leave on its own)
+  const int xg = (int)(task % nxg);
+  long r = task / nxg;
+  const int yt = (H + SY - 1) / SY;
+  const int ys = (int)(r % yt) * SY;
+  const int b = (int)(r / yt);
+  const int sy = min(SY, H - ys);
+  const int T = sy + 4;  // input rows ys - 2 .. ys + sy + 1
+
+  const int cg = lane % 6, xq = lane / 6;
+  const bool active = xq < 10;
+  const int c = cg * 4;
+  const int xw0 = xg * RBW_PXW;            // first output column of the wave
+  const int x0 = xw0 - 2;                  // image column of ring pixel 0
+  const int npw = min(RBW_PXW, W - xw0);   // valid output columns of the wave (>= 1)
+  const int nvp = npw * 3;                 // valid 16-byte pieces of an output row
+  const bool two_stores = nvp > 64;        // wave-uniform: the counted waits assume this many store instructions per row
+
+  // ---- 1x1 weights of all 24 output channels: A operand (row = channel, 8 consecutive k per lane), rows / k >= 24 zero
+  u32x4_t wA[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int k0 = ks * 16 + hh * 8;
+    wA[ks] = u32x4_t{0u, 0u, 0u, 0u};
+    if (l31 < CP && k0 < CP) wA[ks] = *reinterpret_cast<const u32x4_t*>(pw + (long)l31 * ldpw + k0);
+  }
+  f32x4 pbias[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) pbias[g] = *reinterpret_cast<const f32x4*>(pwb + 8 * g + 4 * hh);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(wA[ks]));
+#pragma unroll
+  for (int g = 0; g < 3; ++g) asm volatile("" : "+v"(pbias[g]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this wave in flight before the counted DMA stream starts
+
+  // ---- DMA descriptors: piece k = 64 i + lane of a row; 13 pieces per 4 pixels (12 data + 1 gap)
+  const char* zsrc = reinterpret_cast<const char*>(g_rbw_zero_page);
+  const char* inb = reinterpret_cast<const char*>(in + ((long)b * H * W) * CP);
+  unsigned poff[3];
+  bool pok[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int k = 64 * i + lane, g13 = k / 13, r13 = k - g13 * 13;
+    const int p = 4 * g13 + r13 / 3, part = r13 % 3;
+    const int x = x0 + p;
+    pok[i] = r13 != 12 && p < RBW_PXW + 4 && x >= 0 && x < W;
+    poff[i] = (unsigned)((pok[i] ? x : 0) * CP * 2 + part * 16);
+  }
+  lds_u8* const myring = (lds_u8*)ring + wv * (NR * RBW_ROWB);
+#define ROMA_RBW_ISSUE(RROW, SLOT)                                                                  \
+  {                                                                                                 \
+    const int yy_ = ys - 2 + (RROW);                                                                \
+    const bool rok_ = (RROW) < T && yy_ >= 0 && yy_ < H;                                            \
+    const char* rb_ = inb + (long)(rok_ ? yy_ : 0) * W * CP * 2;                                    \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                   \
+        rbw_glds16((rok_ && pok[i]) ? rb_ + poff[i] : zsrc, myring + (SLOT) * RBW_ROWB + i * 1024); \
+  }
+
+  const f32x4 bx = *(lds_f32x4*)(wsm + 25 * CP + c);
+  const f32x2 bias0 = f32x2{bx[0], bx[1]}, bias1 = f32x2{bx[2], bx[3]};
+  f32x2 acc[5][4][2];
+#pragma unroll
+  for (int s5 = 0; s5 < 5; ++s5)
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      acc[s5][px][0] = bias0;
+      acc[s5][px][1] = bias1;
+    }
+  const unsigned rd0 = (unsigned)(size_t)myring + (unsigned)(xq * 208 + cg * 8);
+  bf16_t* const obase = out + ((long)b * H * W) * CP;
+  // output pieces of this lane: k = lane and lane + 64, clamped into the valid range (duplicates store the same bytes)
+  const int ok0 = min(lane, nvp - 1), ok1 = min(lane + 64, nvp - 1);
+
+#pragma unroll
+  for (int rr = 0; rr < NR - 1; ++rr) ROMA_RBW_ISSUE(rr, rr);
+
+  int slot = 0, fill = NR - 1;
+  // Row t has landed once at most the operations issued AFTER its DMA are outstanding: the DMA of rows t+1 .. t+NR-1 (3 each)
+  // and the 2 output stores of every iteration s in [t-NR+1, t-1] that had an output row (s >= 4).
+#define ROMA_RBW_WAIT_CASE(K) \
+  case K: ROMA_RBW_WAIT_VM(3 * (NR - 1) + 2 * K); break;
+#pragma nounroll
+  for (int t = 0; t < T; ++t) {
+    ROMA_RBW_ISSUE(t + NR - 1, fill);
+    const int kst = two_stores ? min(max(t - 4, 0), NR - 1) : 0;  // (one store per row: wait conservatively)
+    switch (kst) {
+      ROMA_RBW_WAIT_CASE(0) ROMA_RBW_WAIT_CASE(1) ROMA_RBW_WAIT_CASE(2)
+      default: ROMA_RBW_WAIT_VM(3 * (NR - 1) + 2 * (NR - 1)); break;
+    }
+    const int o = t - 4;  // output row (relative to ys) finished by input row t
+    if (active) {
+      unsigned long long cr[8];
+      const unsigned ra = rd0 + (unsigned)slot * RBW_ROWB;
+      asm volatile(
+          "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:48\n\tds_read_b64 %2, %8 offset:96\n\t"
+          "ds_read_b64 %3, %8 offset:144\n\tds_read_b64 %4, %8 offset:208\n\tds_read_b64 %5, %8 offset:256\n\t"
+          "ds_read_b64 %6, %8 offset:304\n\tds_read_b64 %7, %8 offset:352\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(cr[0]), "=&v"(cr[1]), "=&v"(cr[2]), "=&v"(cr[3]), "=&v"(cr[4]), "=&v"(cr[5]), "=&v"(cr[6]), "=&v"(cr[7])
+          : "v"(ra)
+          : "memory");
+#define ROMA_RBW_CVT(J)                                                  \
+  {                                                                      \
+    const uint32_t lo_ = (uint32_t)cr[J], hi_ = (uint32_t)(cr[J] >> 32); \
+    v[J][0] = f32x2{h16_lo(lo_), h16_hi(lo_)};                           \
+    v[J][1] = f32x2{h16_lo(hi_), h16_hi(hi_)};                           \
+  }
+      f32x2 v[8][2];
+      ROMA_RBW_CVT(0) ROMA_RBW_CVT(1) ROMA_RBW_CVT(2)
+      f32x4 wq[2][5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) wq[0][k] = *(lds_f32x4*)(wsm + ((4 - k) * 5 + 0) * CP + c);
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        if (kx < 4) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) wq[(kx + 1) & 1][k] = *(lds_f32x4*)(wsm + ((4 - k) * 5 + kx + 1) * CP + c);
+        }
+        ROMA_RBW_CVT(kx + 3)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {  // acc[k] holds output row t - 4 + k (tap row ky = 4 - k)
+          const f32x4 wx = wq[kx & 1][k];
+          const f32x2 w0 = f32x2{wx[0], wx[1]}, w1 = f32x2{wx[2], wx[3]};
+#pragma unroll
+          for (int px = 0; px < 4; ++px) {
+            acc[k][px][0] = v[px + kx][0] * w0 + acc[k][px][0];
+            acc[k][px][1] = v[px + kx][1] * w1 + acc[k][px][1];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef ROMA_RBW_CVT
+      if (o >= 0) {
+        lds_u8* xrow = Xt + (xq * 4) * RBW_XROW + cg * 8;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          u32x2_t u;
+          u.x = pack_bf16x2(fmaxf(acc[0][px][0][0], 0.f), fmaxf(acc[0][px][0][1], 0.f));
+          u.y = pack_bf16x2(fmaxf(acc[0][px][1][0], 0.f), fmaxf(acc[0][px][1][1], 0.f));
+          *(lds_u32x2*)(xrow + px * RBW_XROW) = u;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          acc[k][px][0] = acc[k + 1][px][0];
+          acc[k][px][1] = acc[k + 1][px][1];
+        }
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        acc[4][px][0] = bias0;
+        acc[4][px][1] = bias1;
+      }
+    }
+    if (o >= 0) {
+      // ---------------- 1x1 convolution of output row o on MFMA, out of the wave's own Xt
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f32x16 oa;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) oa[4 * g + j] = g < 3 ? pbias[g][j] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const u32x4_t xf = *(lds_u32x4*)(Xt + (u * 32 + l31) * RBW_XROW + ks * 32 + hh * 16);
+          oa = mfma_h16_32x32x16(wA[ks], xf, oa);
+        }
+        const int pxl = u * 32 + l31;
+        if (pxl < RBW_PXW) {
+          lds_u8* orow = Ot + pxl * (CP * 2) + 4 * hh * 2;
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            u32x2_t q;
+            q.x = pack_bf16x2(oa[4 * g + 0], oa[4 * g + 1]);
+            q.y = pack_bf16x2(oa[4 * g + 2], oa[4 * g + 3]);
+            *(lds_u32x2*)(orow + g * 16) = q;
+          }
+        }
+      }
+      // stream the row out: 120 contiguous 16-byte pieces (fewer on the right image edge)
+      char* orow_g = reinterpret_cast<char*>(obase + ((long)(ys + o) * W + xw0) * CP);
+      {
+        const u32x4_t q = *(lds_u32x4*)(Ot + ok0 * 16);
+        *reinterpret_cast<u32x4_t*>(orow_g + ok0 * 16) = q;
+      }
+      if (two_stores) {
+        const u32x4_t q = *(lds_u32x4*)(Ot + ok1 * 16);
+        *reinterpret_cast<u32x4_t*>(orow_g + ok1 * 16) = q;
+      }
+    }
+    fill = slot;
+    slot = slot + 1 == NR ? 0 : slot + 1;
+  }
+#undef ROMA_RBW_WAIT_CASE
+#undef ROMA_RBW_ISSUE
+  ROMA_RBW_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
+}
+
+int g_rb24_wave = -1;  // roma_tuning("rb24w", v): 1 = this kernel for C = 24 (default), 0 = refiner_block_kernel<24>, -1 = env ROMA_RB24W
+
+// 0 = launched, 1 = not this kernel's problem, < 0 = error
+int refiner_block24_wave_try_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
+                                    const float* pw_b, int B, int H, int W, int dt, hipStream_t s) {
+  static const int env = getenv("ROMA_RB24W") ? atoi(getenv("ROMA_RB24W")) : 1;
+  if (!(g_rb24_wave >= 0 ? g_rb24_wave : env)) return 1;
+  if (dt != DT_BF16 || H < 1 || W < 1 || (long)W * RBW_C * 2 >= (1l << 31)) return 1;
+  if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) return 1;
+  if ((reinterpret_cast<uintptr_t>(pw) & 15) != 0 || ldpw % 8 != 0) return 1;
+  const int nxg = (W + RBW_PXW - 1) / RBW_PXW;
+  // strip height: a strip of SY rows reads SY + 4 input rows and pays ~3 rows of pipeline fill; 2048 waves are resident
+  // (8 per CU) and take the tasks in rounds - pick the split of H that minimises rounds x (SY + 7)
+  int SY = H;
+  {
+    long best = -1;
+    for (int ns = (H + 95) / 96; ns <= std::max(1, H / 6); ++ns) {
+      const int sy = (H + ns - 1) / ns;
+      const long nt = (long)B * nxg * ((H + sy - 1) / sy);
+      const long cost = ((nt + 2047) / 2048) * (sy + 7);
+      if (best < 0 || cost < best) {
+        best = cost;
+        SY = sy;
+      }
+    }
+  }
+  const long ntasks = (long)B * nxg * ((H + SY - 1) / SY);
+  ROMA_REQUIRE(ntasks < (1l << 31), "refiner_block: grid too large");
+  const long nwg = (ntasks + 3) / 4, wg_per_xcd = (nwg + 7) / 8;  // (the kernel decodes the same arithmetic)
+  hipLaunchKernelGGL(refiner_block24_wave_kernel, dim3((unsigned)(wg_per_xcd * 8)), dim3(256), 0, s, (const bf16_t*)in,
+                     (bf16_t*)out, dw_w, dw_b, (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, ntasks);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace roma

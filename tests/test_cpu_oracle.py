@@ -354,6 +354,40 @@ def test_hot_gemm_kernels_do_not_spill(built_lib):
         assert k["spill"] <= limit, k
 
 
+def test_dma_ring_kernels_keep_their_queue(built_lib):
+    """The wave-private LDS-DMA ring kernels (dwconv_ring.hip, refiner_block24w.hip) and the attention v2 kernels live off
+    register budgets and counted waits: a spilled register is a scratch (VMEM) access that drains the counted DMA queue, and
+    an `s_waitcnt vmcnt(0)` that hipcc puts in front of an LDS access it cannot tell apart from the DMA target does the same
+    (refiner_block24w: Ot as a slice of the Xt object got one per row).  Held here on the built objects: no spills, and
+    between the first and the last `global_load_lds` of the row loop no full drain other than the counted constants."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    from audit_asm_reads import extract_code_object
+    build = os.path.join(ROOT, "roma_amd", "csrc", "build")
+    objs = {f: os.path.join(build, f) for f in ("dwconv_ring.o", "refiner_block24w.o", "attention.o")}
+    if not all(os.path.exists(o) for o in objs.values()):
+        pytest.skip("object files not present (library shipped pre-built)")
+    for f in ("dwconv_ring.o", "refiner_block24w.o"):
+        ks = kernel_resources.kernels(objs[f])
+        assert len(ks) == 1 and ks[0]["spill"] == 0 and ks[0]["scratch"] == 0 and ks[0]["vgpr"] <= 256, ks
+        dis = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", extract_code_object(objs[f])], capture_output=True,
+                             text=True, check=True).stdout.splitlines()
+        dma = [i for i, ln in enumerate(dis) if "global_load_lds_dwordx4" in ln]
+        assert len(dma) >= 6, f
+        # the row loop = from the last DMA issue (the loop's own) to the loop's back edge: the next backward branch
+        body = []
+        for ln in dis[dma[-1]:]:
+            body.append(ln)
+            if re.search(r"s_cbranch_\w+ 6[0-9]{4}\b|s_branch 6[0-9]{4}\b", ln):  # negative 16-bit offset = backward
+                break
+        waits = [int(m.group(1)) for ln in body for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", ln)] if m]
+        assert waits and min(waits) >= 9, (f, waits)  # >= 3 DMA x (NR - 1 >= 3) rows stay in flight
+    att = [k for k in kernel_resources.kernels(objs["attention.o"]) if "attn_h16_v2_kernel" in k["name"]]
+    assert len(att) == 8 and all(k["spill"] == 0 for k in att), att
+    assert all(k["vgpr"] <= (168 if "<64" in k["name"] else 256) for k in att), att  # 3 / 2 workgroups per CU
+
+
 def test_isa_audit_no_touch_of_registers_with_asm_lds_reads_in_flight(built_lib):
     """Every hand-scheduled GEMM K loop reads its MFMA fragments with inline-asm ds_read_b128 whose completion hipcc does
     not track; the construct is only correct if nothing touches those registers before our s_waitcnt (the round-1 f32

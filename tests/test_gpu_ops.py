@@ -638,8 +638,40 @@ def test_dwconv5x5_ring_repeated_launches_under_load(lib):
     assert bad == 0, f"{bad} of 200 launches differ"
 
 
+def test_refiner_block24_wave_repeated_launches_under_load(lib):
+    """refiner_block24_wave_kernel orders its ring with counted vmcnt waits only; a wrong count shows up as a timing
+    dependent mismatch, so: 150 launches against the workgroup kernel's result while a GEMM runs on a second stream."""
+    B, H, W, Cp = 4, 211, 333, 24
+    x = rnd(B, H, W, Cp, seed=1).to(torch.bfloat16).cuda()
+    w, b = (rnd(25, Cp, seed=2, std=0.2)).cuda(), rnd(Cp, seed=3).cuda()
+    pw, pb = rnd(Cp, Cp, seed=4, std=Cp ** -0.5).to(torch.bfloat16).cuda(), rnd(Cp, seed=5).cuda()
+    ref = torch.empty_like(x)
+    lib.roma_tuning(b"rb24w", 0)
+    try:
+        ok(lib, lib.roma_op_refiner_block(P(x), P(ref), P(w), P(b), P(pw), P(pb), B, H, W, Cp, BF16, None))
+        torch.cuda.synchronize()
+    finally:
+        lib.roma_tuning(b"rb24w", -1)
+    A = rnd(8192, 1024, seed=6).to(torch.bfloat16).cuda()
+    Wg = rnd(1024, 1024, seed=7, std=0.03).to(torch.bfloat16).cuda()
+    Cg = torch.empty((8192, 1024), device="cuda", dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    out = torch.empty_like(ref)
+    bad = 0
+    for it in range(150):
+        if it % 4 == 0:
+            ok(lib, lib.roma_op_gemm(P(A), 1024, P(Wg), 1024, P(Cg), 1024, 8192, 1024, 1024, 1, 0, 0, 0, None, None, None, 0, 0, 1.0,
+                                     BF16, BF16, C.c_void_p(side.cuda_stream)))
+        out.fill_(float("nan"))
+        ok(lib, lib.roma_op_refiner_block(P(x), P(out), P(w), P(b), P(pw), P(pb), B, H, W, Cp, BF16, None))
+        bad += int(not torch.equal(out.view(torch.int16), ref.view(torch.int16)))
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of 150 launches differ"
+
+
 @pytest.mark.parametrize("Cp,B,H,W", [(24, 2, 13, 10), (24, 1, 75, 301), (24, 1, 290, 150), (144, 2, 13, 10), (144, 1, 41, 59),
-                                      (144, 1, 262, 31), (144, 5, 70, 280), (24, 3, 3, 200), (144, 2, 1, 30)])
+                                      (144, 1, 262, 31), (144, 5, 70, 280), (24, 3, 3, 200), (144, 2, 1, 30), (24, 2, 97, 40),
+                                      (24, 1, 33, 81), (24, 1, 1, 21), (24, 4, 140, 139)])
 def test_refiner_block_fused(lib, Cp, B, H, W):
     """Fused dw5x5+BN+ReLU+1x1 (refiner_block.hip) vs torch f64 on the same bf16-rounded operands: ragged strips,
     x tiles and pixel blocks, both strip heights (H >= 256 selects 36-row strips), strips shorter than the pipeline depth.
@@ -661,6 +693,15 @@ def test_refiner_block_fused(lib, Cp, B, H, W):
         outs.append(out)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     out = outs[0]
+    if Cp == 24:  # the wave-private kernel (default) against the workgroup kernel: same arithmetic, same bits
+        lib.roma_tuning(b"rb24w", 0)
+        try:
+            o2 = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=torch.bfloat16)
+            ok(lib, lib.roma_op_refiner_block(P(xin), P(o2), P(wp), P(b.cuda()), P(pw.cuda()), P(pb.cuda()), B, H, W, Cp, BF16, None))
+            torch.cuda.synchronize()
+        finally:
+            lib.roma_tuning(b"rb24w", -1)
+        assert torch.equal(out.view(torch.int16), o2.view(torch.int16))
     got = out.cpu().double()
     assert torch.isfinite(got).all()
     # bf16 output rounding (2^-8 relative) + the occasional 1-ulp flip of the bf16 intermediate
