@@ -116,25 +116,26 @@ __device__ __forceinline__ void dwr_row(f32x2 (&acc)[5][4][2], const f32x4 (&wre
 __global__ __launch_bounds__(256, 2) void dwconv5x5_ring_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
                                                                 const float* __restrict__ w, const float* __restrict__ bias,
                                                                 int B, int H, int W, int Cp, int SY, int nchunk, int nxg,
-                                                                long nblocks) {
+                                                                long ntasks) {
   constexpr int NR = DWR_NR;
   __shared__ __attribute__((aligned(1024))) unsigned char ring[DWR_RING];  // the DMA target: read with inline asm only
-  const long per_xcd = (nblocks + 7) / 8;  // each XCD owns a contiguous band of blocks (the row halos hit its own L2)
-  const long lb = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-  if (lb >= nblocks) return;
+  // a wave's task = (image, strip, 64-channel chunk, 16-column tile), tiles fastest: the four waves of a workgroup take
+  // four neighbouring column tiles (together they read whole rows of 64 + 4 pixels), and no wave is wasted when the tile
+  // count is not a multiple of four (16 x 70 x 70 x 1152: 5 tiles - a workgroup of "four tiles of one chunk" idled 3 of 8).
+  // Each XCD owns a contiguous band of workgroups (the row halos hit its own L2).
+  const long nwg = (ntasks + 3) / 4, wg_per_xcd = (nwg + 7) / 8;
+  const long lw = (long)(blockIdx.x % 8) * wg_per_xcd + blockIdx.x / 8;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // block -> (image, strip, group of 4 column tiles, 64-channel chunk), chunk fastest: the four waves take the four
-  // neighbouring column tiles of one chunk (together they read whole rows of 64 + 4 pixels)
-  const int nxg4 = (nxg + 3) / 4;
-  const int chunk = (int)(lb % nchunk);
-  long r = lb / nchunk;
-  const int xg = (int)(r % nxg4) * 4 + wv;
-  r /= nxg4;
+  const long task = lw * 4 + wv;
+  if (lw >= nwg || task >= ntasks) return;  // no barriers: a wave may leave on its own
+  const int xg = (int)(task % nxg);
+  long r = task / nxg;
+  const int chunk = (int)(r % nchunk);
+  r /= nchunk;
   const int yt = (H + SY - 1) / SY;
   const int ys = (int)(r % yt) * SY;
   const int b = (int)(r / yt);
-  if (xg >= nxg) return;  // a column tile beyond the image (last group of four): no barriers, a wave may leave on its own
   const int sy = min(SY, H - ys);
   const int T = sy + 4;  // input rows ys - 2 .. ys + sy + 1
 
@@ -235,32 +236,35 @@ int dwconv5x5_ring_try_launch(const void* in, void* out, const float* w, const f
   if ((reinterpret_cast<uintptr_t>(w) & 15) != 0 || (reinterpret_cast<uintptr_t>(bias) & 15) != 0) return 1;
   const int nchunk = Cp / 64;
   const int nxg = (W + DWR_PXW - 1) / DWR_PXW;
-  // strip height: a strip of SY rows reads SY + 4 input rows and pays ~3 rows of pipeline fill; 512 workgroups are resident
-  // (two per CU) and take the blocks in rounds - pick the split of H that minimises rounds x (SY + 7)
+  // strip height: a strip of SY rows reads SY + 4 input rows and pays ~3 rows of pipeline fill; 2048 waves are resident
+  // (8 per CU) and take the tasks in rounds - pick the split of H that minimises rounds x (SY + 7)
   int SY = H;
   {
     long best = -1;
-    const long per_strip = (long)B * ((nxg + 3) / 4) * nchunk;
+    const long per_strip = (long)B * nxg * nchunk;
     for (int ns = (H + 47) / 48; ns <= std::max(1, H / 6); ++ns) {
       const int sy = (H + ns - 1) / ns;
-      const long nb = per_strip * ((H + sy - 1) / sy);
-      const long cost = ((nb + 511) / 512) * (sy + 7);
+      const long nt = per_strip * ((H + sy - 1) / sy);
+      const long cost = ((nt + 2047) / 2048) * (sy + 7);
       if (best < 0 || cost < best) {
         best = cost;
         SY = sy;
       }
     }
   }
-  const long nblocks = (long)B * ((H + SY - 1) / SY) * ((nxg + 3) / 4) * nchunk;
-  ROMA_REQUIRE(nblocks < (1l << 30), "dwconv5x5: grid too large");
-  // Coarse tasks (a wave = 64 channels x 16 columns x a whole strip) need a large problem: below ~4 rounds of the 512
-  // resident workgroups the finer-grained register-prefetch kernel wins (16 x 140 x 140 x 576: 0.206 vs 0.223 ms,
-  // 16 x 70 x 70 x 1152: 0.130 vs 0.140; 16 x 216 x 216 x 576: 0.443 vs 0.430, 16 x 108 x 108 x 1152: 0.251 vs 0.218 -
-  // profiles/r03_v7_visit.log), so the pass-1 refiners stay on it.  ROMA_DW_RING=2 forces this kernel (tests, A/B).
-  if ((g_dw_ring >= 0 ? g_dw_ring : env) != 2 && nblocks < 2000) return 1;
+  const long ntasks = (long)B * ((H + SY - 1) / SY) * nxg * nchunk;
+  ROMA_REQUIRE(ntasks < (1l << 31), "dwconv5x5: grid too large");
+  // Coarse tasks (a wave = 64 channels x 16 columns x a strip) need a problem that fills the 2048 resident waves: measured
+  // per launch, ring / register-prefetch kernel (profiles/r03_v14_dwconv_ring_flat_tasks.log), B = 16 and B = 8 (one
+  // sub-batch stream): 40^2 x 1408: 53.9 / 48.6 and 34.9 / 32.6 us; 70^2 x 1152: 118 / 142 and 62.7 / 59.0; 140^2 x 576:
+  // 205 / 224 and 86.8 / 109; 108^2 x 1152: 220 / 258 and 112 / 137; 216^2 x 576: 407 / 463 and 204 / 240.  The crossover
+  // sits between 45 M and 90 M elements.  ROMA_DW_RING=2 forces this kernel (tests, A/B).
+  static const long min_elems = getenv("ROMA_DW_RING_MINELEMS") ? atol(getenv("ROMA_DW_RING_MINELEMS")) : (64l << 20);
+  if ((g_dw_ring >= 0 ? g_dw_ring : env) != 2 && (long)B * H * W * Cp < min_elems) return 1;
   ProfScope ps("dwconv5x5_kernel<" ROMA_H16_NAME ">", 2.0 * (double)B * H * W * Cp * 2.0, "byte", s);
-  hipLaunchKernelGGL(dwconv5x5_ring_kernel, dim3((unsigned)(((nblocks + 7) / 8) * 8)), dim3(256), 0, s, (const bf16_t*)in,
-                     (bf16_t*)out, w, bias, B, H, W, Cp, SY, nchunk, nxg, nblocks);
+  const long nwg = (ntasks + 3) / 4;
+  hipLaunchKernelGGL(dwconv5x5_ring_kernel, dim3((unsigned)(((nwg + 7) / 8) * 8)), dim3(256), 0, s, (const bf16_t*)in,
+                     (bf16_t*)out, w, bias, B, H, W, Cp, SY, nchunk, nxg, ntasks);
   ROMA_LAUNCH_CHECK();
   return 0;
 }
