@@ -17,4 +17,5 @@ int refiner_block_launch(const void* in, void* out, const float* dw_w, const flo
 int refiner_block24_wave_try_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
                                     const float* pw_b, int B, int H, int W, int dt, hipStream_t s);
 extern int g_rb24_wave;
+extern int g_rb144_1b;
 }  // namespace roma

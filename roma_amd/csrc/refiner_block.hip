@@ -370,10 +370,322 @@ __global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __r
 }
 #undef ROMA_RB_ISSUE_ROW
 
+// ---------------------------------------------------------------------------------------------------------------------
+// C = 144 with ONE barrier per image row (the default; roma_tuning("rb144_1b", 0) keeps the kernel above for A/B).
+//
+// The kernel above needs two barriers per row: B2 (the depthwise tile Xt is complete / the ring slot is free) and B3 (the
+// output tile Ot is complete before the whole workgroup streams it out / the next input row has landed).  Here
+//   * Xt is double buffered: row t's 1x1 reads Xt[t & 1] while the fastest wave may already write Xt[(t + 1) & 1];
+//   * every wave stores exactly what it computed - its own 32-channel slice of the row (64 B per pixel) and, when it is its
+//     turn, the 16-channel remainder block - so nobody waits for anybody else's part of Ot;
+//   * a wave waits for its own DMA pieces of row t + 1 BEFORE the barrier of row t, which makes that barrier the "row t + 1
+//     is visible" point as well.
+// The second Xt buffer is paid for with the ring: NR = 3 rows (the DMA still runs a full row ahead of the one being
+// waited for).  Arithmetic and its order are unchanged: bit-identical results (tests).
+constexpr int RB1_NR = 3;
+constexpr int RB1_XT = RBCfg<144>::PXB * 32 * RBCfg<144>::XROW;
+static_assert(RBCfg<144>::WORK_BYTES + RB1_XT + RB1_NR * RBCfg<144>::RSTRIDE <= 80 * 1024, "two workgroups per CU");
+
+__global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                                     const float* __restrict__ dww, const float* __restrict__ dwb,
+                                                                     const bf16_t* __restrict__ pw, long ldpw,
+                                                                     const float* __restrict__ pwb, int B, int H, int W, int SY,
+                                                                     int nxg, int nblocks) {
+  constexpr int CP = 144;
+  typedef RBCfg<CP> Cf;
+  constexpr int GC = Cf::GC, XQ = Cf::XQ, PX = Cf::PX, KS = Cf::KS, NR = RB1_NR, KW = Cf::KW;
+  constexpr int XROW = Cf::XROW, NDMA = Cf::NDMA, RSTRIDE = Cf::RSTRIDE, OPIX = Cf::OPIX;
+  static_assert(Cf::PXB == 1 && Cf::NBF == 4 && Cf::TAIL == 16, "one 32-pixel block, four full channel blocks + 16");
+  static_assert((NR - 2) * KW + (NR - 1) * 3 < 64, "vmcnt range");
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[NR * RSTRIDE];
+  __shared__ __attribute__((aligned(16))) unsigned char work[Cf::OFF_XT];          // taps, 1x1 bias, remainder weights
+  __shared__ __attribute__((aligned(16))) unsigned char xtb[2 * RB1_XT];           // Xt, double buffered
+  __shared__ __attribute__((aligned(16))) unsigned char otb[PX * OPIX];            // Ot: per-wave channel slices
+  lds_u8* const wk = (lds_u8*)work;
+  lds_f32* const wsm = (lds_f32*)wk;
+  lds_f32* const pbs = (lds_f32*)(wk + Cf::OFF_PWB);
+  lds_u8* const Wt = wk + Cf::OFF_WT;
+  lds_u8* const Ot = (lds_u8*)otb;
+
+  const int per_xcd = (nblocks + 7) / 8;
+  const long lb = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (lb >= nblocks) return;
+  const int xg = (int)(lb % nxg);
+  long rr = lb / nxg;
+  const int yt = (H + SY - 1) / SY;
+  const int ys = (int)(rr % yt) * SY;
+  const int b = (int)(rr / yt);
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int x0 = xg * PX;
+  const int sy = min(SY, H - ys);
+  const int T = sy + 4;
+  const int npx = min(PX, W - x0);
+
+  {
+    // taps + bias in SLOT order: slot s of a tap row holds channel group (s + 32) % 36, i.e. the row starts with groups
+    // 32 .. 35 (see the lane map below)
+    constexpr int nvec = 26 * GC;
+#pragma unroll
+    for (int it = 0; it < (nvec + 255) / 256; ++it) {
+      const int i = tid + 256 * it;
+      if (i < nvec) {
+        const int row = i / GC, sl = i - row * GC, g = (sl + 32) % GC;
+        *(lds_f32x4*)(wsm + i * 4) = *reinterpret_cast<const f32x4*>(row < 25 ? dww + ((long)row * GC + g) * 4 : dwb + (long)g * 4);
+      }
+    }
+    if (tid < GC) *(lds_f32x4*)(pbs + tid * 4) = *reinterpret_cast<const f32x4*>(pwb + tid * 4);
+    constexpr int wslots = Cf::TAIL * (XROW / 16);
+    for (int i = tid; i < wslots; i += 256) {
+      const int n = i / (XROW / 16), sl = i - n * (XROW / 16);
+      u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+      if (sl < CP * 2 / 16) v = *reinterpret_cast<const u32x4_t*>(pw + (long)(32 * Cf::NBF + n) * ldpw + sl * 8);
+      *(lds_u32x4*)(Wt + n * XROW + sl * 16) = v;
+    }
+    for (int i = tid; i < 2 * RB1_XT / 16; i += 256) *(lds_u32x4*)((lds_u8*)xtb + i * 16) = u32x4_t{0u, 0u, 0u, 0u};
+  }
+  u32x4_t wown[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    wown[ks] = *reinterpret_cast<const u32x4_t*>(pw + (long)(32 * wv + l31) * ldpw + ks * 16 + hh * 8);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wown[ks]));
+
+  const char* zsrc = reinterpret_cast<const char*>(g_rb_zero_page);
+  const char* inb = reinterpret_cast<const char*>(in + ((long)b * H * W) * CP);
+  const int qoff0 = (wv * 64 + lane) * 16;
+  bool qok[KW];
+#pragma unroll
+  for (int q = 0; q < KW; ++q) {
+    const int chunk = (wv + 4 * q) * 64 + lane;
+    const int x = x0 - 2 + chunk / (CP / 8);
+    qok[q] = chunk * 16 < Cf::IN_ROWB && x >= 0 && x < W;
+  }
+  const int kw = (NDMA - wv + 3) / 4;  // pieces this wave really issues per row (3 ; 2 ; 2 ; 2)
+#define ROMA_RB1_ISSUE_ROW(RROW, SLOT)                                                                 \
+  {                                                                                                    \
+    const int yy_ = ys - 2 + (RROW);                                                                   \
+    const bool rok_ = (RROW) < T && yy_ >= 0 && yy_ < H;                                               \
+    const char* rb_ = inb + ((long)(rok_ ? yy_ : 0) * W + x0 - 2) * (CP * 2);                          \
+    _Pragma("unroll") for (int q = 0; q < KW; ++q) {                                                   \
+      if (wv + 4 * q < NDMA)                                                                           \
+        rb_glds16((rok_ && qok[q]) ? rb_ + qoff0 + q * 4096 : zsrc, (lds_u8*)ring + (SLOT) * RSTRIDE + (wv + 4 * q) * 1024); \
+    }                                                                                                  \
+  }
+
+  ROMA_RB_BARRIER();  // staged tiles visible; nothing of ours in flight yet
+#pragma unroll
+  for (int r = 0; r < NR; ++r) ROMA_RB1_ISSUE_ROW(r, r);
+  if (kw == KW) ROMA_RB_WAIT_VM((NR - 1) * KW); else ROMA_RB_WAIT_VM((NR - 1) * (KW - 1));
+  ROMA_RB_BARRIER();  // input row 0 landed
+
+  // Lane -> (column quad xq, channel group cg).  With the plain tid = 36 xq + cg map a 16-lane pass of the tap reads
+  // (ds_read_b128, 64 B per 4 lanes) straddles the 35 -> 0 wrap of the channel groups in 1-2 of every 4 passes, and groups
+  // 32 .. 35 share their banks with groups 0 .. 3 / 16 .. 19 (144 dwords per tap row = 2.25 x 64): 2-way conflicts on the 25
+  // tap reads of every row (LDS bank-conflict share 0.32, profiles/r03_pmc_sq_summary.json).  Here every pass reads 16
+  // CONSECUTIVE slots of the tap row (or repeats an address of the same pass, which broadcasts):
+  //   waves 0-2: lanes 0-35 = quad 2w, slots 4..35, 0..3;  lanes 36-63 = quad 2w + 1, slots 0..27
+  //   wave 3:    lanes 0-35 = quad 6, slots 0..35;         lanes 36-59 = slots 28..35 of quads 1, 3, 5
+  int xq, wslot;
+  if (wv < 3) {
+    xq = lane < 36 ? 2 * wv : 2 * wv + 1;
+    wslot = lane < 36 ? (lane + 4) % 36 : lane - 36;
+  } else {
+    const int k24 = lane - 36;
+    xq = lane < 36 ? 6 : 1 + 2 * (k24 >> 3);
+    wslot = lane < 36 ? lane : 28 + (k24 & 7);
+  }
+  const int cg = (wslot + 32) % 36;
+  const int xb = x0 + xq * 4;
+  const bool active = (wv < 3 || lane < 60) && xb < W;
+  const int c = cg * 4;        // channel offset: ring reads, Xt writes
+  const int cw = wslot * 4;    // position inside a tap row of wsm
+  const f32x4 bx = *(lds_f32x4*)(wsm + 25 * CP + cw);
+  const f32x2 bias0 = f32x2{bx[0], bx[1]}, bias1 = f32x2{bx[2], bx[3]};
+  f32x2 acc[5][4][2];
+#pragma unroll
+  for (int s5 = 0; s5 < 5; ++s5)
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      acc[s5][px][0] = bias0;
+      acc[s5][px][1] = bias1;
+    }
+  const unsigned ring_lds = (unsigned)(size_t)((lds_u8*)ring);
+  const unsigned rd0 = ring_lds + (unsigned)((xq * 4 * CP + c) * 2);
+  bf16_t* obase = out + ((long)b * H * W) * CP;
+
+  int slot = 0;
+#pragma nounroll
+  for (int t = 0; t < T; ++t) {
+    const int o = t - 4;
+    lds_u8* const Xt = (lds_u8*)xtb + (t & 1) * RB1_XT;
+    if (active) {
+      unsigned long long cr[8];
+      const unsigned ra = rd0 + (unsigned)slot * RSTRIDE;
+      asm volatile(
+          "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:%9\n\tds_read_b64 %2, %8 offset:%10\n\t"
+          "ds_read_b64 %3, %8 offset:%11\n\tds_read_b64 %4, %8 offset:%12\n\tds_read_b64 %5, %8 offset:%13\n\t"
+          "ds_read_b64 %6, %8 offset:%14\n\tds_read_b64 %7, %8 offset:%15\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(cr[0]), "=&v"(cr[1]), "=&v"(cr[2]), "=&v"(cr[3]), "=&v"(cr[4]), "=&v"(cr[5]), "=&v"(cr[6]), "=&v"(cr[7])
+          : "v"(ra), "n"(CP * 2), "n"(CP * 4), "n"(CP * 6), "n"(CP * 8), "n"(CP * 10), "n"(CP * 12), "n"(CP * 14)
+          : "memory");
+#define ROMA_RB_CVT(J)                                                   \
+  {                                                                      \
+    const uint32_t lo_ = (uint32_t)cr[J], hi_ = (uint32_t)(cr[J] >> 32); \
+    v[J][0] = f32x2{h16_lo(lo_), h16_hi(lo_)};                           \
+    v[J][1] = f32x2{h16_lo(hi_), h16_hi(hi_)};                           \
+  }
+      f32x2 v[8][2];
+      ROMA_RB_CVT(0) ROMA_RB_CVT(1) ROMA_RB_CVT(2)
+      f32x4 wq[2][5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) wq[0][k] = *(lds_f32x4*)(wsm + ((4 - k) * 5 + 0) * CP + cw);
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        if (kx < 4) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) wq[(kx + 1) & 1][k] = *(lds_f32x4*)(wsm + ((4 - k) * 5 + kx + 1) * CP + cw);
+        }
+        ROMA_RB_CVT(kx + 3)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const f32x4 wx = wq[kx & 1][k];
+          const f32x2 w0 = f32x2{wx[0], wx[1]}, w1 = f32x2{wx[2], wx[3]};
+#pragma unroll
+          for (int px = 0; px < 4; ++px) {
+            acc[k][px][0] = v[px + kx][0] * w0 + acc[k][px][0];
+            acc[k][px][1] = v[px + kx][1] * w1 + acc[k][px][1];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef ROMA_RB_CVT
+      if (o >= 0) {
+        lds_u8* xrow = Xt + (xq * 4) * XROW + cg * 8;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          u32x2_t u;
+          u.x = pack_bf16x2(fmaxf(acc[0][px][0][0], 0.f), fmaxf(acc[0][px][0][1], 0.f));
+          u.y = pack_bf16x2(fmaxf(acc[0][px][1][0], 0.f), fmaxf(acc[0][px][1][1], 0.f));
+          *(lds_u32x2*)(xrow + px * XROW) = u;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          acc[k][px][0] = acc[k + 1][px][0];
+          acc[k][px][1] = acc[k + 1][px][1];
+        }
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        acc[4][px][0] = bias0;
+        acc[4][px][1] = bias1;
+      }
+    }
+    // this wave's pieces of input row t + 1 must have landed: everything issued after them may stay in flight - the DMA of
+    // rows t + 2 .. t + NR - 1 (row t + NR is issued below) and the 3 stores of each of the last NR - 1 iterations that
+    // had an output row (iterations >= 4)
+    {
+      const int kst = min(max(t - 4, 0), NR - 1);
+      if (kw == KW) {
+        if (kst == 0) ROMA_RB_WAIT_VM((NR - 2) * KW); else if (kst == 1) ROMA_RB_WAIT_VM((NR - 2) * KW + 3); else ROMA_RB_WAIT_VM((NR - 2) * KW + 6);
+      } else {
+        if (kst == 0) ROMA_RB_WAIT_VM((NR - 2) * (KW - 1)); else if (kst == 1) ROMA_RB_WAIT_VM((NR - 2) * (KW - 1) + 3); else ROMA_RB_WAIT_VM((NR - 2) * (KW - 1) + 6);
+      }
+    }
+    ROMA_RB_BARRIER();  // Xt[t & 1] complete; every wave is done with ring slot `slot`; input row t + 1 is visible
+    ROMA_RB1_ISSUE_ROW(t + NR, slot);
+    if (o >= 0) {
+      // ---------------- 1x1 convolution of output row o: own 32-channel block (weights in registers) ...
+      int lanev = lane;  // opaque copy: keeps loop-invariant addresses from being hoisted into long-lived registers
+      asm volatile("" : "+v"(lanev));
+      const int l31v = lanev & 31, hhv = lanev >> 5;
+      {
+        f32x16 oa;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bq = *(lds_f32x4*)(pbs + 32 * wv + 8 * g + 4 * hhv);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) oa[4 * g + j] = bq[j];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const u32x4_t xf = *(lds_u32x4*)(Xt + l31v * XROW + ks * 32 + hhv * 16);
+          oa = mfma_h16_32x32x16(wown[ks], xf, oa);
+        }
+        if (l31v < PX) {
+          lds_u8* orow = Ot + l31v * OPIX + (32 * wv + 4 * hhv) * 2;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            u32x2_t q;
+            q.x = pack_bf16x2(oa[4 * g + 0], oa[4 * g + 1]);
+            q.y = pack_bf16x2(oa[4 * g + 2], oa[4 * g + 3]);
+            *(lds_u32x2*)(orow + g * 16) = q;
+          }
+        }
+      }
+      // ... and, when it is this wave's turn, the 16-channel remainder block (weights from LDS)
+      const bool mine = ((o & 3) == wv);  // wave-uniform
+      if (mine) {
+        const int wrow = l31v < Cf::TAIL ? l31v : l31v - Cf::TAIL;
+        f32x16 ta;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+          if (8 * g + 4 * hhv < Cf::TAIL) bq = *(lds_f32x4*)(pbs + 32 * Cf::NBF + 8 * g + 4 * hhv);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ta[4 * g + j] = bq[j];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const u32x4_t wf = *(lds_u32x4*)(Wt + wrow * XROW + ks * 32 + hhv * 16);
+          const u32x4_t xf = *(lds_u32x4*)(Xt + l31v * XROW + ks * 32 + hhv * 16);
+          ta = mfma_h16_32x32x16(wf, xf, ta);
+        }
+        if (l31v < PX) {
+          lds_u8* orow = Ot + l31v * OPIX + (32 * Cf::NBF + 4 * hhv) * 2;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (8 * g + 4 * hhv < Cf::TAIL) {
+              u32x2_t q;
+              q.x = pack_bf16x2(ta[4 * g + 0], ta[4 * g + 1]);
+              q.y = pack_bf16x2(ta[4 * g + 2], ta[4 * g + 3]);
+              *(lds_u32x2*)(orow + g * 16) = q;
+            }
+          }
+        }
+      }
+      // stream out what this wave wrote: its slice = npx x 4 pieces of 16 B (two stores per lane), then either the
+      // remainder block's npx x 2 pieces or - to keep the store count per row uniform for the counted waits - piece 0 again
+      char* orow_g = reinterpret_cast<char*>(obase + ((long)(ys + o) * W + x0) * CP);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int j = min(lanev + 64 * it, npx * 4 - 1);
+        const int jp = j >> 2, jc = j & 3;
+        const u32x4_t q = *(lds_u32x4*)(Ot + jp * OPIX + 64 * wv + jc * 16);
+        *reinterpret_cast<u32x4_t*>(orow_g + jp * (CP * 2) + 64 * wv + jc * 16) = q;
+      }
+      {
+        const int j = mine ? min(lanev, npx * 2 - 1) : 0;
+        const int jp = mine ? (j >> 1) : 0, jc = mine ? (j & 1) : 0;
+        const int cb = mine ? 64 * Cf::NBF : 64 * wv;  // byte column of the piece inside a pixel
+        const u32x4_t q = *(lds_u32x4*)(Ot + jp * OPIX + cb + jc * 16);
+        *reinterpret_cast<u32x4_t*>(orow_g + jp * (CP * 2) + cb + jc * 16) = q;
+      }
+    }
+    slot = slot + 1 == NR ? 0 : slot + 1;
+  }
+  ROMA_RB_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
+}
+#undef ROMA_RB1_ISSUE_ROW
+
 // (A stand-alone depthwise kernel on the same LDS-DMA ring was measured for the wide scales, C = 576 / 1152 / 1408:
 //  0.541 vs 0.504 ms at 16x216x216x576, 0.299 vs 0.266 ms at 16x108x108x1152 - slower than the register-prefetch
 //  kernel in elementwise.hip.  The depthwise phase is bound by its 200 v_pk_fma_f32 + 25 LDS weight reads per row,
 //  not by load latency; the ring only pays off here, where it also frees the registers the 1x1 weights need.)
+int g_rb144_1b = -1;  // roma_tuning("rb144_1b", v): 1 = refiner_block144_1b_kernel (default), 0 = refiner_block_kernel<144>, -1 = env ROMA_RB144_1B
 bool refiner_block_supported(int Cp, int dt) { return dt == DT_BF16 && (Cp == 24 || Cp == 144); }
 
 template <int CP>
@@ -407,6 +719,13 @@ static int launch_cp(const void* in, void* out, const float* dw_w, const float* 
     fprintf(stderr, "refiner_block<%d>: %d workgroups/CU, grid %d\n", CP, nb_cu, nblocks);
   }
   dim3 grid((unsigned)(((nblocks + 7) / 8) * 8));
+  static const int env1b = getenv("ROMA_RB144_1B") ? atoi(getenv("ROMA_RB144_1B")) : 1;
+  if (CP == 144 && (g_rb144_1b >= 0 ? g_rb144_1b : env1b) && !dbg) {
+    hipLaunchKernelGGL(refiner_block144_1b_kernel, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, dw_w, dw_b,
+                       (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks);
+    ROMA_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(refiner_block_kernel<CP>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, dw_w, dw_b,
                      (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks, dbg);
   ROMA_LAUNCH_CHECK();

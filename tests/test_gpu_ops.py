@@ -638,20 +638,22 @@ def test_dwconv5x5_ring_repeated_launches_under_load(lib):
     assert bad == 0, f"{bad} of 200 launches differ"
 
 
-def test_refiner_block24_wave_repeated_launches_under_load(lib):
-    """refiner_block24_wave_kernel orders its ring with counted vmcnt waits only; a wrong count shows up as a timing
-    dependent mismatch, so: 150 launches against the workgroup kernel's result while a GEMM runs on a second stream."""
-    B, H, W, Cp = 4, 211, 333, 24
+@pytest.mark.parametrize("Cp,key", [(24, b"rb24w"), (144, b"rb144_1b")])
+def test_refiner_block_repeated_launches_under_load(lib, Cp, key):
+    """refiner_block24_wave_kernel / refiner_block144_1b_kernel order their rings with counted vmcnt waits (and one barrier
+    per row); a wrong count shows up as a timing dependent mismatch, so: 150 launches against the two-barrier workgroup
+    kernel's result while a GEMM runs on a second stream."""
+    B, H, W = (4, 211, 333) if Cp == 24 else (3, 150, 187)
     x = rnd(B, H, W, Cp, seed=1).to(torch.bfloat16).cuda()
     w, b = (rnd(25, Cp, seed=2, std=0.2)).cuda(), rnd(Cp, seed=3).cuda()
     pw, pb = rnd(Cp, Cp, seed=4, std=Cp ** -0.5).to(torch.bfloat16).cuda(), rnd(Cp, seed=5).cuda()
     ref = torch.empty_like(x)
-    lib.roma_tuning(b"rb24w", 0)
+    lib.roma_tuning(key, 0)
     try:
         ok(lib, lib.roma_op_refiner_block(P(x), P(ref), P(w), P(b), P(pw), P(pb), B, H, W, Cp, BF16, None))
         torch.cuda.synchronize()
     finally:
-        lib.roma_tuning(b"rb24w", -1)
+        lib.roma_tuning(key, -1)
     A = rnd(8192, 1024, seed=6).to(torch.bfloat16).cuda()
     Wg = rnd(1024, 1024, seed=7, std=0.03).to(torch.bfloat16).cuda()
     Cg = torch.empty((8192, 1024), device="cuda", dtype=torch.bfloat16)
@@ -693,15 +695,17 @@ def test_refiner_block_fused(lib, Cp, B, H, W):
         outs.append(out)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     out = outs[0]
-    if Cp == 24:  # the wave-private kernel (default) against the workgroup kernel: same arithmetic, same bits
-        lib.roma_tuning(b"rb24w", 0)
-        try:
-            o2 = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=torch.bfloat16)
-            ok(lib, lib.roma_op_refiner_block(P(xin), P(o2), P(wp), P(b.cuda()), P(pw.cuda()), P(pb.cuda()), B, H, W, Cp, BF16, None))
-            torch.cuda.synchronize()
-        finally:
-            lib.roma_tuning(b"rb24w", -1)
-        assert torch.equal(out.view(torch.int16), o2.view(torch.int16))
+    # the default kernels (C = 24: wave-private, C = 144: one barrier per row) against the two-barrier workgroup kernel:
+    # same arithmetic, same bits
+    key = b"rb24w" if Cp == 24 else b"rb144_1b"
+    lib.roma_tuning(key, 0)
+    try:
+        o2 = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ok(lib, lib.roma_op_refiner_block(P(xin), P(o2), P(wp), P(b.cuda()), P(pw.cuda()), P(pb.cuda()), B, H, W, Cp, BF16, None))
+        torch.cuda.synchronize()
+    finally:
+        lib.roma_tuning(key, -1)
+    assert torch.equal(out.view(torch.int16), o2.view(torch.int16))
     got = out.cpu().double()
     assert torch.isfinite(got).all()
     # bf16 output rounding (2^-8 relative) + the occasional 1-ulp flip of the bf16 intermediate
