@@ -14,13 +14,6 @@ echo "== bench (default)"
 timeout 900 python bench.py --steps 20 --warmup 3 > "$OUT/bench_bf16.json" 2> "$OUT/bench_bf16.err"; tail -1 "$OUT/bench_bf16.err" | cut -c1-200; cut -c1-300 "$OUT/bench_bf16.json"
 echo "== bench, one stream"
 timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-other-configs --streams 1 > "$OUT/bench_bf16_1stream.json" 2> "$OUT/bench_bf16_1stream.err"; cut -c1-240 "$OUT/bench_bf16_1stream.json"
-echo "== gather-list kernel: 4 vs 8 waves per workgroup"
-for lw in 8 4; do
-  ROMA_LC_LISTW=$lw timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-other-configs > "$OUT/bench_listw$lw.json" 2> "$OUT/bench_listw$lw.err"
-  python -c "
-import json; r=json.load(open('$OUT/bench_listw$lw.json')); k=r['kernels']
-print('listw $lw', round(r['value'],2), 'pairs/s', {n:round(v['ms_per_step'],3) for n,v in k.items() if n.startswith('local_corr')})"
-done
 echo "== kernel trace of the bench"
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity --no-other-configs --streams 1 > "$OUT/prof.log" 2>&1
