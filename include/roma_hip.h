@@ -89,7 +89,13 @@ int roma_destroy(roma_handle_t h);
  * route the large bf16 GEMMs to the 8-phase kernel or keep them on the one-barrier-per-slab kernel (-1 = environment
  * ROMA_GEMM8P, default on); "gemm_dbg" = experiment bits of the GEMM kernels (-1 = environment ROMA_GEMM_DBG);
  * "lc_mode" = local correlation: 0 tiled LDS form with a per-tile gather work list (default), 1 every tile on the gather
- * list, 2 the per-pixel kernel of round 1 (-1 = environment ROMA_LC_MODE). */
+ * list, 2 the per-pixel kernel of round 1, 3 the VALU tile kernel (-1 = environment ROMA_LC_MODE); "conv64" = bit mask of the
+ * weight-stationary VGG front-end kernels; "attn_xcd" 1 / 0 = attention work items in per-XCD bands; "attn_v" 2 / 1 =
+ * attention kernel generation (2 = deferred-rescale kernel, default); "dw_ring" 0 / 1 / 2 = depthwise 5x5: register-prefetch
+ * kernel / wave-private ring kernel for launches >= 64 M elements (default) / ring kernel for every shape it takes;
+ * "rb24w" 1 / 0 = C = 24 fused block: wave-private kernel (default) / two-barrier workgroup kernel; "rb144_1b" 1 / 0 = C = 144
+ * fused block: one barrier per row (default) / two.  Every alternative computes the same values (the stencil / block
+ * kernels bit for bit); -1 restores the default (or the environment variable of the same name in upper case, ROMA_...). */
 int roma_tuning(const char* key, int value);
 int roma_profile_enable(int on);
 long roma_profile_report(char* buf, long nbytes);
