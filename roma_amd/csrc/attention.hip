@@ -326,6 +326,10 @@ __global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_bf16_kernel(const 
 // The K / V tiles are double buffered in LDS (one barrier per tile instead of two).  Also measured and not kept: all V^T
 // fragments of a tile requested before the softmax instead of one right before each MFMA - no change at three workgroups
 // per CU (5.239 vs 5.248 ms, profiles/r03_v11_attention.log), and slower when the 32 extra registers cost the third workgroup (v2 / v1 = 0.956 instead of 0.907, profiles/r03_v10_attention.log).
+// Neither did a software-pipelined form - the score MFMAs of tile t + 1 issued ahead of the softmax of tile t into a second
+// accumulator set, K one tile ahead of V through the buffers: correct (same tests), but its 206 registers leave two
+// workgroups per CU and it ran 5.65-5.69 ms against 5.27-5.28 (profiles/r03_v18_attention_pipelined.log): a third wave per
+// SIMD hides the softmax better than the wave's own look-ahead.
 // K / V addressing is a uniform tile pointer + a per-thread 32-bit offset (the kernel above rebuilt 64-bit addresses
 // every tile and spilled 8-10 registers at its 128-register cap).
 __device__ __forceinline__ float attn_max_halves(float t) {  // max of lane i and lane i ^ 32, in both
@@ -507,7 +511,6 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_h16_v2_kernel(cons
   }
 }
 #undef ROMA_ATTN_STAGE
-#undef ROMA_ATTN_FETCH2
 
 int g_attn_version = -1;  // roma_tuning("attn_v", v): 2 = attn_h16_v2_kernel (default), 1 = attn_bf16_kernel, -1 = env ROMA_ATTN_V
 int g_attn_xcd_map = -1;  // roma_tuning("attn_xcd", v): 1 = per-XCD bands of (b, head) (default), 0 = plain order, -1 = env ROMA_ATTN_XCD
