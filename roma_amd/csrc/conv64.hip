@@ -158,12 +158,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const bf16_t* __res
 
   bf16_t* outb = out + (long)b * H * W * COUT;
   for (int o = 0; o < sy; ++o) {
-    // input row ys + o + 1 (the last of this output row's three) was issued one iteration ago, behind it only the 4
-    // output stores of that iteration; first iteration: everything the prologue issued
+    // input row ys + o + 1 (the last of this output row's three) was issued one iteration ago; behind it only the 4 output
+    // stores of that iteration, which may NOT stay in flight: a store can retire before an older load, so vmcnt(4) would
+    // let a wave through with the row still on its way (dwconv_ring.hip).  First iteration: everything the prologue issued.
     if (o == 0) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     } else {
-      C64_WAIT_VM(4);
+      C64_WAIT_VM(0);
     }
     __builtin_amdgcn_s_barrier();
     C64_ISSUE_ROW(ys + o + 2, (o + 3) & 3)  // into the slot of input row ys + o - 2: every wave is past its last read

@@ -155,9 +155,6 @@ __global__ __launch_bounds__(256, 2) void dwconv5x5_ring_kernel(const bf16_t* __
   const int xb = xg * DWR_PXW + xq * 4;   // first output column of this lane
   const int x0 = xg * DWR_PXW - 2;        // image column of ring pixel 0
   const int npx = min(4, W - xb);         // valid output columns of this lane (<= 0: the lane only helps with the DMA)
-  // the counted waits assume 4 store instructions per row; in a tile with fewer than 4 valid columns some of them have no
-  // active lane and may be skipped, so such a tile waits conservatively (only the DMA may stay in flight)
-  const bool edge = W - xg * DWR_PXW < 4;
 
   // ---- DMA descriptors: piece p = 64 i + lane of a row -> ring slot p >> 3 (slot s holds pixel s - s / 5, s % 5 == 4
   // stays empty), 16-byte part p & 7 of the pixel's 128-byte channel line
@@ -200,25 +197,23 @@ __global__ __launch_bounds__(256, 2) void dwconv5x5_ring_kernel(const bf16_t* __
 
   int slot = 0;       // ring slot of input row t
   int fill = NR - 1;  // ring slot the next DMA goes to (= slot of row t - 1)
-  // Row t is complete once at most the operations issued AFTER its DMA are outstanding: the DMA of rows t + 1 .. t + NR - 1
-  // (3 each) and the 4 output stores of every iteration s in [t - NR + 1, t - 1] that had an output row (s >= 4).
-#define ROMA_DWR_WAIT_CASE(K) \
-  case K: ROMA_DWR_WAIT_VM(3 * (NR - 1) + 4 * K); break;
+  // Row t has landed once at most the DMA issued AFTER it is outstanding: rows t + 1 .. t + NR - 1, 3 pieces each.  The output
+  // stores of the last iterations are younger than that DMA too, but they may NOT be added to the allowance: vmcnt counts
+  // loads and stores in one counter, loads retire in order among themselves and so do stores, but a store can retire before
+  // an OLDER load - with an allowance of 3 (NR - 1) + 4 k a wave whose young stores were acknowledged early would pass the
+  // wait with row t still in flight and read the slot's previous row (seen as 1-in-1000 one-ulp patches in the two-stream
+  // stress, profiles/r03_v20_determinism_stress.log).  With the allowance equal to the number of younger LOADS the wait is
+  // exact: if row t were outstanding, so would be all 3 (NR - 1) younger pieces.
 #pragma nounroll
   for (int t = 0; t < T; ++t) {
     ROMA_DWR_ISSUE(t + NR - 1, fill);
-    const int kst = edge ? 0 : min(max(t - 4, 0), NR - 1);
-    switch (kst) {
-      ROMA_DWR_WAIT_CASE(0) ROMA_DWR_WAIT_CASE(1) ROMA_DWR_WAIT_CASE(2) ROMA_DWR_WAIT_CASE(3) ROMA_DWR_WAIT_CASE(4)
-      default: ROMA_DWR_WAIT_VM(3 * (NR - 1) + 4 * (NR - 1)); break;
-    }
+    ROMA_DWR_WAIT_VM(3 * (NR - 1));
     const int o = t - 4;
     dwr_row(acc, wreg, bias0, bias1, rd0 + (unsigned)slot * DWR_ROWB, o >= 0 && npx > 0,
             obase + ((long)(ys + max(o, 0)) * W + xb) * Cp, (long)Cp, npx);
     fill = slot;
     slot = slot + 1 == NR ? 0 : slot + 1;
   }
-#undef ROMA_DWR_WAIT_CASE
 #undef ROMA_DWR_ISSUE
   ROMA_DWR_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
 }

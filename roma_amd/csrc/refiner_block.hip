@@ -343,13 +343,10 @@ __global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __r
         }
       }
     }
-    // input row t+1 must have landed: everything issued after its DMA may stay in flight.  That is the DMA of rows
-    // t+2 .. t+NR (kw pieces each) plus, in steady state, the 2 output stores of each of the last NR-1 iterations.
-    if (t >= NR + 3) {
-      if (kw == KW) ROMA_RB_WAIT_VM((NR - 1) * (KW + 2)); else ROMA_RB_WAIT_VM((NR - 1) * (KW + 1));
-    } else {
-      if (kw == KW) ROMA_RB_WAIT_VM((NR - 1) * KW); else ROMA_RB_WAIT_VM((NR - 1) * (KW - 1));
-    }
+    // input row t+1 must have landed: the DMA issued after it may stay in flight - rows t+2 .. t+NR, kw pieces each.  (The
+    // output stores of the last iterations are younger than that DMA as well but must not be added to the allowance: vmcnt
+    // counts loads and stores together and a store can retire before an older load - dwconv_ring.hip.)
+    if (kw == KW) ROMA_RB_WAIT_VM((NR - 1) * KW); else ROMA_RB_WAIT_VM((NR - 1) * (KW - 1));
     ROMA_RB_BARRIER();  // B3: Ot complete, input row t+1 visible to every wave
     if (o >= 0 && !(dbg & 4)) {
       // stream the row out: always exactly two 16-byte stores per lane (clamped duplicates keep the count uniform)
@@ -396,7 +393,6 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
   constexpr int GC = Cf::GC, XQ = Cf::XQ, PX = Cf::PX, KS = Cf::KS, NR = RB1_NR, KW = Cf::KW;
   constexpr int XROW = Cf::XROW, NDMA = Cf::NDMA, RSTRIDE = Cf::RSTRIDE, OPIX = Cf::OPIX;
   static_assert(Cf::PXB == 1 && Cf::NBF == 4 && Cf::TAIL == 16, "one 32-pixel block, four full channel blocks + 16");
-  static_assert((NR - 2) * KW + (NR - 1) * 3 < 64, "vmcnt range");
   __shared__ __attribute__((aligned(1024))) unsigned char ring[NR * RSTRIDE];
   __shared__ __attribute__((aligned(16))) unsigned char work[Cf::OFF_XT];          // taps, 1x1 bias, remainder weights
   __shared__ __attribute__((aligned(16))) unsigned char xtb[2 * RB1_XT];           // Xt, double buffered
@@ -584,17 +580,10 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
         acc[4][px][1] = bias1;
       }
     }
-    // this wave's pieces of input row t + 1 must have landed: everything issued after them may stay in flight - the DMA of
-    // rows t + 2 .. t + NR - 1 (row t + NR is issued below) and the 3 stores of each of the last NR - 1 iterations that
-    // had an output row (iterations >= 4)
-    {
-      const int kst = min(max(t - 4, 0), NR - 1);
-      if (kw == KW) {
-        if (kst == 0) ROMA_RB_WAIT_VM((NR - 2) * KW); else if (kst == 1) ROMA_RB_WAIT_VM((NR - 2) * KW + 3); else ROMA_RB_WAIT_VM((NR - 2) * KW + 6);
-      } else {
-        if (kst == 0) ROMA_RB_WAIT_VM((NR - 2) * (KW - 1)); else if (kst == 1) ROMA_RB_WAIT_VM((NR - 2) * (KW - 1) + 3); else ROMA_RB_WAIT_VM((NR - 2) * (KW - 1) + 6);
-      }
-    }
+    // this wave's pieces of input row t + 1 must have landed: the DMA issued after them may stay in flight - row t + 2 only
+    // (row t + NR is issued below).  The stores of the last iterations are NOT part of the allowance (a store can retire
+    // before an older load: dwconv_ring.hip); they were issued a whole stencil ago.
+    if (kw == KW) ROMA_RB_WAIT_VM((NR - 2) * KW); else ROMA_RB_WAIT_VM((NR - 2) * (KW - 1));
     ROMA_RB_BARRIER();  // Xt[t & 1] complete; every wave is done with ring slot `slot`; input row t + 1 is visible
     ROMA_RB1_ISSUE_ROW(t + NR, slot);
     if (o >= 0) {

@@ -16,7 +16,7 @@
 //     two 32-pixel MFMA blocks (the second one 8 pixels + zeros) x 2 k-steps against the 1x1 weights held in registers,
 //     bias in the accumulator init; the result is packed into a wave-private Ot[40][24] and leaves as 120 contiguous
 //     16-byte pieces, two stores per lane;
-//   * the only thing that orders anything is the wave's own counted `s_waitcnt vmcnt` (3 DMA + 2 stores per row) and the
+//   * the only thing that orders anything is the wave's own counted `s_waitcnt vmcnt` (allowance = the younger DMA) and the
 //     in-order LDS pipeline: NO barrier after the weights have been staged, the waves drift freely, and a wave whose tile is
 //     off the image simply leaves.
 //   * arithmetic and its order are those of refiner_block_kernel<24>: results are bit-identical (tests).
@@ -52,7 +52,7 @@ constexpr int RBW_RING = 4 * RBW_NR * RBW_ROWB;           // 48 KiB per workgrou
 constexpr int RBW_WORK = 4 * (RBW_XT + RBW_OT);           // 28 KiB
 constexpr int RBW_WSM = 26 * RBW_C * 4;                   // depthwise taps + bias, f32
 static_assert(RBW_RING + RBW_WORK + RBW_WSM <= 80 * 1024, "two workgroups per CU");
-static_assert(3 * (RBW_NR - 1) + 2 * (RBW_NR - 1) <= 63, "vmcnt is a 6-bit counter");
+static_assert(3 * (RBW_NR - 1) <= 63, "vmcnt is a 6-bit counter");
 
 #define ROMA_RBW_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
   const int x0 = xw0 - 2;                  // image column of ring pixel 0
   const int npw = min(RBW_PXW, W - xw0);   // valid output columns of the wave (>= 1)
   const int nvp = npw * 3;                 // valid 16-byte pieces of an output row
-  const bool two_stores = nvp > 64;        // wave-uniform: the counted waits assume this many store instructions per row
+  const bool two_stores = nvp > 64;        // wave-uniform
 
   // ---- 1x1 weights of all 24 output channels: A operand (row = channel, 8 consecutive k per lane), rows / k >= 24 zero
   u32x4_t wA[2];
@@ -170,18 +170,12 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
   for (int rr = 0; rr < NR - 1; ++rr) ROMA_RBW_ISSUE(rr, rr);
 
   int slot = 0, fill = NR - 1;
-  // Row t has landed once at most the operations issued AFTER its DMA are outstanding: the DMA of rows t+1 .. t+NR-1 (3 each)
-  // and the 2 output stores of every iteration s in [t-NR+1, t-1] that had an output row (s >= 4).
-#define ROMA_RBW_WAIT_CASE(K) \
-  case K: ROMA_RBW_WAIT_VM(3 * (NR - 1) + 2 * K); break;
+  // Row t has landed once at most the DMA issued AFTER it is outstanding: rows t + 1 .. t + NR - 1, 3 pieces each.  (The
+  // younger output stores must not be added to the allowance - a store can retire before an older load: dwconv_ring.hip.)
 #pragma nounroll
   for (int t = 0; t < T; ++t) {
     ROMA_RBW_ISSUE(t + NR - 1, fill);
-    const int kst = two_stores ? min(max(t - 4, 0), NR - 1) : 0;  // (one store per row: wait conservatively)
-    switch (kst) {
-      ROMA_RBW_WAIT_CASE(0) ROMA_RBW_WAIT_CASE(1) ROMA_RBW_WAIT_CASE(2)
-      default: ROMA_RBW_WAIT_VM(3 * (NR - 1) + 2 * (NR - 1)); break;
-    }
+    ROMA_RBW_WAIT_VM(3 * (NR - 1));
     const int o = t - 4;  // output row (relative to ys) finished by input row t
     if (active) {
       unsigned long long cr[8];
@@ -288,7 +282,6 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
     fill = slot;
     slot = slot + 1 == NR ? 0 : slot + 1;
   }
-#undef ROMA_RBW_WAIT_CASE
 #undef ROMA_RBW_ISSUE
   ROMA_RBW_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
 }
