@@ -359,7 +359,7 @@ def test_dma_ring_kernels_keep_their_queue(built_lib):
     register budgets and counted waits: a spilled register is a scratch (VMEM) access that drains the counted DMA queue, and
     an `s_waitcnt vmcnt(0)` that hipcc puts in front of an LDS access it cannot tell apart from the DMA target does the same
     (refiner_block24w: Ot as a slice of the Xt object got one per row).  Held here on the built objects: no spills, and
-    between the first and the last `global_load_lds` of the row loop no full drain other than the counted constants."""
+    in the row loop exactly one wait constant: the number of younger DMA pieces."""
     import re
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources
@@ -382,7 +382,10 @@ def test_dma_ring_kernels_keep_their_queue(built_lib):
             if re.search(r"s_cbranch_\w+ 6[0-9]{4}\b|s_branch 6[0-9]{4}\b", ln):  # negative 16-bit offset = backward
                 break
         waits = [int(m.group(1)) for ln in body for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", ln)] if m]
-        assert waits and min(waits) >= 9, (f, waits)  # >= 3 DMA x (NR - 1 >= 3) rows stay in flight
+        # exactly the younger DMA may stay in flight - 3 pieces x (NR - 1) rows - and nothing else: no full drain, and no
+        # allowance for the younger output stores either (a store can retire before an older load; the 1-in-1000 stale-row
+        # reads of profiles/r03_v20_determinism_stress.log)
+        assert waits and set(waits) == {15 if f == "dwconv_ring.o" else 9}, (f, waits)
     att = [k for k in kernel_resources.kernels(objs["attention.o"]) if "attn_h16_v2_kernel" in k["name"]]
     assert len(att) == 8 and all(k["spill"] == 0 for k in att), att
     assert all(k["vgpr"] <= (168 if "<64" in k["name"] else 256) for k in att), att  # 3 / 2 workgroups per CU
