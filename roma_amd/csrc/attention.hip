@@ -445,7 +445,11 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_h16_v2_kernel(cons
       for (int r = 0; r < 16; ++r) tm[(2 * kt + (r >> 3)) & 3] = fmaxf(tm[(2 * kt + (r >> 3)) & 3], s[kt][r]);
     float tmax = attn_max_halves(fmaxf(fmaxf(tm[0], tm[1]), fmaxf(tm[2], tm[3])));
     const bool first = kv0 == 0;
-    if (__builtin_amdgcn_ballot_w64(first || tmax > THR) != 0) {  // wave-uniform: move the reference (rare after tile 0)
+    // wave-uniform decision: move the reference (rare after tile 0).  Padding queries (qi >= N) have no vote: their Q rows
+    // are whatever the workspace holds (the model's DINOv2 and decoder layouts share it, so "padding" of one is data of the
+    // other), and a vote of theirs would make the rounding of the VALID queries of the wave depend on that leftover - seen
+    // as run-to-run differences of the last patch token, amplified by the coarse arg-max (profiles/r03_v24_*.log).
+    if (__builtin_amdgcn_ballot_w64(first || (qi < a.N && tmax > THR)) != 0) {
       const float delta = first ? tmax : fmaxf(tmax, 0.f);
       if (!first) {  // O and l are still zero on the first tile (and alpha could overflow there)
         const float alpha = EXP2 ? __builtin_amdgcn_exp2f(-delta) : __expf(-delta);
@@ -520,6 +524,8 @@ int attention_launch(const AttnArgs& a_in, hipStream_t stream) {
   ROMA_REQUIRE(a.hd == 64 || a.hd == 128, "attention: head dim must be 64 or 128");
   ROMA_REQUIRE(a.npad % 128 == 0 && a.npad >= a.N, "attention: Npad must be a multiple of 128 and >= N");
   ROMA_REQUIRE(a.ldo % 4 == 0, "attention: ldo must be a multiple of 4");
+  static const bool force_exp2 = getenv("ROMA_ATTN_FORCE_EXP2") && atoi(getenv("ROMA_ATTN_FORCE_EXP2")) != 0;  // tools/attn_determinism.py
+  if (force_exp2) a.exp2_domain = 1;
   const long nwork = (long)((a.N + 127) / 128) * a.heads * a.B;
   static const int map_env = getenv("ROMA_ATTN_XCD") ? atoi(getenv("ROMA_ATTN_XCD")) : 1;
   a.xcd_map = g_attn_xcd_map >= 0 ? g_attn_xcd_map : map_env;

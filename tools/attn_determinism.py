@@ -1,0 +1,55 @@
+"""Run-to-run determinism of the attention kernels at the model's shapes (GPU box): the same operands, N launches, bitwise
+compare; then version 2 against version 1.  ROMA_ATTN_FORCE_EXP2=1 selects the exp2-domain instantiation the model uses."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from roma_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def run(B, heads, hd, N, runs=12, spiky=False):
+    npad = (N + 127) // 128 * 128
+    g = torch.Generator().manual_seed(3)
+    q = torch.zeros((B, heads, npad, hd), dtype=torch.bfloat16)
+    k = torch.zeros_like(q)
+    vt = torch.zeros((B, heads, hd, npad), dtype=torch.bfloat16)
+    q[:, :, :N] = (torch.randn(B, heads, N, hd, generator=g) * 1.2 / hd ** 0.5).to(torch.bfloat16)
+    k[:, :, :N] = (torch.randn(B, heads, N, hd, generator=g) * 1.5).to(torch.bfloat16)
+    vt[:, :, :, :N] = torch.randn(B, heads, hd, N, generator=g).to(torch.bfloat16)
+    if spiky:  # keys that score far above the running reference at scattered tiles: the deferred-rescale branch fires
+        for t in range(70, N, 131):
+            k[:, :, t] = (k[:, :, t].float() * 9.0).to(torch.bfloat16)
+    q, k, vt = q.cuda(), k.cuda(), vt.cuda()
+    outs = {}
+    for ver in (2, 1):
+        lib.roma_tuning(b"attn_v", ver)
+        res = []
+        for _ in range(runs):
+            o = torch.full((B * N, heads * hd), float("nan"), device="cuda", dtype=torch.bfloat16)
+            assert lib.roma_op_attention(P(q), P(k), P(vt), P(o), B, heads, N, npad, hd, 1, 1, None) == 0
+            torch.cuda.synchronize()
+            res.append(o)
+        nd = sum(int(not torch.equal(res[0].view(torch.int16), r.view(torch.int16))) for r in res[1:])
+        worst = max(float((res[0].float() - r.float()).abs().max()) for r in res[1:])
+        nbad = max(int((res[0].view(torch.int16) != r.view(torch.int16)).sum()) for r in res[1:])
+        print(f"B{B} h{heads} hd{hd} N{N} spiky={int(spiky)} v{ver}: {nd}/{runs - 1} launches differ from the first (max abs {worst:.3e}, {nbad} elements), "
+              f"finite={bool(torch.isfinite(res[0].float()).all())}", flush=True)
+        outs[ver] = res[0]
+    lib.roma_tuning(b"attn_v", -1)
+    print(f"   v2 vs v1: max abs {float((outs[2].float() - outs[1].float()).abs().max()):.3e}", flush=True)
+
+
+if __name__ == "__main__":
+    for spiky in (False, True):
+        run(8, 16, 64, 1601, spiky=spiky)
+        run(8, 8, 128, 1600, spiky=spiky)
+        run(2, 16, 64, 257, spiky=spiky)
