@@ -265,6 +265,26 @@ def test_bf16_full8_vs_reference_golden(full_models):
     _bf16_vs_golden("bf16_full8", full_models["bf16"], _dev(synthetic.make_inputs(8, 560, 864, seed=1)), g)
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
+def test_h16_full8_reproducible_and_stream_split_exact(full_models, fmt):
+    """At the benchmark's size and batch: repeated calls agree bit for bit, and so do the two-stream and the single-stream
+    schedule.  The 112 -> 168 stress (tests/test_gpu_match.py) cannot see what only appears with N = 1601 tokens or with
+    launches large enough for the ring kernels - round 3's attention kernel let padding queries vote on a wave-wide
+    decision, which made the last patch token depend on leftover workspace data at this size only."""
+    from roma_amd import synthetic
+    m = full_models[fmt]
+    inp = _dev(synthetic.make_inputs(8, 560, 864, seed=1))
+    outs = []
+    for dual in (True, True, False, True, False):
+        m.dual_stream = dual
+        w, c, _ = _run(m, inp)
+        outs.append((w, c))
+    m.dual_stream = True
+    for i, (w, c) in enumerate(outs[1:], 1):
+        assert np.array_equal(w, outs[0][0]) and np.array_equal(c, outs[0][1]), (
+            i, float(np.abs(w - outs[0][0]).max()), float(np.abs(c - outs[0][1]).max()))
+
+
 def test_f16_full8_vs_reference_golden(full_models):
     """The bench workload in the reference's DEFAULT precision policy (amp_dtype=torch.float16: IEEE binary16 storage,
     libroma_hip_f16.so) against the reference's fp32 output: same gates, 4 x tighter bounds."""
