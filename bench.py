@@ -99,9 +99,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (default 8; 1 for --config coarse)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"],
-                    help="bf16 = the metric's dtype (the reference's timing script); f16 = the reference's default amp_dtype "
-                         "(IEEE binary16 storage, libroma_hip_f16.so); f32 = the exact parity mode")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "mixed"],
+                    help="bf16 = the metric's dtype, one 16-bit format everywhere; f16 = the reference's default amp_dtype "
+                         "(IEEE binary16 storage, libroma_hip_f16.so); mixed = what the reference's timing script really runs: "
+                         "bf16 DINOv2 + binary16 VGG / decoder / refiners (ROMA_MIXED); f32 = the exact parity mode")
     ap.add_argument("--config", default="full", choices=["full", "coarse"],
                     help="full = 560 -> 864 upsample path (the metric); coarse = coarse-only 560 (BASELINE config 2)")
     ap.add_argument("--coarse", type=int, default=560)
@@ -152,9 +153,10 @@ def main():
     else:
         from roma_amd import _lib, roma_outdoor
         sd, dsd = synthetic.make_matcher_state_dict(0), synthetic.make_dinov2_state_dict(0)
-        amp = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+        amp = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "mixed": torch.bfloat16}[args.dtype]
         model = roma_outdoor(device=dev, weights=sd, dinov2_weights=dsd, coarse_res=args.coarse, upsample_res=args.upsample,
-                             amp_dtype=amp, symmetric=True, upsample_preds=full, max_batch=args.batch)
+                             amp_dtype=amp, symmetric=True, upsample_preds=full, max_batch=args.batch,
+                             decoder_dtype=torch.float16 if args.dtype == "mixed" else None)
         model.dual_stream = args.streams == 2
         inp = {k: v.to(dev) for k, v in synthetic.make_inputs(args.batch, args.coarse, args.upsample if full else None,
                                                               seed=1 + rank).items()}
@@ -375,10 +377,11 @@ def main():
         import parity_metrics as PM
 
         def side_config(dtype, is_full, batch, steps, warmup, seed_w, seed_in, golden):
-            amp_ = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype]
+            amp_ = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "mixed": torch.bfloat16}[dtype]
             sd_, dsd_ = (sd, dsd) if seed_w == 0 else (synthetic.make_matcher_state_dict(seed_w), synthetic.make_dinov2_state_dict(seed_w))
             m_ = roma_outdoor(device=dev, weights=sd_, dinov2_weights=dsd_, coarse_res=560, upsample_res=864, amp_dtype=amp_,
-                              symmetric=True, upsample_preds=is_full, max_batch=batch)
+                              symmetric=True, upsample_preds=is_full, max_batch=batch,
+                              decoder_dtype=torch.float16 if dtype == "mixed" else None)
             i_ = {k: v.to(dev) for k, v in synthetic.make_inputs(batch, 560, 864 if is_full else None, seed=seed_in).items()}
             kw_ = dict(im_A_high_res=i_["im_A_high_res"], im_B_high_res=i_["im_B_high_res"]) if is_full else {}
             run = lambda: m_.match(i_["im_A"], i_["im_B"], **kw_)  # noqa: E731
@@ -420,6 +423,9 @@ def main():
             "config2_coarse_only_b1_bf16": side_config("bf16", False, 1, 30, 5, 0, 1, "match_full_coarse.npz"),
             "config5_indoor_f32_b8": side_config("f32", True, 8, 3, 1, 2, 3, "match_full8_indoor.npz"),
             "f16_storage_b8 (the reference's default amp_dtype)": side_config("f16", True, 8, 10, 3, 0, 1, "match_full8.npz"),
+            # the precision mix the reference's timing script really runs (amp_dtype = bfloat16 reaches DINOv2 only,
+            # roma_models.py:183-188; VGG / decoder / refiners autocast to float16): the parity-bearing 16-bit line
+            "mixed_bf16_dinov2_f16_rest_b8 (the reference timing script's policy)": side_config("mixed", True, 8, 10, 3, 0, 1, "match_full8.npz"),
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -28,7 +28,12 @@ typedef struct roma_model* roma_handle_t;
  * bfloat16 and accepts ROMA_F32 / ROMA_BF16; libroma_hip_f16.so (same sources, -DROMA_H16_F16) stores IEEE binary16 - the
  * reference's default amp_dtype (model_zoo/__init__.py:37) - and accepts ROMA_F32 / ROMA_F16.  The other code is an error
  * (ROMA_ERR_ARG), never a reinterpretation.  roma_h16_format() returns the code of the loaded library. */
-enum { ROMA_F32 = 0, ROMA_BF16 = 1, ROMA_F16 = 2 };
+enum { ROMA_F32 = 0, ROMA_BF16 = 1, ROMA_F16 = 2,
+       /* the precision policy the reference's own timing script runs (tests/test_roma_upsample_inference_time.py:36-45):
+        * amp_dtype = bfloat16 reaches DINOv2 only (model_zoo/roma_models.py:183-188); the VGG pyramid, the decoder and the
+        * refiners keep binary16 (encoders.py:7, matcher.py:46,341).  Accepted by libroma_hip_f16.so, which loads
+        * libroma_hip.so from its own directory and runs DINOv2 there through roma_vit_forward. */
+       ROMA_MIXED = 3 };
 int roma_h16_format(void);
 enum { ROMA_ERR_ARG = -1, ROMA_ERR_HIP = -2, ROMA_ERR_STATE = -3 };
 
@@ -45,6 +50,41 @@ typedef struct {
 
 const char* roma_last_error(void);
 const char* roma_version(void);
+
+/* ---- DINOv2 ViT-L/14 as a stand-alone entry (dinov2.py:192-237: patch embed, cls + position embedding, 24 pre-norm
+ * blocks, final LayerNorm, patch tokens).  Everything is a DEVICE pointer prepared by the caller: weights in THIS
+ * library's 16-bit format (w) or f32 (everything else; LayerScale already folded into proj / fc2), workspace of the
+ * sizes given below.  act = ROMA_F32 or this library's 16-bit code.  Used by ROMA_MIXED handles of the other build. */
+typedef struct {
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+  const float *ls1, *ls2;                    /* per-channel LayerScale applied in the epilogue, or NULL when folded */
+  const void *qkv_w, *proj_w, *fc1_w, *fc2_w; /* [N][ldw], K-contiguous */
+  const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
+  int qkv_ldw, proj_ldw, fc1_ldw, fc2_ldw;
+} roma_vit_block_t;
+
+typedef struct {
+  int B, H, W;                      /* B pairs = 2B images: im_a[B,3,H,W], im_b[B,3,H,W] f32 (H, W multiples of 14) */
+  int act;                          /* ROMA_F32 or the library's 16-bit code */
+  int bf16_residual;                /* 16-bit mode: residual stream in 16 bits (the reference's bf16 backbone) */
+  const float *im_a, *im_b;
+  const void* patch_w;              /* [1024][patch_ldw], k = c*196 + ky*14 + kx, zero padded */
+  const float* patch_b;
+  int patch_ldw;
+  const float *cls_tok, *pos_emb;   /* [1024], [1 + T][1024] (already resized to the token grid) */
+  const roma_vit_block_t* blocks;   /* HOST array */
+  int nblocks;
+  const float *norm_w, *norm_b;
+  /* workspace, T = (H/14)(W/14), rows = 2B (T + 1), Npad = T + 1 rounded up to 128, e = bytes per activation element:
+   * col [2B T patch_ldw] e | pt [2B T 1024] f32 | x [rows 1024] f32 | xs [rows 1024] 2 B (16-bit residual only) |
+   * ln, ao [rows 1024] e | hid [rows 4096] e | q, k, vt [2B 16 Npad 64] e, zero-initialised once and never written by
+   * anyone else (the padding rows must stay zero) */
+  void *col, *pt, *x, *xs, *ln, *ao, *hid, *q, *k, *vt;
+  void* feat_out;                   /* [2B, T, 1024] patch tokens (x_norm_patchtokens), activation dtype */
+} roma_vit_args_t;
+int roma_vit_forward(const roma_vit_args_t* a, void* stream);
+/* bfloat16 bits -> this library's 16-bit format (the hand-over of a ROMA_MIXED handle), n elements */
+int roma_op_convert_from_bf16(const void* in_bf16, void* out_h16, long n, void* stream);
 
 int roma_create(const roma_config_t* cfg, roma_handle_t* out);
 /* name: a key of the reference's matcher state-dict, or "dinov2." + a key of the DINOv2 dict.
@@ -94,9 +134,14 @@ int roma_destroy(roma_handle_t h);
  * attention kernel generation (2 = deferred-rescale kernel, default); "dw_ring" 0 / 1 / 2 = depthwise 5x5: register-prefetch
  * kernel / wave-private ring kernel for launches >= 64 M elements (default) / ring kernel for every shape it takes;
  * "rb24w" 1 / 0 = C = 24 fused block: wave-private kernel (default) / two-barrier workgroup kernel; "rb144_1b" 1 / 0 = C = 144
- * fused block: one barrier per row (default) / two.  Every alternative computes the same values (the stencil / block
+ * fused block: one barrier per row (default) / two; "gemm8p_sched" 1 / 0 = K-loop schedule of the 8-phase GEMM: k-half
+ * phases (default) / quadrant phases (bit-identical results).  Every alternative computes the same values (the stencil / block
  * kernels bit for bit); -1 restores the default (or the environment variable of the same name in upper case, ROMA_...). */
 int roma_tuning(const char* key, int value);
+/* measuring tool (tools/bench_gemm_ablation.py): after a GEMM launched with the "gemm_dbg" trace bit (32768), copies the
+ * phase time stamps [workgroup < 16][wave group][K tile < 256][phase] (low 32 bits of s_memtime at each phase's first
+ * barrier release) to the host; returns the number of bytes written. */
+long roma_debug_gemm_trace(unsigned int* dst_host, long nbytes);
 int roma_profile_enable(int on);
 long roma_profile_report(char* buf, long nbytes);
 

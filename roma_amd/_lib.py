@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libroma_hip.so")
 LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(_HERE, "libroma_hip_f16.so")}
 
-ROMA_F32, ROMA_BF16, ROMA_F16 = 0, 1, 2
+ROMA_F32, ROMA_BF16, ROMA_F16, ROMA_MIXED = 0, 1, 2, 3
 H16_CODE = {"bf16": ROMA_BF16, "f16": ROMA_F16}
 
 
@@ -44,6 +44,9 @@ SIGNATURES = {
     "roma_debug_inject": (_i, [_vp, C.c_char_p, _vp, _l]),
     "roma_destroy": (_i, [_vp]),
     "roma_tuning": (_i, [C.c_char_p, _i]),
+    "roma_debug_gemm_trace": (_l, [_vp, _l]),
+    "roma_vit_forward": (_i, [_vp, _vp]),
+    "roma_op_convert_from_bf16": (_i, [_vp, _vp, _l, _vp]),
     "roma_profile_enable": (_i, [_i]),
     "roma_profile_report": (_l, [C.c_char_p, _l]),
     "roma_op_local_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -3,6 +3,7 @@
 #include <mutex>
 #include <map>
 #include <vector>
+#include <dlfcn.h>
 #include <string.h>
 
 #include "../../include/roma_hip.h"
@@ -16,6 +17,7 @@
 #include "kde.h"
 #include "keypoints.h"
 #include "tiny.h"
+#include "vit.h"
 #include "sampling.h"
 
 namespace roma {
@@ -42,6 +44,15 @@ void prof_end(hipStream_t s) { (void)hipEventRecord(g_prof.back().e1, s); }
 struct roma_model {
   roma::Model m;
 };
+
+namespace roma {
+// ROMA_MIXED: the sibling bfloat16 library (once a mixed handle has loaded it) keeps its own switches and its own launch
+// profile; tuning calls and the profile of THIS library are forwarded / merged so that callers see one library.
+void* g_peer_lib = nullptr;  // set by Model::load_peer (model.hip)
+template <typename F> static F peer_sym(const char* name) {
+  return g_peer_lib ? reinterpret_cast<F>(dlsym(g_peer_lib, name)) : nullptr;
+}
+}  // namespace roma
 
 using namespace roma;
 
@@ -85,7 +96,11 @@ int roma_create(const roma_config_t* cfg, roma_handle_t* out) {
   ROMA_REQUIRE(cfg->upsample_h >= 0 && cfg->upsample_w >= 0 && (cfg->upsample_h == 0 || (cfg->upsample_h >= 16 && cfg->upsample_w >= 16)),
                "roma_create: bad upsample resolution");
   ROMA_REQUIRE(cfg->max_batch >= 1, "roma_create: max_batch must be >= 1");
-  if (dt_code(cfg->precision) < 0) return ROMA_ERR_ARG;  // ROMA_F32 or this build's 16-bit format
+  if (cfg->precision == ROMA_MIXED) {  // bf16 DINOv2 (sibling library) + binary16 elsewhere: a mode of the binary16 build
+    ROMA_REQUIRE(ROMA_H16_CODE == ROMA_F16, "ROMA_MIXED: load libroma_hip_f16.so (it runs DINOv2 through libroma_hip.so)");
+  } else if (dt_code(cfg->precision) < 0) {
+    return ROMA_ERR_ARG;  // ROMA_F32 or this build's 16-bit format
+  }
   int ndev = 0;
   ROMA_CHECK_HIP(hipGetDeviceCount(&ndev));
   ROMA_REQUIRE(cfg->device >= 0 && cfg->device < ndev, "roma_create: no such HIP device (the HIP path has no CPU fallback)");
@@ -199,9 +214,11 @@ int roma_destroy(roma_handle_t h) {
 
 int roma_tuning(const char* key, int value) {
   ROMA_REQUIRE(key, "roma_tuning: null key");
+  if (auto f = peer_sym<int (*)(const char*, int)>("roma_tuning")) (void)f(key, value);
   const std::string k(key);
   if (k == "gemm8p") g_gemm_tuning[0] = value;
   else if (k == "gemm_dbg") g_gemm_tuning[1] = value;
+  else if (k == "gemm8p_sched") g_gemm8p_sched = value;
   else if (k == "lc_mode") g_lc_mode = value;
   else if (k == "conv64") g_conv64_mode = value;
   else if (k == "attn_xcd") g_attn_xcd_map = value;
@@ -216,7 +233,26 @@ int roma_tuning(const char* key, int value) {
   return 0;
 }
 
+int roma_vit_forward(const roma_vit_args_t* a, void* stream) {
+  ROMA_REQUIRE(a, "roma_vit_forward: null argument");
+  ROMA_REQUIRE(a->act == ROMA_F32 || a->act == ROMA_H16_CODE, "roma_vit_forward: act must be ROMA_F32 or this library's 16-bit code");
+  return vit_forward(*a, S(stream));
+}
+
+int roma_op_convert_from_bf16(const void* in_bf16, void* out_h16, long n, void* stream) {
+  ROMA_REQUIRE(in_bf16 && out_h16, "roma_op_convert_from_bf16: null pointer");
+  return convert_from_bf16_launch(in_bf16, out_h16, n, S(stream));
+}
+
+long roma_debug_gemm_trace(unsigned int* dst_host, long nbytes) {
+  ROMA_REQUIRE(dst_host && nbytes > 0, "roma_debug_gemm_trace: null destination");
+  if (hipDeviceSynchronize() != hipSuccess) return ROMA_ERR_HIP;
+  const int rc = gemm8p_trace_read(dst_host, nbytes);
+  return rc < 0 ? rc : std::min<long>(nbytes, (long)sizeof(unsigned) * 16 * 2 * 256 * 4);
+}
+
 int roma_profile_enable(int on) {
+  if (auto f = peer_sym<int (*)(int)>("roma_profile_enable")) (void)f(on);
   for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   g_prof.clear();
   g_prof_on = on != 0;
@@ -241,6 +277,16 @@ long roma_profile_report(char* buf, long nbytes) {
              kv.first.c_str(), kv.second.calls, kv.second.ms, kv.second.work, kv.second.unit.c_str());
     js += tmp;
     first = false;
+  }
+  if (auto f = peer_sym<long (*)(char*, long)>("roma_profile_report")) {  // the sibling library's launches (DINOv2 of a mixed handle)
+    const long n = f(nullptr, 0);
+    if (n > 3) {
+      std::string peer((size_t)n, '\0');
+      if (f(&peer[0], n) > 0) {
+        peer.resize(strlen(peer.c_str()));
+        if (peer.size() > 2) js += (first ? "" : ", ") + peer.substr(1, peer.size() - 2);
+      }
+    }
   }
   js += "}";
   if (!buf) return (long)js.size() + 1;

@@ -51,6 +51,16 @@ void set_error(const std::string& msg);
   } while (0)
 #define ROMA_LAUNCH_CHECK() ROMA_CHECK_HIP(hipGetLastError())
 
+// f32 -> bfloat16 bits (round-to-nearest-even) whatever this build's own h16 is: ROMA_MIXED handles of the binary16 build pack
+// their DINOv2 weights for the bfloat16 library with it (model.hip)
+__host__ __device__ inline unsigned short f32_to_bfloat16_bits(float f) {
+  union { uint32_t u; float f; } x;
+  x.f = f;
+  if ((x.u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((x.u >> 16) | 0x40);  // NaN
+  const uint32_t r = 0x7fffu + ((x.u >> 16) & 1u);
+  return (unsigned short)((x.u + r) >> 16);
+}
+
 // ---- h16 <-> f32 (round-to-nearest-even), usable on host and device ----
 #ifdef ROMA_H16_F16
 __host__ __device__ inline float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }

@@ -34,6 +34,9 @@ int assemble_tokens_launch(const float* patch, const float* cls, const float* po
 int copy2d_launch(const void* in, long ldi, int dt_in, void* out, long ldo, int dt_out, long rows, int cols,
                   hipStream_t s);
 
+// bfloat16 bits -> this build's 16-bit format, n elements (n % 4 == 0); identity in the bf16 build
+int convert_from_bf16_launch(const void* in, void* out, long n, hipStream_t s);
+
 // L2 norm of each row: in [M, C] (ld, dt) -> norms f32 [M]
 int rownorm_launch(const void* in, long ld, int dt, float* norms, long M, int C, hipStream_t s);
 

@@ -317,6 +317,27 @@ int copy2d_launch(const void* in, long ldi, int dt_in, void* out, long ldo, int 
   return 0;
 }
 
+// bfloat16 bits -> this build's 16-bit format (identity in the bf16 build): the hand-over of a ROMA_MIXED handle, whose
+// DINOv2 ran in the bfloat16 library.  autocast does the same cast when the binary16 proj head consumes the bf16 features.
+__global__ __launch_bounds__(256) void convert_from_bf16_kernel(const uint2* __restrict__ in, uint2* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const uint2 u = in[i];
+    uint2 r;
+    r.x = pack_bf16x2(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u));
+    r.y = pack_bf16x2(__uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    out[i] = r;
+  }
+}
+
+int convert_from_bf16_launch(const void* in, void* out, long n, hipStream_t s) {
+  ROMA_REQUIRE(n % 4 == 0 && n > 0, "convert_from_bf16: n must be a positive multiple of 4");
+  const long n4 = n / 4;
+  dim3 grid((unsigned)std::min<long>((n4 + 255) / 256, 65536));
+  hipLaunchKernelGGL(convert_from_bf16_kernel, grid, dim3(256), 0, s, (const uint2*)in, (uint2*)out, n4);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------ row L2 norms
 template <typename T>
 __global__ __launch_bounds__(256) void rownorm_kernel(const T* in, long ld, float* norms, long M, int C) {

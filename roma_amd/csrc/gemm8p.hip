@@ -53,9 +53,18 @@ int g_gemm_tuning[2] = {-1, -1};  // [0] gemm8p on / off, [1] dbg bits; -1 = env
 enum { E8_NONE = 0, E8_RELU = 1, E8_GELU = 2, E8_RESBF16 = 3, E8_QKV = 4 };
 
 #define R8_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-#define R8_DS_READ(REG, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(REG) : "v"(ADDR), "n"(OFF))
+#define R8_DS_READ(REG, ADDR, OFF)                                                               \
+  if constexpr (x_rd) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(REG) : "v"(ADDR), "n"(OFF)); \
+  else asm volatile("" : "=v"(REG)); /* no-read ablation: the register is (re)defined here, with whatever it holds */
 
-template <typename TOUT, bool CONV, int EPI, bool DMAMF>
+// ablation / trace build (ABL, tools/bench_gemm_ablation.py): phase time stamps of waves 0 and 4 of the first 16 workgroups
+// [workgroup][wave group][K tile < 256][phase] -> low 32 bits of s_memtime at the phase's first barrier release
+__device__ unsigned int g_gemm_trace[16 * 2 * 256 * 4];
+
+// SCHED 0: quadrant phases (reads 12 / 4 / 8 / 0 per phase).  SCHED 1 ("KH"): k-half phases (reads 8 / 6 / 6 / 4), see
+// the loop body.  ABL (measuring tool only, compile-time so that the loop carries no branches): 1 = phase trace above,
+// 2 = no fragment reads, 4 = no LDS-DMA, 8 = no MFMA (selected by a.dbg bits 32768 + 4096 / 8192 / 16384).
+template <typename TOUT, bool CONV, int EPI, bool DMAMF, int SCHED = 0, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int TILE_A = BM * ROWB, BUF = TILE_A + BN * ROWB;  // 64 KiB per K tile
@@ -191,6 +200,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
 
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   u32x4 af[2][4], bf0[4], bf1[4];  // A fragments [mt][k-group] of the current 64-row half; W fragments of both halves
+  // SCHED 1: A fragments [mt][k-group of the pair] of the current (half, k-pair); W halves 0 / 1 of k-pair 0 (fw*) and 1 (fw*n)
+  u32x4 fa[2][2], fw0[2], fw1[2], fw0n[2], fw1n[2];
+  constexpr bool x_rd = !(ABL & 2), x_dma = !(ABL & 4), x_mf = !(ABL & 8);
+  unsigned long long tstamp[4] = {0, 0, 0, 0};
 
 #define R8_READ_A(MH, SB)                                                                                     \
   _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int g = 0; g < 4; ++g)               \
@@ -219,6 +232,31 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
       acc[NH][(MH) * 2 + mt] = mfma_h16_32x32x16(BF[G],    \
                                                                        af[mt][G], \
                                                                        acc[NH][(MH) * 2 + mt]);
+  // ---- SCHED 1 ("KH") fragment reads / waits / MFMA blocks
+#define R8K_READ_A(MH, GP, SB)                                                                                \
+  _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int gl = 0; gl < 2; ++gl)            \
+      R8_DS_READ(fa[mt][gl], (SB) + a_row0 + rd[2 * (GP) + gl], ((MH) * 128 + mt * 32) * ROWB);
+#define R8K_READ_W(DST, NH, GP, SB) \
+  _Pragma("unroll") for (int gl = 0; gl < 2; ++gl) R8_DS_READ(DST[gl], (SB) + w_row0 + rd[2 * (GP) + gl], ((NH) * 128) * ROWB);
+#define R8K_WAIT_A() \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1])::"memory")
+#define R8K_WAIT_AW(W)                                                                                         \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                          \
+               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(W[0]), "+v"(W[1])::"memory")
+#define R8K_WAIT_AWW(W, V)                                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                          \
+               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(W[0]), "+v"(W[1]), "+v"(V[0]), \
+                 "+v"(V[1])::"memory")
+  // 8 MFMAs over the FOUR accumulators of row half MH (each reused after 4 MFMAs); k order per accumulator unchanged
+#define R8K_MFMA(MH, W0, W1)                                                                                   \
+  if (x_mf) {                                                                                                  \
+    _Pragma("unroll") for (int gl = 0; gl < 2; ++gl) {                                                         \
+      _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                         \
+          acc[0][(MH) * 2 + mt] = mfma_h16_32x32x16(W0[gl], fa[mt][gl], acc[0][(MH) * 2 + mt]);               \
+      _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                                                         \
+          acc[1][(MH) * 2 + mt] = mfma_h16_32x32x16(W1[gl], fa[mt][gl], acc[1][(MH) * 2 + mt]);               \
+    }                                                                                                          \
+  }
   // DMAMF phase (experiment, off by default): the two LDS-DMA pieces of the phase are issued BETWEEN the MFMAs (after the
   // 2nd and the 4th of 8) instead of in the load block.  The idea: an LDS-DMA instruction costs the issuing wave ~100-180
   // cycles in a block that also carries the fragment reads but ~60 among bare MFMAs (MI355X_MICROARCH.md).  Measured: no
@@ -244,9 +282,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
   __builtin_amdgcn_sched_barrier(0);             \
   __builtin_amdgcn_s_barrier();                  \
   __builtin_amdgcn_sched_barrier(0);
-#define R8_PHASE(WAIT, MF)                       \
+#define R8_PHASE(WAIT, MF) R8_PHASE_T(WAIT, MF, 0)
+#define R8_PHASE_T(WAIT, MF, PH)                 \
   __builtin_amdgcn_sched_barrier(0);             \
   __builtin_amdgcn_s_barrier();                  \
+  if constexpr ((ABL & 1) != 0) tstamp[PH] = __builtin_readcyclecounter(); \
   WAIT;                                          \
   __builtin_amdgcn_sched_barrier(0);             \
   if (prio) __builtin_amdgcn_s_setprio(1);       \
@@ -265,8 +305,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
 
   // ---- prologue: K tile 0 complete, A0 / W0 of K tile 1 under way (nk >= 2 is guaranteed by the dispatcher)
   R8_TILE_SETUP(c_tm, c_tn)
-  R8_ISSUE_A(0, 0, 0) R8_ISSUE_W(0, 0, 0) R8_ISSUE_W(1, 0, 0) R8_ISSUE_A(1, 0, 0)
-  R8_ISSUE_A(0, 1, 1) R8_ISSUE_W(0, 1, 1)
+  if constexpr (SCHED == 1) {
+    // KH stream order: ... A0(s) W0(s) W1(s) A1(s) | W0(s+1): K tile 0 complete, W0 of K tile 1 under way; the wait leaves
+    // A1(0) and W0(1) in flight (A1(0) is covered by the P1 wait of the first K tile)
+    R8_ISSUE_A(0, 0, 0) R8_ISSUE_W(0, 0, 0) R8_ISSUE_W(1, 0, 0) R8_ISSUE_A(1, 0, 0)
+    R8_ISSUE_W(0, 1, 1)
+  } else {
+    R8_ISSUE_A(0, 0, 0) R8_ISSUE_W(0, 0, 0) R8_ISSUE_W(1, 0, 0) R8_ISSUE_A(1, 0, 0)
+    R8_ISSUE_A(0, 1, 1) R8_ISSUE_W(0, 1, 1)
+  }
   R8_WAIT_VM(4);
   __builtin_amdgcn_s_barrier();
   if (stagger && wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0 from here on
@@ -326,29 +373,90 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
         R8_PHASE_DM(, 1, 0, bf0, if (n2) R8_ISSUE_W1(0, 0, k2, cb), if (n2) R8_ISSUE_W1(0, 1, k2, cb))
         continue;
       }
+      if constexpr (SCHED == 1) {
+        // "KH": a phase is one 64-row half x BOTH column halves x one k-pair (two of the four 16-deep k-groups), so the 24
+        // fragment reads of a K tile fall 8 / 6 / 6 / 4 on the four load blocks instead of 12 / 4 / 8 / 0 (P1's 48 KB
+        // per wave group is 192 LDS cycles + the read latency against the partner group's 256-cycle MFMA block), only
+        // 12 fragments are live instead of 16 (-16 VGPRs), and the 8 MFMAs of a phase rotate over 4 accumulators instead
+        // of 2.  Every accumulator still receives its k-groups in the order 0, 1, 2, 3: results are bit-identical.
+        //   P1: A0 W0 W1 of k-pair 0 -> rows 0;  P2: A1 k-pair 0 (+ W0 k-pair 1) -> rows 1;
+        //   P3: A1 k-pair 1 (+ W1 k-pair 1) -> rows 1;  P4: A0 k-pair 1 -> rows 0
+        // Region life times: W0 until P2, A1 and W1 until P3, A0 until P4, so the DMA stream is
+        //   P1(s): W1(s+1), P2(s): A0(s+1), P3(s): A1(s+1), P4(s): W0(s+2)        (each >= 2 phases after the last read)
+        // with TWO counted waits per K tile, each one phase ahead of the reads it covers: P4 vmcnt(4) (leaves A1(s+1),
+        // W0(s+2); covers P1(s+1)'s reads) and P1 vmcnt(4) (leaves W0(s+1), W1(s+1); covers A1(s), read in P2).
+        // P1
+        if (x_rd) {
+          R8K_READ_W(fw0, 0, 0, sb)
+          R8K_READ_W(fw1, 1, 0, sb)
+          __builtin_amdgcn_sched_barrier(0);
+          R8K_READ_A(0, 0, sb)
+        }
+        if (n1) {
+          if (x_dma) R8_ISSUE_W(1, k1, cb ^ 1u)
+          R8_WAIT_VM(4);
+        } else {
+          R8_WAIT_VM(0);
+        }
+        R8_PHASE_T(R8K_WAIT_AWW(fw0, fw1), R8K_MFMA(0, fw0, fw1), 0)
+        // P2
+        if (x_rd) {
+          R8K_READ_A(1, 0, sb)
+          R8K_READ_W(fw0n, 0, 1, sb)
+        }
+        if (n1 && x_dma) R8_ISSUE_A(0, k1, cb ^ 1u)
+        R8_PHASE_T(R8K_WAIT_AW(fw0n), R8K_MFMA(1, fw0, fw1), 1)
+        // P3
+        if (x_rd) {
+          R8K_READ_A(1, 1, sb)
+          R8K_READ_W(fw1n, 1, 1, sb)
+        }
+        if (n1 && x_dma) R8_ISSUE_A(1, k1, cb ^ 1u)
+        R8_PHASE_T(R8K_WAIT_AW(fw1n), R8K_MFMA(1, fw0n, fw1n), 2)
+        // P4: the DMA stream enters the next output tile here when kt == nk - 2
+        if (x_rd) R8K_READ_A(0, 1, sb)
+        if (in1 && !in2 && has_next) R8_TILE_SETUP(n_tm, n_tn)
+        if (n2) {
+          if (x_dma) R8_ISSUE_W(0, k2, cb)
+          R8_WAIT_VM(4);
+        } else {
+          R8_WAIT_VM(2);
+        }
+        R8_PHASE_T(R8K_WAIT_A(), R8K_MFMA(0, fw0n, fw1n), 3)
+      } else {
       // P1: A0 + W0 -> (0,0); stage W1(s+1)
-      R8_READ_W(bf0, 0, sb)
-      __builtin_amdgcn_sched_barrier(0);
-      R8_READ_A(0, sb)
-      if (n1) R8_ISSUE_W(1, k1, cb ^ 1u)
-      R8_PHASE(R8_WAIT_LGKM_AW(bf0), R8_MFMA_Q(0, 0, bf0))
+      if (x_rd) {
+        R8_READ_W(bf0, 0, sb)
+        __builtin_amdgcn_sched_barrier(0);
+        R8_READ_A(0, sb)
+      }
+      if (n1 && x_dma) R8_ISSUE_W(1, k1, cb ^ 1u)
+      R8_PHASE_T(R8_WAIT_LGKM_AW(bf0), if (x_mf) R8_MFMA_Q(0, 0, bf0), 0)
       // P2: W1 -> (0,1); stage A1(s+1)
-      R8_READ_W(bf1, 1, sb)
-      if (n1) R8_ISSUE_A(1, k1, cb ^ 1u)
-      R8_PHASE(R8_WAIT_LGKM_W(bf1), R8_MFMA_Q(0, 1, bf1))
+      if (x_rd) R8_READ_W(bf1, 1, sb)
+      if (n1 && x_dma) R8_ISSUE_A(1, k1, cb ^ 1u)
+      R8_PHASE_T(R8_WAIT_LGKM_W(bf1), if (x_mf) R8_MFMA_Q(0, 1, bf1), 1)
       // P3: A1 -> (1,1); stage A0(s+2).  The DMA stream enters the next output tile here when kt == nk - 2.
-      R8_READ_A(1, sb)
+      if (x_rd) R8_READ_A(1, sb)
       if (in1 && !in2 && has_next) R8_TILE_SETUP(n_tm, n_tn)
-      if (n2) R8_ISSUE_A(0, k2, cb)
-      R8_PHASE(R8_WAIT_LGKM_A(), R8_MFMA_Q(1, 1, bf1))
+      if (n2 && x_dma) R8_ISSUE_A(0, k2, cb)
+      R8_PHASE_T(R8_WAIT_LGKM_A(), if (x_mf) R8_MFMA_Q(1, 1, bf1), 2)
       // P4: no reads -> (1,0); stage W0(s+2); all of s+1 must have landed before this phase's first barrier
       if (n2) {
-        R8_ISSUE_W(0, k2, cb)
+        if (x_dma) R8_ISSUE_W(0, k2, cb)
         R8_WAIT_VM(4);
       } else {
         R8_WAIT_VM(0);
       }
-      R8_PHASE(, R8_MFMA_Q(1, 0, bf0))
+      R8_PHASE_T(, if (x_mf) R8_MFMA_Q(1, 0, bf0), 3)
+      }
+      if constexpr ((ABL & 1) != 0) {
+        // one 16-byte record per K tile in the (idle) epilogue staging slice of this wave
+        if (gk < 256u && lane == 0) {
+          uint4 rec = {(unsigned)tstamp[0], (unsigned)tstamp[1], (unsigned)tstamp[2], (unsigned)tstamp[3]};
+          *reinterpret_cast<uint4*>(smem + 2 * BUF + wave * 4096 + gk * 16) = rec;
+        }
+      }
     }
     li = li_next;
     c_tm = n_tm;
@@ -402,6 +510,21 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
     if (!has_next) break;
   }
   if (stagger && wr == 0) __builtin_amdgcn_s_barrier();  // group 0 meets group 1's extra barrier
+  if constexpr ((ABL & 1) != 0) {
+    __syncthreads();
+    if (blockIdx.x < 16 && (wave == 0 || wave == 4)) {
+      const unsigned* src = reinterpret_cast<const unsigned*>(smem + 2 * BUF + wave * 4096);
+      unsigned* dst = g_gemm_trace + ((blockIdx.x * 2 + (wave >> 2)) * 256) * 4;
+      for (int i = lane; i < 1024; i += 64) dst[i] = src[i];
+    }
+  }
+#undef R8_PHASE_T
+#undef R8K_MFMA
+#undef R8K_WAIT_AWW
+#undef R8K_WAIT_AW
+#undef R8K_WAIT_A
+#undef R8K_READ_W
+#undef R8K_READ_A
 #undef R8_PHASE
 #undef R8_PHASE_DM
 #undef R8_MFMA_G
@@ -418,8 +541,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
 #undef R8_TILE_SETUP
 }
 
-template <typename TOUT, bool CONV, int EPI, bool DMAMF = false>
-static int launch8p(const GemmArgs& a, hipStream_t stream, const char* epi_name) {
+template <typename TOUT, bool CONV, int EPI, bool DMAMF = false, int SCHED = 0, int ABL = 0>
+static int launch8p_s(const GemmArgs& a, hipStream_t stream, const char* epi_name) {
   constexpr int BM = 256, BN = 256;
   const long nblk = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const size_t lds = (size_t)2 * (BM + BN) * ROWB + 8 * 4096;  // 160 KiB: one persistent workgroup per CU
@@ -431,12 +554,32 @@ static int launch8p(const GemmArgs& a, hipStream_t stream, const char* epi_name)
   int dev = 0;
   ROMA_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<TOUT, CONV, EPI, DMAMF>),
+    ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<TOUT, CONV, EPI, DMAMF, SCHED, ABL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((gemm8p_kernel<TOUT, CONV, EPI, DMAMF>), dim3((unsigned)gx), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((gemm8p_kernel<TOUT, CONV, EPI, DMAMF, SCHED, ABL>), dim3((unsigned)gx), dim3(512), lds, stream, a);
   ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// schedule selection: roma_tuning("gemm8p_sched", v) (-1 = environment ROMA_GEMM8P_SCHED, default 1 = k-half phases; 0 =
+// quadrant phases); dbg bit 65536 flips it for one launch (A/B inside one process)
+int g_gemm8p_sched = -1;
+static int gemm8p_sched_of(const GemmArgs& a) {
+  static const int sched_env = getenv("ROMA_GEMM8P_SCHED") ? atoi(getenv("ROMA_GEMM8P_SCHED")) : 1;
+  const int base = g_gemm8p_sched >= 0 ? g_gemm8p_sched : sched_env;
+  return (base ? 1 : 0) ^ ((a.dbg & 65536) ? 1 : 0);
+}
+template <typename TOUT, bool CONV, int EPI>
+static int launch8p(const GemmArgs& a, hipStream_t stream, const char* epi_name) {
+  if (gemm8p_sched_of(a)) return launch8p_s<TOUT, CONV, EPI, false, 1>(a, stream, epi_name);
+  return launch8p_s<TOUT, CONV, EPI, false, 0>(a, stream, epi_name);
+}
+
+int gemm8p_trace_read(unsigned* host, long n) {
+  if (n > (long)(sizeof(unsigned) * 16 * 2 * 256 * 4)) n = (long)(sizeof(unsigned) * 16 * 2 * 256 * 4);
+  ROMA_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), (size_t)n));
   return 0;
 }
 
@@ -493,7 +636,18 @@ int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
     if (a.act == ACT_RELU) return launch8p<bf16_t, false, E8_RELU>(a, stream, "relu");
     // A/B switch: LDS-DMA issued between the MFMAs instead of in the load block.  Measured (tools/bench_gemm_overhead.py bit 512, profiles/r02_v11_gemm_overhead.log):
     // neutral at K = 1024, -4 % at K = 4096, -15 % on the 3x3 convolution (its per-piece select sits between the MFMAs)
-    if (a.dbg & 512) return launch8p<bf16_t, false, E8_NONE, true>(a, stream, "none");
+    if (a.dbg & 512) return launch8p_s<bf16_t, false, E8_NONE, true>(a, stream, "none");
+    if (a.dbg & 32768) {  // ablation / trace builds (tools/bench_gemm_ablation.py)
+      const int sched = gemm8p_sched_of(a);
+      const int abl = 1 | ((a.dbg & 4096) ? 2 : 0) | ((a.dbg & 8192) ? 4 : 0) | ((a.dbg & 16384) ? 8 : 0);
+#define R8_ABL_CASE(S, X) \
+  if (sched == S && abl == X) return launch8p_s<bf16_t, false, E8_NONE, false, S, X>(a, stream, "none");
+      R8_ABL_CASE(0, 1) R8_ABL_CASE(0, 3) R8_ABL_CASE(0, 5) R8_ABL_CASE(0, 9) R8_ABL_CASE(0, 7) R8_ABL_CASE(0, 11) R8_ABL_CASE(0, 13)
+      R8_ABL_CASE(1, 1) R8_ABL_CASE(1, 3) R8_ABL_CASE(1, 5) R8_ABL_CASE(1, 9) R8_ABL_CASE(1, 7) R8_ABL_CASE(1, 11) R8_ABL_CASE(1, 13)
+#undef R8_ABL_CASE
+      set_error("gemm8p: no such ablation build");
+      return -2;
+    }
     return launch8p<bf16_t, false, E8_NONE>(a, stream, "none");
   }
   if (a.out_dt == DT_F32) {

@@ -30,6 +30,14 @@ struct Lin {  // y = x W^T + b ; W in activation dtype [N][ldw]
 struct VitBlockW {
   float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr, *ls1 = nullptr, *ls2 = nullptr;
   Lin qkv, proj, fc1, fc2;
+  roma_vit_block_t pub() const {  // the plain-pointer form vit.h / roma_vit_forward take
+    roma_vit_block_t b{};
+    b.ln1_w = ln1w; b.ln1_b = ln1b; b.ln2_w = ln2w; b.ln2_b = ln2b; b.ls1 = ls1; b.ls2 = ls2;
+    b.qkv_w = qkv.w; b.proj_w = proj.w; b.fc1_w = fc1.w; b.fc2_w = fc2.w;
+    b.qkv_b = qkv.b; b.proj_b = proj.b; b.fc1_b = fc1.b; b.fc2_b = fc2.b;
+    b.qkv_ldw = qkv.ldw; b.proj_ldw = proj.ldw; b.fc1_ldw = fc1.ldw; b.fc2_ldw = fc2.ldw;
+    return b;
+  }
 };
 
 struct RefinerW {
@@ -63,6 +71,12 @@ class Model {
   static constexpr int MAX_STREAMS_DECL = 4;
   roma_config_t cfg{};
   int act_dt = 0;  // DT_F32 / DT_BF16
+  // ROMA_MIXED (binary16 build only): DINOv2 runs in bfloat16 in the sibling library (its weights are packed as bfloat16
+  // bits here, its patch tokens converted to binary16 behind it), everything else in this build's binary16.
+  bool mixed = false;
+  bool pack_as_bf16 = false;                                   // upload_act: write bfloat16 bits whatever the build
+  void* peer_lib = nullptr;                                    // dlopen handle of libroma_hip.so
+  int (*peer_vit_forward)(const roma_vit_args_t*, void*) = nullptr;
   bool finalized = false;
   bool debug = false;
   bool fuse_refiner_blocks = true;  // bf16 mode: fused dw5x5+1x1 kernel at the narrow scales (option "fuse_refiner_blocks")
@@ -129,6 +143,7 @@ class Model {
                     float* cert, hipStream_t st);
   int check_contract();
   int pack_weights();
+  int load_peer();
   int match_impl(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
                  float* cert, hipStream_t st, bool dry, Arena& arena, Arena& persist);
   int dbg_save(const char* name, const void* p, size_t bytes, hipStream_t st);

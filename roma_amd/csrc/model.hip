@@ -1,6 +1,7 @@
 // Model object: weight intake / packing and the match() kernel schedule (see model.h).
 #include "model.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,6 +15,7 @@
 #include "gemm.h"
 #include "local_corr.h"
 #include "refiner_block.h"
+#include "vit.h"
 
 namespace roma {
 
@@ -35,6 +37,41 @@ Model::~Model() {
   for (void* p : owned) (void)hipFree(p);
   for (auto& kv : dbg) (void)hipFree(kv.second.first);
   for (auto& kv : inject) (void)hipFree(kv.second.first);
+}
+
+extern void* g_peer_lib;  // api.hip: roma_tuning / roma_profile_* forward to the sibling library once it is loaded
+
+// ROMA_MIXED: the bfloat16 build of this library (libroma_hip.so, next to this shared object) runs DINOv2.  Loaded once per
+// process with RTLD_LOCAL: both libraries export the same C ABI, each keeps its own symbols.
+int Model::load_peer() {
+  static void* lib = nullptr;
+  static int (*fwd)(const roma_vit_args_t*, void*) = nullptr;
+  if (!lib) {
+    ROMA_REQUIRE(roma_h16_format() == ROMA_F16, "ROMA_MIXED is a mode of the binary16 build (libroma_hip_f16.so)");
+    Dl_info info;
+    ROMA_REQUIRE(dladdr(reinterpret_cast<void*>(&roma_vit_forward), &info) && info.dli_fname, "ROMA_MIXED: cannot locate this library");
+    std::string path(info.dli_fname);
+    const size_t slash = path.find_last_of('/');
+    path = (slash == std::string::npos ? std::string("") : path.substr(0, slash + 1)) + "libroma_hip.so";
+    void* l = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!l) {
+      set_error("ROMA_MIXED: cannot load the bfloat16 library " + path + ": " + (dlerror() ? dlerror() : "?"));
+      return ROMA_ERR_STATE;
+    }
+    auto fmt = reinterpret_cast<int (*)(void)>(dlsym(l, "roma_h16_format"));
+    auto f = reinterpret_cast<int (*)(const roma_vit_args_t*, void*)>(dlsym(l, "roma_vit_forward"));
+    if (!fmt || !f || fmt() != ROMA_BF16) {
+      dlclose(l);
+      set_error("ROMA_MIXED: " + path + " is not the bfloat16 build of this library version");
+      return ROMA_ERR_STATE;
+    }
+    lib = l;
+    fwd = f;
+    g_peer_lib = l;
+  }
+  peer_lib = lib;
+  peer_vit_forward = fwd;
+  return 0;
 }
 
 int Model::debug_inject(const char* name, const void* host, size_t bytes) {
@@ -190,7 +227,11 @@ int Model::upload_act(const std::vector<float>& v, void** out) {
     return 0;
   }
   std::vector<bf16_t> h(v.size());
-  for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_bf16(v[i]);
+  if (pack_as_bf16) {
+    for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_bfloat16_bits(v[i]);  // ROMA_MIXED: the DINOv2 weights of the bf16 library
+  } else {
+    for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_bf16(v[i]);
+  }
   void* p = nullptr;
   ROMA_CHECK_HIP(hipMalloc(&p, std::max<size_t>(h.size(), 8) * sizeof(bf16_t)));
   owned.push_back(p);
@@ -348,11 +389,13 @@ int Model::pack_weights() {
     if (int rc = make_lin(H(p + ".mlp.fc2.weight"), &H(p + ".mlp.fc2.bias"), 1024, 4096, &o.fc2)) return rc;
     return 0;
   };
+  pack_as_bf16 = mixed;  // ROMA_MIXED: DINOv2's GEMM operands are bfloat16 (it runs in the bf16 library)
   for (int i = 0; i < 24; ++i)
     if (int rc = pack_vit("dinov2.blocks." + std::to_string(i), true, true, dino[i])) return rc;
+  if (int rc = make_lin(H("dinov2.patch_embed.proj.weight"), &H("dinov2.patch_embed.proj.bias"), 1024, 588, &patch)) return rc;
+  pack_as_bf16 = false;
   for (int i = 0; i < 5; ++i)
     if (int rc = pack_vit("decoder.embedding_decoder.blocks." + std::to_string(i), false, false, tdec[i])) return rc;
-  if (int rc = make_lin(H("dinov2.patch_embed.proj.weight"), &H("dinov2.patch_embed.proj.bias"), 1024, 588, &patch)) return rc;
   {
     std::vector<float> cls(H("dinov2.cls_token"));
     if (int rc = upload_f32(cls, &cls_tok)) return rc;
@@ -425,7 +468,10 @@ int Model::finalize() {
   ROMA_REQUIRE(!finalized, "roma_finalize: already finalized");
   ROMA_CHECK_HIP(hipSetDevice(cfg.device));
   if (int rc = check_contract()) return rc;
-  act_dt = cfg.precision == ROMA_F32 ? DT_F32 : DT_BF16;  // roma_create admitted only this build's 16-bit code
+  act_dt = cfg.precision == ROMA_F32 ? DT_F32 : DT_BF16;  // roma_create admitted only this build's 16-bit code (+ ROMA_MIXED)
+  mixed = cfg.precision == ROMA_MIXED;
+  if (mixed)
+    if (int rc = load_peer()) return rc;
   if (int rc = pack_weights()) return rc;
   host.clear();
   // plan the workspace with a dry run at the largest configuration
@@ -741,51 +787,13 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
     cert_fin = (float*)AL((size_t)ndp * Hfin * Wfin, 4);
   }
 
-  // shared ViT block (DINOv2 and the coordinate decoder): residual stream x updated in place; x_dt = DT_F32, or
-  // DT_BF16 for DINOv2 in bf16 mode (the proj / fc2 GEMMs then add the bf16 residual in their row-writer)
+  // shared ViT block (vit.hip): DINOv2 goes through vit_forward / roma_vit_forward below, the coordinate decoder calls the
+  // block directly (f32 residual stream)
   auto vit_block = [&](const VitBlockW& w, void* x, int x_dt, long rows, int Bn, int N, int npad, int heads, int hd, float eps,
                        void* ln, void* ao, void* hid) -> int {
-    auto residual_gemm = [&](GemmArgs& g) -> int {
-      g.C = x; g.ldc = 1024; g.ldr = 1024;
-      if (x_dt == DT_BF16) { g.out_dt = DT_BF16; g.res_bf16 = x; }
-      else { g.out_dt = DT_F32; g.res = (const float*)x; }
-      return gemm_launch(g, st);
-    };
-    RUN(layernorm_launch_dt(x, x_dt, w.ln1w, w.ln1b, ln, rows, 1024, eps, act_dt, st));
-    {
-      GemmArgs g;
-      g.A = ln; g.lda = 1024; g.W = w.qkv.w; g.ldw = w.qkv.ldw; g.M = (int)rows; g.N = 3072; g.K = 1024;
-      g.in_dt = act_dt; g.out_dt = act_dt; g.bias = w.qkv.b; g.mode = EPI_QKV;
-      g.q = qbuf; g.k = kbuf; g.vt = vtbuf; g.heads = heads; g.hd = hd; g.ntok = N; g.npad = npad;
-      // bf16 mode: fold log2(e) into the query scale so the softmax is a bare v_exp_f32 (2^x) per element
-      g.qscale = (act_dt == DT_BF16 ? 1.4426950408889634f : 1.0f) / sqrtf((float)hd);
-      RUN(gemm_launch(g, st));
-    }
-    {
-      AttnArgs a;
-      a.q = qbuf; a.k = kbuf; a.vt = vtbuf; a.out = ao; a.B = Bn; a.heads = heads; a.N = N; a.npad = npad; a.hd = hd;
-      a.ldo = 1024; a.in_dt = act_dt; a.out_dt = act_dt; a.exp2_domain = act_dt == DT_BF16 ? 1 : 0;
-      RUN(attention_launch(a, st));
-    }
-    {
-      GemmArgs g;
-      g.A = ao; g.lda = 1024; g.W = w.proj.w; g.ldw = w.proj.ldw; g.M = (int)rows; g.N = 1024; g.K = 1024;
-      g.in_dt = act_dt; g.bias = w.proj.b; g.scale = w.ls1;
-      RUN(residual_gemm(g));
-    }
-    RUN(layernorm_launch_dt(x, x_dt, w.ln2w, w.ln2b, ln, rows, 1024, eps, act_dt, st));
-    {
-      GemmArgs g;
-      g.A = ln; g.lda = 1024; g.W = w.fc1.w; g.ldw = w.fc1.ldw; g.C = hid; g.ldc = 4096; g.M = (int)rows; g.N = 4096; g.K = 1024;
-      g.in_dt = act_dt; g.out_dt = act_dt; g.bias = w.fc1.b; g.act = ACT_GELU;
-      RUN(gemm_launch(g, st));
-    }
-    {
-      GemmArgs g;
-      g.A = hid; g.lda = 4096; g.W = w.fc2.w; g.ldw = w.fc2.ldw; g.M = (int)rows; g.N = 1024; g.K = 4096;
-      g.in_dt = act_dt; g.bias = w.fc2.b; g.scale = w.ls2;
-      RUN(residual_gemm(g));
-    }
+    VitScratch sc;
+    sc.ln = ln; sc.ao = ao; sc.hid = hid; sc.q = qbuf; sc.k = kbuf; sc.vt = vtbuf;
+    RUN(vit_block_run(w.pub(), x, x_dt, rows, Bn, N, npad, heads, hd, eps, act_dt, sc, st));
     return 0;
   };
 
@@ -865,28 +873,38 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       void* col = AL((size_t)nimg * T * patch.ldw, esz);
       float* pt = (float*)AL((size_t)nimg * T * 1024, 4);
       float* x = (float*)AL((size_t)rows_d * 1024, 4);
-      RUN(im2col_patch14_launch(imA, col, B, H, W, patch.ldw, act_dt, st));
-      RUN(im2col_patch14_launch(imB, off(col, (long)B * T * patch.ldw), B, H, W, patch.ldw, act_dt, st));
-      {
-        GemmArgs g;
-        g.A = col; g.lda = patch.ldw; g.W = patch.w; g.ldw = patch.ldw; g.C = pt; g.ldc = 1024;
-        g.M = nimg * T; g.N = 1024; g.K = patch.ldw; g.k_alg = 588; g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = patch.b;
-        RUN(gemm_launch(g, st));
-      }
-      RUN(assemble_tokens_launch(pt, cls_tok, pos_emb, x, nimg, T, 1024, st));
       static const bool res_f32_env = getenv("ROMA_VIT_RES_F32") && atoi(getenv("ROMA_VIT_RES_F32")) != 0;
-      void* xs = x;
-      int x_dt = DT_F32;
-      if (act_dt == DT_BF16 && (dry || (vit_bf16_residual && !res_f32_env))) {  // bf16 residual stream (model.h);
-        xs = AL((size_t)rows_d * 1024, 2);                                         // always planned, the option may flip later
-        x_dt = DT_BF16;
-        RUN(copy2d_launch(x, 1024, DT_F32, xs, 1024, DT_BF16, rows_d, 1024, st));
+      void* xs = nullptr;
+      if (act_dt == DT_BF16) xs = AL((size_t)rows_d * 1024, 2);  // 16-bit residual stream: always planned, the option may flip later
+      void* feat_vit = feat[4];
+      if (mixed) feat_vit = AL((size_t)nimg * T * 1024, 2);       // bfloat16 patch tokens of the sibling library
+      if (!dry) {
+        roma_vit_block_t blk[24];
+        for (int i = 0; i < 24; ++i) blk[i] = dino[i].pub();
+        roma_vit_args_t va{};
+        va.B = B; va.H = H; va.W = W;
+        va.act = act_dt == DT_F32 ? ROMA_F32 : (mixed ? ROMA_BF16 : roma_h16_format());
+        va.bf16_residual = act_dt == DT_BF16 && vit_bf16_residual && !res_f32_env;
+        va.im_a = imA; va.im_b = imB;
+        va.patch_w = patch.w; va.patch_b = patch.b; va.patch_ldw = patch.ldw;
+        va.cls_tok = cls_tok; va.pos_emb = pos_emb;
+        va.blocks = blk; va.nblocks = 24;
+        va.norm_w = dino_nw; va.norm_b = dino_nb;
+        va.col = col; va.pt = pt; va.x = x; va.xs = xs; va.ln = ln; va.ao = ao; va.hid = hid;
+        va.q = qbuf; va.k = kbuf; va.vt = vtbuf;
+        va.feat_out = feat_vit;
+        if (mixed) {
+          // DINOv2 in bfloat16 (the reference's amp_dtype reaches only it, roma_models.py:183-188) in the bf16 build of this
+          // library, on this sub-batch's stream; autocast then casts its features to binary16 for the proj head
+          if (int rc = peer_vit_forward(&va, st)) {
+            set_error("ROMA_MIXED: roma_vit_forward of the bfloat16 library failed");
+            return rc;
+          }
+          RUN(convert_from_bf16_launch(feat_vit, feat[4], (long)nimg * T * 1024, st));
+        } else {
+          RUN(vit_forward(va, st));
+        }
       }
-      for (int i = 0; i < 24; ++i)
-        if (int rc = vit_block(dino[i], xs, x_dt, rows_d, nimg, Nd, Npd, 16, 64, 1e-6f, ln, ao, hid)) return rc;
-      RUN(layernorm_launch_dt(xs, x_dt, dino_nw, dino_nb, ln, rows_d, 1024, 1e-6f, act_dt, st));
-      for (int i = 0; i < nimg; ++i)  // drop the cls token: x_norm_patchtokens
-        RUN(copy2d_launch(off(ln, ((long)i * Nd + 1) * 1024), 1024, act_dt, off(feat[4], (long)i * T * 1024), 1024, act_dt, T, 1024, st));
       arena.release(dmark);
       if (int rc = CK("feat16", feat[4], (size_t)nimg * T * 1024 * esz)) return rc;
       if (debug && !dry)

@@ -69,11 +69,11 @@ def _pil_to_normalised(im, hw):
 class RegressionMatcher:
     """Drop-in for romatch.models.matcher.RegressionMatcher (inference surface)."""
 
-    HANDLE_CACHE = 2  # library handles (resolution configurations) kept alive per matcher
+    HANDLE_CACHE = 2  # default number of library handles (resolution configurations) kept alive per matcher
 
     def __init__(self, weights, dinov2_weights, h=560, w=560, sample_mode="threshold_balanced", upsample_preds=False,
                  symmetric=False, sample_thresh=0.05, name=None, attenuate_cert=None, upsample_res=None,
-                 device=None, amp_dtype=torch.float16, max_batch=8):
+                 device=None, amp_dtype=torch.float16, max_batch=8, decoder_dtype=None, handle_cache=None):
         dev = torch.device(device if device is not None else "cuda")
         if dev.type != "cuda":
             raise _lib.RomaHipError(f"roma_amd runs only on a HIP device (got device={device!r}); there is no CPU fallback")
@@ -95,7 +95,20 @@ class RegressionMatcher:
         # storage, f32 accumulate; torch.bfloat16 (the reference's timing script) and torch.float32 on libroma_hip.so.
         # gfx950's MFMA has one 16-bit rate for both formats.
         self.amp_dtype = amp_dtype
-        self._lib = _lib.load(_lib.fmt_of(amp_dtype))
+        # decoder_dtype: the 16-bit format of everything that is NOT DINOv2.  In the reference `amp_dtype` reaches only the
+        # DINOv2 backbone (model_zoo/roma_models.py:183-188); the VGG pyramid, the decoder and the refiners autocast to
+        # float16 whatever it is (encoders.py:7, matcher.py:46,341) - so the reference's timing script (amp_dtype=bfloat16)
+        # runs bf16 DINOv2 + fp16 elsewhere.  decoder_dtype=torch.float16 with amp_dtype=torch.bfloat16 selects exactly
+        # that (ROMA_MIXED: libroma_hip_f16.so runs DINOv2 through libroma_hip.so); None keeps ONE format everywhere.
+        if decoder_dtype is not None and decoder_dtype != amp_dtype:
+            if not (amp_dtype == torch.bfloat16 and decoder_dtype == torch.float16):
+                raise ValueError("decoder_dtype: only amp_dtype=torch.bfloat16 with decoder_dtype=torch.float16 is a mixed mode")
+        self.decoder_dtype = decoder_dtype
+        self.mixed = decoder_dtype is not None and decoder_dtype != amp_dtype
+        self._lib = _lib.load("f16" if self.mixed else _lib.fmt_of(amp_dtype))
+        # resolution configurations kept alive: each holds its packed weights (~0.9 GB in 16-bit modes) and a workspace
+        # planned for max_batch (~12 GB at batch 8, 560 -> 864); 1 releases the old handle as soon as the new one is built
+        self.handle_cache = int(handle_cache) if handle_cache is not None else self.HANDLE_CACHE
         self.max_batch = int(max_batch)
         self.training = False
         self.debug = False
@@ -122,8 +135,8 @@ class RegressionMatcher:
         tensors when it differs from the configured one (the attributes are never mutated, as in the reference)."""
         h, w = hw if hw is not None else (self.h_resized, self.w_resized)
         up = tuple(int(v) for v in self.upsample_res) if self.upsample_preds else (0, 0)
-        return (int(h), int(w), up,
-                _lib.ROMA_F32 if self.amp_dtype == torch.float32 else _lib.H16_CODE[self._lib.h16], self.max_batch, self.device.index)
+        prec = _lib.ROMA_F32 if self.amp_dtype == torch.float32 else (_lib.ROMA_MIXED if self.mixed else _lib.H16_CODE[self._lib.h16])
+        return (int(h), int(w), up, prec, self.max_batch, self.device.index)
 
     def _ensure_handle(self, hw=None):
         key = self._config_key(hw)
@@ -135,10 +148,6 @@ class RegressionMatcher:
             self._cache.move_to_end(key)
             self._handle, self._built = self._cache[key], key
             return
-        while len(self._cache) >= self.HANDLE_CACHE:  # evict the least recently used handle
-            _, old = self._cache.popitem(last=False)
-            self._lib.roma_destroy(old)
-        self._handle = self._built = None
         lib = self._lib
         uh, uw = key[2]
         cfg = _lib.RomaConfig(key[0], key[1], uh, uw, int(bool(self.symmetric)), int(bool(self.upsample_preds)),
@@ -159,6 +168,10 @@ class RegressionMatcher:
         except Exception:
             lib.roma_destroy(h)
             raise
+        # evict only now that the new handle exists (a failed build leaves the matcher on its old, working handle)
+        while len(self._cache) >= max(self.handle_cache, 1):
+            _, old = self._cache.popitem(last=False)
+            self._lib.roma_destroy(old)
         self._handle = h
         self._built = key
         self._cache[key] = h
@@ -461,7 +474,7 @@ def roma_model(resolution, upsample_preds, device=None, weights=None, dinov2_wei
     """romatch/models/model_zoo/roma_models.py:32-205.  `use_custom_corr` is accepted for API
     compatibility; the fused HIP local-correlation kernel is always used.
 
-    Accepted: `amp_dtype` float32 (exact-f32 MFMA parity mode), bfloat16, float16 (runs as bfloat16, with a warning);
+    Accepted: `amp_dtype` float32 (exact-f32 MFMA parity mode), bfloat16 (libroma_hip.so), float16 (libroma_hip_f16.so);
     `resolution` a multiple of 56 per side (14 for the DINOv2 patch grid as in the reference, and 8 because the VGG
     pyramid is kept un-floored down to stride 8); `upsample_res` a multiple of 8."""
     resolution = _to_hw(resolution)
@@ -478,17 +491,20 @@ def roma_model(resolution, upsample_preds, device=None, weights=None, dinov2_wei
 
 def roma_outdoor(device, weights=None, dinov2_weights=None, coarse_res: Union[int, tuple] = 560,
                  upsample_res: Union[int, tuple] = 864, amp_dtype: torch.dtype = torch.float16, symmetric=True,
-                 use_custom_corr=True, upsample_preds=True, max_batch=8):
-    """romatch/models/model_zoo/__init__.py:31-61."""
+                 use_custom_corr=True, upsample_preds=True, max_batch=8, decoder_dtype=None):
+    """romatch/models/model_zoo/__init__.py:31-61.  `decoder_dtype=torch.float16` with `amp_dtype=torch.bfloat16` = the
+    precision mix of the reference's timing script (RegressionMatcher.__init__)."""
     return roma_model(resolution=coarse_res, upsample_preds=upsample_preds, weights=weights,
                       dinov2_weights=dinov2_weights, device=device, amp_dtype=amp_dtype, symmetric=symmetric,
-                      use_custom_corr=use_custom_corr, upsample_res=upsample_res, max_batch=max_batch)
+                      use_custom_corr=use_custom_corr, upsample_res=upsample_res, max_batch=max_batch,
+                      decoder_dtype=decoder_dtype)
 
 
 def roma_indoor(device, weights=None, dinov2_weights=None, coarse_res: Union[int, tuple] = 560,
                 upsample_res: Union[int, tuple] = 864, amp_dtype: torch.dtype = torch.float16, symmetric=True,
-                use_custom_corr=True, upsample_preds=True, max_batch=8):
+                use_custom_corr=True, upsample_preds=True, max_batch=8, decoder_dtype=None):
     """romatch/models/model_zoo/__init__.py:64-93 (same graph as roma_outdoor, different weights)."""
     return roma_model(resolution=coarse_res, upsample_preds=upsample_preds, weights=weights,
                       dinov2_weights=dinov2_weights, device=device, amp_dtype=amp_dtype, symmetric=symmetric,
-                      use_custom_corr=use_custom_corr, upsample_res=upsample_res, max_batch=max_batch)
+                      use_custom_corr=use_custom_corr, upsample_res=upsample_res, max_batch=max_batch,
+                      decoder_dtype=decoder_dtype)

@@ -165,6 +165,90 @@ def test_accuracy_harness_metrics_on_synthetic_planes():
     assert set(AH.check_acceptance({k: v[0] for k, v in AH.ACCEPTANCE.items()}).values()) == {True}
 
 
+def test_pose_five_point_solver_and_error_metrics_exact():
+    """tools/pose_geometry.py (the restated cv2.findEssentialMat / recoverPose behind utils.py:30-51): the five-point solver
+    returns the true essential matrix among its solutions on noise-free minimal samples, the RANSAC + cheirality pipeline
+    recovers (R, t) with 30 % outliers, and compute_pose_error / pose_auc (utils.py:126-147) give their closed-form values."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pose_geometry as PG
+    rng = np.random.default_rng(3)
+
+    def rot(ax, a):
+        ax = ax / np.linalg.norm(ax)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+    for _ in range(4):
+        R, t = rot(rng.normal(size=3), 0.1 + 0.4 * rng.random()), rng.normal(size=3)
+        t /= np.linalg.norm(t)
+        X = np.c_[rng.uniform(-1, 1, (5, 2)), rng.uniform(2, 6, 5)]
+        x0, X1 = X[:, :2] / X[:, 2:], X @ R.T + t
+        x1 = X1[:, :2] / X1[:, 2:]
+        Es, _ = PG.five_point(x0[None], x1[None])
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Et = tx @ R
+        Et /= np.linalg.norm(Et)
+        assert 1 <= len(Es) <= 10 and min(min(np.abs(E - Et).max(), np.abs(E + Et).max()) for E in Es) < 1e-9
+        assert np.abs(np.einsum("ni,mij,nj->mn", np.c_[x1, np.ones(5)], Es, np.c_[x0, np.ones(5)])).max() < 1e-10
+        # full pipeline: 1 500 points, 30 % gross outliers, 0.3 px noise at f = 800
+        X = np.c_[rng.uniform(-1, 1, (1500, 2)), rng.uniform(2, 6, 1500)]
+        K = np.array([[800.0, 0, 320], [0, 800, 240], [0, 0, 1]])
+        k0 = (X[:, :2] / X[:, 2:]) * 800 + K[:2, 2]
+        X1 = X @ R.T + t
+        k1 = (X1[:, :2] / X1[:, 2:]) * 800 + K[:2, 2] + 0.3 * rng.normal(size=(1500, 2))
+        k1[:450] = rng.uniform(0, 640, (450, 2))
+        Re, te, mask = PG.estimate_pose(k0, k1, K, K, 0.5 / 800, conf=0.99999, rng=rng)
+        e_t, e_R = PG.compute_pose_error(np.c_[R, t[:, None]], Re, te)
+        assert e_t < 1.5 and e_R < 1.0 and 900 < mask.sum() < 1100, (e_t, e_R, mask.sum())
+    assert PG.estimate_pose(k0[:4], k1[:4], K, K, 1e-3) is None
+    # metrics: a 90-degree rotation about z; translation sign ambiguity folds 170 degrees to 10
+    Rz = rot(np.array([0.0, 0, 1]), np.pi / 2)
+    e_t, e_R = PG.compute_pose_error(np.c_[np.eye(3), np.array([1.0, 0, 0])[:, None]], Rz,
+                                     np.array([-np.cos(np.deg2rad(10)), np.sin(np.deg2rad(10)), 0.0]))
+    assert abs(e_R - 90) < 1e-9 and abs(e_t - 10) < 1e-9
+    # pose_auc: all errors 0 -> 1; errors uniform on [0, 10] -> AUC@10 = 1/2 (recall rises linearly), all above -> 0
+    assert PG.pose_auc([0.0] * 8, [5, 10, 20]) == [1.0, 1.0, 1.0]
+    assert PG.pose_auc([50.0] * 8, [5, 10, 20]) == [0.0, 0.0, 0.0]
+    assert abs(PG.pose_auc(list(np.linspace(0, 10, 2001)), [10])[0] - 0.5) < 1e-3
+
+
+def test_pose_benchmark_loop_on_synthetic_two_view_scenes():
+    """tools/accuracy_harness.pose_benchmark = the loop of megadepth_pose_estimation_benchmark.py:25-116 (match -> 5 x sample
+    -> to_pixel_coordinates at the 1 200-pixel scale -> estimate_pose -> pose_auc) on synthetic two-view scenes with exact
+    poses: a perfect matcher scores AUC ~ 1, and the AUC falls monotonically as pixel noise is injected into the matches.
+    The stand-in model carries the oracle's `sample` (matcher.py:598-629) and the reference's coordinate convention."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import accuracy_harness as AH
+    from oracle import roma_oracle as O
+
+    class Perfect:
+        def __init__(self, pair):
+            self.pair = pair
+
+        def match(self, a, b):
+            return self.pair["gt_matches"], self.pair["gt_certainty"]
+
+        def sample(self, m, c, num):
+            return O.sample(m, c, num=num, generator=torch.Generator().manual_seed(5))
+
+        @staticmethod
+        def to_pixel_coordinates(coords, H_A, W_A, H_B, W_B):
+            kA, kB = coords[..., :2], coords[..., 2:]
+            return (torch.stack((W_A / 2 * (kA[..., 0] + 1), H_A / 2 * (kA[..., 1] + 1)), dim=-1),
+                    torch.stack((W_B / 2 * (kB[..., 0] + 1), H_B / 2 * (kB[..., 1] + 1)), dim=-1))
+
+    aucs = []
+    # noise in pixels of the 160 x 120 image; the benchmark works at the 1 200-pixel scale (x 7.5) with a 0.5-pixel threshold
+    for noise in (0.0, 0.02, 1.0):
+        tot = []
+        for seed in (0, 1):
+            pair = AH.synthetic_relief_pair(120, 160, seed=seed, noise_px=noise, outlier_frac=0.1 if noise else 0.0)
+            r = AH.pose_benchmark(Perfect(pair), [pair], seed=seed, num=1500, repeats=2)
+            tot.append(r["auc_5"])
+        aucs.append(float(np.mean(tot)))
+    assert aucs[0] > 0.99 and aucs[0] > aucs[1] + 0.01 and aucs[1] > aucs[2] + 0.3 and aucs[1] > 0.8, aucs
+    assert set(AH.check_acceptance_pose({k: v[0] for k, v in AH.ACCEPTANCE_POSE.items()}).values()) == {True}
+
+
 def test_tiny_oracle_vs_reference_golden():
     """oracle.tiny_oracle (TinyRoMa inference, romatch/models/tiny.py) against the reference's own TinyRoMa run with the
     seeded stand-in backbone (tests/golden/tiny_reference.npz): both correspondence levels from the stored features
@@ -332,7 +416,11 @@ def test_bench_self_spawn_n2_dry_run():
     assert abs(r["value"] - 4 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-6 * r["value"]
 
 
-def test_hot_gemm_kernels_do_not_spill(built_lib):
+BUILD_DIRS = ("build", "build_f16")  # libroma_hip.so (bf16 storage) and libroma_hip_f16.so (-DROMA_H16_F16): separate codegen
+
+
+@pytest.mark.parametrize("bdir", BUILD_DIRS)
+def test_hot_gemm_kernels_do_not_spill(built_lib, bdir):
     """The staged epilogues keep per-column vectors and residual pieces next to 96-128 accumulator registers; one careless
     change tips a kernel into scratch (round 2: 169 spilled registers on the 256 x 192 bf16 tile, 247 -> 335 us, every
     test still green).  The code-object metadata of the built objects is held to: no spill at all in the 256 x 192 kernel
@@ -340,21 +428,24 @@ def test_hot_gemm_kernels_do_not_spill(built_lib):
     below rejects scratch traffic between the MFMAs)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources
-    objs = {f: os.path.join(ROOT, "roma_amd", "csrc", "build", f) for f in ("gemm8p.o", "gemm6p.o", "conv64.o")}
+    objs = {f: os.path.join(ROOT, "roma_amd", "csrc", bdir, f) for f in ("gemm8p.o", "gemm6p.o", "conv64.o")}
     if not all(os.path.exists(o) for o in objs.values()):
         pytest.skip("object files not present (library shipped pre-built)")
     k6 = kernel_resources.kernels(objs["gemm6p.o"])
     assert len(k6) >= 4 and all(k["spill"] == 0 and k["scratch"] == 0 for k in k6), k6
     k64 = kernel_resources.kernels(objs["conv64.o"])  # 144 weight registers + 64 for accumulators and fragments: 242-256 of 256
     assert len(k64) == 4 and all(k["spill"] == 0 and k["scratch"] == 0 for k in k64), k64
-    k8 = [k for k in kernel_resources.kernels(objs["gemm8p.o"]) if k["name"].startswith("gemm8p_kernel<bf16")]
-    assert len(k8) >= 6
+    # production instantiations only: <..., SCHED, ABL = 0> (the ABL != 0 ablation builds of tools/bench_gemm_ablation.py
+    # run without their epilogue and may spill there)
+    k8 = [k for k in kernel_resources.kernels(objs["gemm8p.o"]) if k["name"].startswith("gemm8p_kernel<bf16") and k["name"].endswith(", 0>")]
+    assert len(k8) >= 12
     for k in k8:
         limit = 8 if ", 3, " in k["name"] else 0  # E8_RESBF16
         assert k["spill"] <= limit, k
 
 
-def test_dma_ring_kernels_keep_their_queue(built_lib):
+@pytest.mark.parametrize("bdir", BUILD_DIRS)
+def test_dma_ring_kernels_keep_their_queue(built_lib, bdir):
     """The wave-private LDS-DMA ring kernels (dwconv_ring.hip, refiner_block24w.hip) and the attention v2 kernels live off
     register budgets and counted waits: a spilled register is a scratch (VMEM) access that drains the counted DMA queue, and
     an `s_waitcnt vmcnt(0)` that hipcc puts in front of an LDS access it cannot tell apart from the DMA target does the same
@@ -364,7 +455,7 @@ def test_dma_ring_kernels_keep_their_queue(built_lib):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources
     from audit_asm_reads import extract_code_object
-    build = os.path.join(ROOT, "roma_amd", "csrc", "build")
+    build = os.path.join(ROOT, "roma_amd", "csrc", bdir)
     objs = {f: os.path.join(build, f) for f in ("dwconv_ring.o", "refiner_block24w.o", "attention.o")}
     if not all(os.path.exists(o) for o in objs.values()):
         pytest.skip("object files not present (library shipped pre-built)")
@@ -391,12 +482,13 @@ def test_dma_ring_kernels_keep_their_queue(built_lib):
     assert all(k["vgpr"] <= (168 if "<64" in k["name"] else 256) for k in att), att  # 3 / 2 workgroups per CU
 
 
-def test_isa_audit_no_touch_of_registers_with_asm_lds_reads_in_flight(built_lib):
+@pytest.mark.parametrize("bdir", BUILD_DIRS)
+def test_isa_audit_no_touch_of_registers_with_asm_lds_reads_in_flight(built_lib, bdir):
     """Every hand-scheduled GEMM K loop reads its MFMA fragments with inline-asm ds_read_b128 whose completion hipcc does
     not track; the construct is only correct if nothing touches those registers before our s_waitcnt (the round-1 f32
     "carried k-group" miscompile: compiler-made v_mov copies of in-flight registers, profiles/r02_f32_carry_isa_excerpt.txt).
     tools/audit_asm_reads.py checks that in the ISA of the objects the library is linked from - on every build."""
-    objs = [os.path.join(ROOT, "roma_amd", "csrc", "build", f) for f in ("gemm.o", "gemm8p.o", "gemm6p.o", "conv64.o")]
+    objs = [os.path.join(ROOT, "roma_amd", "csrc", bdir, f) for f in ("gemm.o", "gemm8p.o", "gemm6p.o", "conv64.o")]
     if not all(os.path.exists(o) for o in objs):
         pytest.skip("object files not present (library shipped pre-built)")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_reads.py")] + objs, capture_output=True, text=True,

@@ -194,10 +194,12 @@ def test_conv3x3_implicit_gemm(lib, dt, B, H, W, Cin, Cout):
     (16384, 576, 512, 0, True),      # f32 output
     (100000, 384, 320, 1, False),    # many tiles per persistent workgroup, K = 5 tiles (odd: both LDS buffers start a tile)
 ])
-def test_gemm8p_matches_classic_and_reference(lib, M, N, K, act, out_f32):
+@pytest.mark.parametrize("sched", [1, 0])
+def test_gemm8p_matches_classic_and_reference(lib, M, N, K, act, out_f32, sched):
     """Both main loops accumulate in the same k order, so the 8-phase kernel must reproduce the classic kernel BIT FOR
     BIT (any race / mis-synchronised LDS-DMA shows up as a difference); the result is also checked against f64, and the
-    8-phase launch is repeated (timing-dependent hazards)."""
+    8-phase launch is repeated (timing-dependent hazards).  sched: the K-loop schedule of gemm8p (1 = k-half phases, the
+    default; 0 = quadrant phases) - gemm6p shapes ignore it."""
     A, W, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, std=K ** -0.5).bfloat16(), rnd(N, seed=3)
     Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
     dto = F32 if out_f32 else BF16
@@ -205,18 +207,21 @@ def test_gemm8p_matches_classic_and_reference(lib, M, N, K, act, out_f32):
         lib.roma_tuning(b"gemm8p", 0)
         base = gemm(lib, Ad, Wd, bias=bd, act=act, dt_in=BF16, dt_out=dto)
         lib.roma_tuning(b"gemm8p", 1)
+        lib.roma_tuning(b"gemm8p_sched", sched)
         for _ in range(3):
             out = gemm(lib, Ad, Wd, bias=bd, act=act, dt_in=BF16, dt_out=dto)
             assert torch.equal(out, base), float((out.float() - base.float()).abs().max())
     finally:
         lib.roma_tuning(b"gemm8p", -1)
+        lib.roma_tuning(b"gemm8p_sched", -1)
     ref = A[:2048].double() @ W.double().T + b.double()
     ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
     assert torch.allclose(out[:2048].cpu().double(), ref, atol=2e-3 if out_f32 else 0.03, rtol=1e-4 if out_f32 else 1e-2)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 70, 70, 256, 512), (3, 56, 60, 128, 256), (2, 72, 70, 64, 256), (1, 108, 108, 512, 512)])
-def test_conv3x3_gemm8p_matches_classic_and_reference(lib, B, H, W, Cin, Cout):
+@pytest.mark.parametrize("sched", [1, 0])
+def test_conv3x3_gemm8p_matches_classic_and_reference(lib, B, H, W, Cin, Cout, sched):
     """3x3 implicit GEMM on the 8-phase kernel (per-tap validity masks, zero page): bitwise vs the classic kernel and
     against torch conv2d (image borders, ragged last m-tile)."""
     x, w, b = rnd(B, Cin, H, W, seed=1).bfloat16(), rnd(Cout, Cin, 3, 3, seed=2, std=(9 * Cin) ** -0.5).bfloat16(), rnd(Cout, seed=3)
@@ -226,6 +231,7 @@ def test_conv3x3_gemm8p_matches_classic_and_reference(lib, B, H, W, Cin, Cout):
     bd = b.cuda()
     outs = {}
     try:
+        lib.roma_tuning(b"gemm8p_sched", sched)
         for mode in (0, 1, 1):
             lib.roma_tuning(b"gemm8p", mode)
             out = torch.zeros((B, H, W, Cout), device="cuda", dtype=torch.bfloat16)
@@ -236,6 +242,7 @@ def test_conv3x3_gemm8p_matches_classic_and_reference(lib, B, H, W, Cin, Cout):
             outs[mode] = out
     finally:
         lib.roma_tuning(b"gemm8p", -1)
+        lib.roma_tuning(b"gemm8p_sched", -1)
     assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
     assert torch.allclose(outs[1].cpu().double(), ref, atol=3e-2, rtol=3e-2)
 

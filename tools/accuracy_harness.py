@@ -1,11 +1,14 @@
-"""Accuracy harness for the dense matchers: the reference's MegaDepth dense benchmark wired to
-roma_amd (romatch/benchmarks/megadepth_dense_benchmark.py:9-116, acceptance numbers tests/test_mega_dense.py:17-21).
+"""Accuracy harness for the dense matchers: the reference's two MegaDepth benchmarks wired to roma_amd -
+dense PCK (romatch/benchmarks/megadepth_dense_benchmark.py:9-116, acceptance numbers tests/test_mega_dense.py:17-21) and
+MegaDepth-1500 pose AUC (romatch/benchmarks/megadepth_pose_estimation_benchmark.py:25-116, acceptance numbers
+tests/test_mega1500.py:17-21; `estimate_pose` / `pose_auc` restated in tools/pose_geometry.py because OpenCV is absent).
 
 There is no MegaDepth data and there are no trained weights on this machine, so what runs offline is the whole harness on
 SYNTHETIC planar scenes with exact ground truth (a textured plane seen from two cameras: depth maps, intrinsics and the
 relative pose are analytic), with the same metric code path the real data takes:
 
     python tools/accuracy_harness.py --synthetic 4                 # GPU box: plumbing check with seeded random weights
+    python tools/accuracy_harness.py --synthetic-pose 2            # GPU box: match -> 5 x sample -> estimate_pose -> AUC
     python tools/accuracy_harness.py --megadepth data/megadepth --weights roma_outdoor.pth --dinov2 dinov2_vitl14_pretrain.pth
 
 With random weights the numbers are meaningless (the matcher has not learnt anything); with the released weights the
@@ -25,6 +28,11 @@ sys.path.insert(0, ROOT)
 # tests/test_mega_dense.py:17-21 (roma_outdoor, coarse_res 560, symmetric False, upsample_preds False, h = w = 560)
 ACCEPTANCE = {"epe": (1.581197752074192, 1e-1), "mega_pck_1": (0.8516846923828125, 2e-3), "mega_pck_3": (0.9566336059570313, 2e-3),
               "mega_pck_5": (0.9714825439453125, 2e-3)}
+
+
+# tests/test_mega1500.py:17-21 (roma_outdoor, coarse_res 672, upsample_res 1344): (value, atol)
+ACCEPTANCE_POSE = {"auc_5": (0.6271474434923545, 3e-1 / 100), "auc_10": (0.7673889435429945, 2e-1 / 100),
+                   "auc_20": (0.8642099162282599, 1e-1 / 100)}
 
 
 def warp_kpts(kpts0, depth0, depth1, T_0to1, K0, K1, relative_depth_error_threshold=0.05):
@@ -133,9 +141,94 @@ def ground_truth_matches(data):
     return torch.cat((grid, x2.reshape(b, h, w, 2).float()), dim=-1)
 
 
+# ------------------------------------------------------------------------------------------- MegaDepth-1500 pose benchmark
+def pose_benchmark(model, pairs, seed=0, num=5000, repeats=5, max_side=1200):
+    """megadepth_pose_estimation_benchmark.py:25-116 over an iterable of pairs
+    {im_A, im_B (what model.match takes: paths, PIL images or [3, H, W] tensors), K1, K2 [3, 3], T_1to2 [3, 4] or [4, 4],
+    size_A = (w1, h1), size_B = (w2, h2) of the ORIGINAL images}: per pair one `match`, then `repeats` x {`sample` 5 000
+    matches, pixel coordinates at the 1 200-pixel scale, shuffle, `estimate_pose` at 0.5 px / mean focal, pose error};
+    failures count as 90 degrees.  Returns the reference's dictionary (auc_5/10/20, map_5/10/20)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pose_geometry as PG
+    rng = np.random.default_rng(seed)
+    tot_e_pose = []
+    for pair in pairs:
+        K1, K2 = np.array(pair["K1"], dtype=np.float64), np.array(pair["K2"], dtype=np.float64)
+        T = np.array(pair["T_1to2"], dtype=np.float64)
+        R, t = T[:3, :3], T[:3, 3]
+        dense_matches, dense_certainty = model.match(pair["im_A"], pair["im_B"])
+        (w1, h1), (w2, h2) = pair["size_A"], pair["size_B"]
+        s1, s2 = max_side / max(w1, h1), max_side / max(w2, h2)   # the scaling of the DKM / RoMa papers (:58-65)
+        w1, h1, w2, h2 = s1 * w1, s1 * h1, s2 * w2, s2 * h2
+        K1, K2 = K1.copy(), K2.copy()
+        K1[:2] *= s1
+        K2[:2] *= s2
+        for _ in range(repeats):
+            sparse, _ = model.sample(dense_matches, dense_certainty, num)
+            k1, k2 = model.to_pixel_coordinates(sparse, h1, w1, h2, w2)
+            k1, k2 = k1.detach().cpu().double().numpy(), k2.detach().cpu().double().numpy()
+            sh = rng.permutation(len(k1))
+            k1, k2 = k1[sh], k2[sh]
+            try:
+                norm_threshold = 0.5 / (np.mean(np.abs(K1[:2, :2])) + np.mean(np.abs(K2[:2, :2])))
+                R_est, t_est, _ = PG.estimate_pose(k1, k2, K1, K2, norm_threshold, conf=0.99999, rng=rng)
+                e_t, e_R = PG.compute_pose_error(np.concatenate((R_est, t_est), axis=-1), R, t)
+            except Exception as e:  # estimate_pose returned None (too few matches / no model), like the reference's except
+                print(repr(e))
+                e_t, e_R = 90, 90
+            tot_e_pose.append(max(e_t, e_R))
+    tot = np.array(tot_e_pose)
+    auc = PG.pose_auc(tot, [5, 10, 20])
+    acc = [(tot < th).mean() for th in (5, 10, 15, 20)]
+    return {"auc_5": auc[0], "auc_10": auc[1], "auc_20": auc[2], "map_5": acc[0], "map_10": float(np.mean(acc[:2])),
+            "map_20": float(np.mean(acc))}
+
+
+def check_acceptance_pose(results):
+    return {k: abs(results[k] - ref) <= tol for k, (ref, tol) in ACCEPTANCE_POSE.items()}
+
+
+def synthetic_relief_pair(h, w, seed=0, noise_px=0.0, outlier_frac=0.0):
+    """A two-view scene with EXACT pose and dense correspondences for the pose harness: camera 1 sees a smooth relief
+    (depth 3 .. 5, not planar), camera 2 is rotated by a few degrees and translated.  Returns the pair dictionary of
+    pose_benchmark plus `gt_matches` [h, w, 4] (normalised A grid, exact B coordinates, optionally perturbed by Gaussian
+    pixel noise / a fraction of uniform outliers) and `gt_certainty` [h, w] (1 where the point projects inside image B)."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda: torch.rand(1, generator=g).item()
+    f = 0.9 * w
+    K = torch.tensor([[f, 0.0, w / 2], [0.0, f, h / 2], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float64) + 0.5, torch.arange(w, dtype=torch.float64) + 0.5, indexing="ij")
+    depth = 4.0 + 0.6 * torch.sin(xs / w * 5.0 + 6.0 * r()) + 0.4 * torch.cos(ys / h * 4.0 + 6.0 * r())
+    ax = torch.tensor([r() - 0.5, r() - 0.5, 0.3 * (r() - 0.5)], dtype=torch.float64)
+    ang = 0.05 + 0.1 * r()
+    ax = ax / ax.norm()
+    Kx = torch.tensor([[0.0, -ax[2], ax[1]], [ax[2], 0.0, -ax[0]], [-ax[1], ax[0], 0.0]], dtype=torch.float64)
+    R = torch.eye(3, dtype=torch.float64) + torch.sin(torch.tensor(ang)) * Kx + (1 - torch.cos(torch.tensor(ang))) * Kx @ Kx
+    t = torch.tensor([0.5 * (r() - 0.5) + 0.3, 0.3 * (r() - 0.5), 0.2 * (r() - 0.5)], dtype=torch.float64)
+    pix = torch.stack([xs, ys, torch.ones_like(xs)], dim=-1)
+    X1 = (pix @ K.inverse().T) * depth[..., None]
+    X2 = X1 @ R.T + t
+    p2 = X2 @ K.T
+    p2 = p2[..., :2] / p2[..., 2:]
+    vis = (p2[..., 0] > 0) & (p2[..., 0] < w) & (p2[..., 1] > 0) & (p2[..., 1] < h) & (X2[..., 2] > 0)
+    if noise_px > 0:
+        p2 = p2 + noise_px * torch.randn(p2.shape, generator=g, dtype=torch.float64)
+    if outlier_frac > 0:
+        bad = torch.rand(h, w, generator=g) < outlier_frac
+        rnd = torch.rand(h, w, 2, generator=g, dtype=torch.float64) * torch.tensor([w, h], dtype=torch.float64)
+        p2 = torch.where(bad[..., None], rnd, p2)
+    gridA = torch.stack((2 * xs / w - 1, 2 * ys / h - 1), dim=-1)
+    gridB = torch.stack((2 * p2[..., 0] / w - 1, 2 * p2[..., 1] / h - 1), dim=-1)
+    return {"im_A": None, "im_B": None, "K1": K.numpy(), "K2": K.numpy(), "T_1to2": torch.cat([R, t[:, None]], dim=1).numpy(),
+            "size_A": (w, h), "size_B": (w, h), "gt_matches": torch.cat((gridA, gridB), dim=-1).float(),
+            "gt_certainty": vis.float()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic planar batches (of 2 pairs) to run")
+    ap.add_argument("--synthetic-pose", type=int, default=0, help="number of synthetic pairs for the pose (MegaDepth-1500) loop")
     ap.add_argument("--megadepth", default=None, help="data root of the MegaDepth test split (reference: data/megadepth)")
     ap.add_argument("--weights", default=None)
     ap.add_argument("--dinov2", default=None)
@@ -154,6 +247,19 @@ def main():
                                     "this machine; see romatch/datasets/megadepth.py for the expected layout")
         raise NotImplementedError("MegaDepth loader: feed benchmark() with batches of the keys listed in its docstring "
                                   "(romatch.datasets.MegadepthBuilder.build_scenes(split='test_loftr', ht=res, wt=res))")
+    if args.synthetic_pose:
+        # the pose loop end to end through roma_amd's match + sample (planar synthetic images; with random weights the matches
+        # are noise, every pose fails or is wrong and the AUC is ~0: a plumbing check of the harness, not a result)
+        pairs = []
+        for s in range(args.synthetic_pose):
+            d = synthetic_planar_batch(1, args.res, args.res, seed=100 + s)
+            pairs.append({"im_A": d["im_A"].to("cuda:0"), "im_B": d["im_B"].to("cuda:0"), "K1": d["K1"][0].numpy(),
+                          "K2": d["K2"][0].numpy(), "T_1to2": d["T_1to2"][0].numpy(), "size_A": (args.res, args.res),
+                          "size_B": (args.res, args.res)})
+        res = pose_benchmark(model, pairs)
+        print(json.dumps({"pose_results": res, "acceptance_on_megadepth1500": {k: v[0] for k, v in ACCEPTANCE_POSE.items()},
+                          "note": "synthetic planar scenes" + ("" if args.weights else ", RANDOM weights: plumbing check only")}))
+        return
     batches = [synthetic_planar_batch(2, args.res, args.res, seed=s) for s in range(args.synthetic)]
     res = benchmark(model, batches)
     print(json.dumps({"results": res, "acceptance_on_megadepth": {k: v[0] for k, v in ACCEPTANCE.items()},
