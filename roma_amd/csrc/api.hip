@@ -222,7 +222,7 @@ int roma_tuning(const char* key, int value) {
   else if (k == "lc_mode") g_lc_mode = value;
   else if (k == "conv64") g_conv64_mode = value;
   else if (k == "attn_xcd") g_attn_xcd_map = value;
-  else if (k == "attn_v") g_attn_version = value;
+  else if (k == "attn_exp2") g_attn_exp2 = value;
   else if (k == "rb24w") g_rb24_wave = value;
   else if (k == "rb144_1b") g_rb144_1b = value;
   else if (k == "dw_ring") g_dw_ring = value;

@@ -18,6 +18,6 @@ struct AttnArgs {
   int xcd_map = 1;            // set by attention_launch (g_attn_xcd_map): workgroup -> work item order, see attention.hip
 };
 extern int g_attn_xcd_map;
-extern int g_attn_version;
+extern int g_attn_exp2;
 int attention_launch(const AttnArgs& a, hipStream_t stream);
 }  // namespace roma

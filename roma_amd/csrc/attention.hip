@@ -153,161 +153,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a) {
   }
 }
 
-// bf16 inputs, f32 softmax/accumulate; v_mfma_f32_32x32x16_bf16.
-template <int HD, typename TOUT, bool EXP2>
-__global__ __launch_bounds__(256, HD == 64 ? 4 : 2) void attn_bf16_kernel(const AttnArgs a) {
-  constexpr int KV = 64;
-  // bf16 elements per LDS row.  K rows (+8: 144 B) are read as 16-byte fragments, conflict free; V^T rows are read as
-  // 8-byte pieces by 32 lanes at once: a 136-byte pitch (34 dwords) spreads them over all 64 banks, the 144-byte
-  // pitch was a 2-way conflict (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.33)
-  constexpr int KS = HD + 8, VS = KV + 4;
-  constexpr int KT = KV / 32, DT = HD / 32, NS = HD / 16;
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[KV * KS];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[HD * VS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, h = lane >> 5;
-  int qt, head, b;
-  if (!attn_decode_block(a, qt, head, b)) return;
-  const long bh = (long)b * a.heads + head;
-  const int qi = qt * 128 + wave * 32 + l31;
-  const bf16_t* Q = reinterpret_cast<const bf16_t*>(a.q) + (bh * a.npad) * HD;
-  const bf16_t* K = reinterpret_cast<const bf16_t*>(a.k) + (bh * a.npad) * HD;
-  const bf16_t* Vt = reinterpret_cast<const bf16_t*>(a.vt) + (bh * HD) * a.npad;
-
-  uint4 qf[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const uint4*>(Q + (long)qi * HD + 16 * s + 8 * h);
-
-  f32x16 o[DT];
-#pragma unroll
-  for (int d = 0; d < DT; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  // K / V tiles travel global -> registers -> LDS; the loads of tile t+1 are issued (all at once) right after tile t
-  // has been published, so their latency is covered by the MFMA / softmax work instead of serialising four dependent
-  // round trips per tile
-  constexpr int NKC = KV * (HD / 8) / 256, NVC = HD * (KV / 8) / 256;  // 16-byte pieces per thread
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;  // (HIP's struct uint4 arrays went to scratch here)
-  u32x4_t kreg[NKC], vreg[NVC];
-#define ROMA_ATTN_FETCH(KV0)                                                                           \
-  {                                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < NKC; ++i) {                                                  \
-      const int idx = tid + 256 * i;                                                                   \
-      const int row = idx / (HD / 8), c8 = idx % (HD / 8);                                             \
-      kreg[i] = *reinterpret_cast<const u32x4_t*>(K + (long)((KV0) + row) * HD + c8 * 8);             \
-    }                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < NVC; ++i) {                                                  \
-      const int idx = tid + 256 * i;                                                                   \
-      const int row = idx / (KV / 8), c8 = idx % (KV / 8);                                             \
-      vreg[i] = *reinterpret_cast<const u32x4_t*>(Vt + (long)row * a.npad + (KV0) + c8 * 8);          \
-    }                                                                                                  \
-  }
-  ROMA_ATTN_FETCH(0);
-  for (int kv0 = 0; kv0 < a.N; kv0 += KV) {
-#pragma unroll
-    for (int i = 0; i < NKC; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx / (HD / 8), c8 = idx % (HD / 8);
-      *reinterpret_cast<u32x4_t*>(&Ks[row * KS + c8 * 8]) = kreg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NVC; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx / (KV / 8), c8 = idx % (KV / 8);
-      typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;  // rows are only 8-byte aligned now
-      *reinterpret_cast<u32x2_t*>(&Vs[row * VS + c8 * 8]) = u32x2_t{vreg[i].x, vreg[i].y};
-      *reinterpret_cast<u32x2_t*>(&Vs[row * VS + c8 * 8 + 4]) = u32x2_t{vreg[i].z, vreg[i].w};
-    }
-    __syncthreads();
-    // unconditional (a conditional fetch made hipcc keep kreg / vreg in scratch); past the end it re-reads the last tile
-    ROMA_ATTN_FETCH(min(kv0 + KV, a.npad - KV));
-    f32x16 s[KT];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-#pragma unroll
-      for (int st = 0; st < NS; ++st) {
-        const uint4 kf = *reinterpret_cast<const uint4*>(&Ks[(32 * kt + l31) * KS + 16 * st + 8 * h]);
-        s[kt] = mfma_h16_32x32x16(kf,
-                                                        qf[st], s[kt]);
-      }
-    }
-    if (kv0 + KV > a.N) {  // only the last tile has keys >= N to mask (uniform branch)
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (key >= a.N) s[kt][r] = -INFINITY;
-        }
-    }
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kt][r]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = EXP2 ? __builtin_amdgcn_exp2f(m_run - m_new) : __expf(m_run - m_new);
-    float lsum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = EXP2 ? __builtin_amdgcn_exp2f(s[kt][r] - m_new) : __expf(s[kt][r] - m_new);
-        s[kt][r] = p;
-        lsum += p;
-      }
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        uint4 pk;
-        pk.x = pack_bf16x2(s[kt][8 * u + 0], s[kt][8 * u + 1]);
-        pk.y = pack_bf16x2(s[kt][8 * u + 2], s[kt][8 * u + 3]);
-        pk.z = pack_bf16x2(s[kt][8 * u + 4], s[kt][8 * u + 5]);
-        pk.w = pack_bf16x2(s[kt][8 * u + 6], s[kt][8 * u + 7]);
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-          const bf16_t* vrow = &Vs[(32 * d + l31) * VS + 32 * kt + 16 * u + 4 * h];
-          const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-          const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 8);
-          const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          o[d] = mfma_h16_32x32x16(vf,
-                                                         pk, o[d]);
-        }
-      }
-    __syncthreads();
-  }
-  l_run += __shfl_xor(l_run, 32);
-  const float inv = 1.f / l_run;
-  if (qi < a.N) {
-    TOUT* O = reinterpret_cast<TOUT*>(a.out) + ((long)b * a.N + qi) * a.ldo + head * HD;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = o[d][4 * rg + j] * inv;
-        ElemIO<TOUT>::st4(O + 32 * d + 8 * rg + 4 * h, v);
-      }
-  }
-}
-
-#undef ROMA_ATTN_FETCH
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Version 2 of the 16-bit kernel (the default; roma_tuning("attn_v", 1) keeps the kernel above for A/B).
+// The 16-bit kernel (round 3's "version 2"; the round-1 kernel it replaced - always-rescaling online softmax, K / V staged
+// through registers - was removed in round 4 after a round of green history: git history, commit 069022a).
 //
 // The kernel above is bound by its VALU work, not by the matrix cores: per 64-key tile and wave, 16 MFMAs (512 cycles)
 // stand beside ~165 plain VALU instructions + 33 v_exp (profiles/r03_pmc_sq_summary.json: MFMA busy 0.37, the waves wait
@@ -516,7 +363,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_h16_v2_kernel(cons
 }
 #undef ROMA_ATTN_STAGE
 
-int g_attn_version = -1;  // roma_tuning("attn_v", v): 2 = attn_h16_v2_kernel (default), 1 = attn_bf16_kernel, -1 = env ROMA_ATTN_V
+int g_attn_exp2 = -1;     // roma_tuning("attn_exp2", v): tools only - force the 2^x softmax (q pre-scaled by log2 e) on / off; -1 = as the caller says
 int g_attn_xcd_map = -1;  // roma_tuning("attn_xcd", v): 1 = per-XCD bands of (b, head) (default), 0 = plain order, -1 = env ROMA_ATTN_XCD
 
 int attention_launch(const AttnArgs& a_in, hipStream_t stream) {
@@ -524,8 +371,7 @@ int attention_launch(const AttnArgs& a_in, hipStream_t stream) {
   ROMA_REQUIRE(a.hd == 64 || a.hd == 128, "attention: head dim must be 64 or 128");
   ROMA_REQUIRE(a.npad % 128 == 0 && a.npad >= a.N, "attention: Npad must be a multiple of 128 and >= N");
   ROMA_REQUIRE(a.ldo % 4 == 0, "attention: ldo must be a multiple of 4");
-  static const bool force_exp2 = getenv("ROMA_ATTN_FORCE_EXP2") && atoi(getenv("ROMA_ATTN_FORCE_EXP2")) != 0;  // tools/attn_determinism.py
-  if (force_exp2) a.exp2_domain = 1;
+  if (g_attn_exp2 >= 0) a.exp2_domain = g_attn_exp2 ? 1 : 0;  // tools/attn_determinism.py (never set on the product path)
   const long nwork = (long)((a.N + 127) / 128) * a.heads * a.B;
   static const int map_env = getenv("ROMA_ATTN_XCD") ? atoi(getenv("ROMA_ATTN_XCD")) : 1;
   a.xcd_map = g_attn_xcd_map >= 0 ? g_attn_xcd_map : map_env;
@@ -535,16 +381,9 @@ int attention_launch(const AttnArgs& a_in, hipStream_t stream) {
   snprintf(pname, sizeof pname, "attn_%s_kernel<%d>", a.in_dt == DT_F32 ? "f32" : ROMA_H16_NAME, a.hd);
   ProfScope ps(pname, 4.0 * (double)a.B * a.heads * (double)a.N * a.N * a.hd, "flop", stream);
 #define ROMA_ATTN(KERNEL, HDV, TOUT) hipLaunchKernelGGL((KERNEL<HDV, TOUT>), grid, dim3(256), 0, stream, a)
-  static const int ver_env = getenv("ROMA_ATTN_V") ? atoi(getenv("ROMA_ATTN_V")) : 2;
-  const int ver = g_attn_version >= 0 ? g_attn_version : ver_env;
 #define ROMA_ATTNV2(HDV, TOUT, E2) hipLaunchKernelGGL((attn_h16_v2_kernel<HDV, TOUT, E2>), grid, dim3(256), 0, stream, a);
-#define ROMA_ATTNB(HDV, TOUT)                                                                         \
-  {                                                                                                   \
-    if (ver >= 2) {                                                                                   \
-      if (a.exp2_domain) ROMA_ATTNV2(HDV, TOUT, true) else ROMA_ATTNV2(HDV, TOUT, false)              \
-    } else if (a.exp2_domain) hipLaunchKernelGGL((attn_bf16_kernel<HDV, TOUT, true>), grid, dim3(256), 0, stream, a);  \
-    else hipLaunchKernelGGL((attn_bf16_kernel<HDV, TOUT, false>), grid, dim3(256), 0, stream, a);     \
-  }
+#define ROMA_ATTNB(HDV, TOUT) \
+  { if (a.exp2_domain) ROMA_ATTNV2(HDV, TOUT, true) else ROMA_ATTNV2(HDV, TOUT, false) }
   if (a.in_dt == DT_F32) {
     if (a.hd == 64) { if (a.out_dt == DT_F32) ROMA_ATTN(attn_f32_kernel, 64, float); else ROMA_ATTN(attn_f32_kernel, 64, bf16_t); }
     else            { if (a.out_dt == DT_F32) ROMA_ATTN(attn_f32_kernel, 128, float); else ROMA_ATTN(attn_f32_kernel, 128, bf16_t); }

@@ -101,6 +101,7 @@ struct FinalArgs {
 int final_epilogue_launch(const FinalArgs& a, hipStream_t s);
 
 // out ^= order-independent 64-bit checksum of `bytes` bytes at p (whole 32-bit words); *out must be zeroed by the caller
+int checksum_cols_launch(const void* p, long rows, int ld, int c0, int c1, unsigned long long* out, hipStream_t s);
 int checksum_launch(const void* p, size_t bytes, unsigned long long* out, hipStream_t s);
 
 }  // namespace roma

@@ -1429,6 +1429,37 @@ __global__ __launch_bounds__(256) void checksum_kernel(const uint32_t* p, long n
   if ((threadIdx.x & 63) == 0 && h) atomicXor(out, h);
 }
 
+// diagnostic variant: only columns [c0, c1) of a [rows][ld] matrix of 16-bit elements
+__global__ __launch_bounds__(256) void checksum_cols_kernel(const unsigned short* p, long rows, int ld, int c0, int c1,
+                                                            unsigned long long* out) {
+  unsigned long long h = 0;
+  const int nc = c1 - c0;
+  const long n = rows * nc;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / nc;
+    const int c = c0 + (int)(i - r * nc);
+    unsigned long long x = ((unsigned long long)p[r * ld + c] << 32) ^ (unsigned long long)(i * 0x9E3779B97F4A7C15ull);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    h ^= x;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)h, off), hi = __shfl_xor((unsigned)(h >> 32), off);
+    h ^= ((unsigned long long)hi << 32) | lo;
+  }
+  if ((threadIdx.x & 63) == 0 && h) atomicXor(out, h);
+}
+
+int checksum_cols_launch(const void* p, long rows, int ld, int c0, int c1, unsigned long long* out, hipStream_t s) {
+  if (rows <= 0 || c1 <= c0) return 0;
+  const unsigned grid = (unsigned)std::min<long>((rows * (c1 - c0) + 255) / 256, 1024);
+  hipLaunchKernelGGL(checksum_cols_kernel, dim3(grid), dim3(256), 0, s, static_cast<const unsigned short*>(p), rows, ld, c0, c1, out);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
 int checksum_launch(const void* p, size_t bytes, unsigned long long* out, hipStream_t s) {
   const long nwords = (long)(bytes / 4);
   if (nwords <= 0) return 0;

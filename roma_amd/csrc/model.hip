@@ -525,8 +525,17 @@ int Model::ensure_side_streams(int n) {
   return 0;
 }
 
+// diagnostics (tools/repro_mixed.py): ROMA_DEBUG_DUAL_SLOT = k keeps the sub-batch stream split on in debug mode and lets only
+// sub-batch k capture its stages (the capture table is per handle, not per stream)
+static const int g_dbg_dual_slot = getenv("ROMA_DEBUG_DUAL_SLOT") ? atoi(getenv("ROMA_DEBUG_DUAL_SLOT")) : -1;
+static int g_dbg_cur_slot = 0;  // set by match_impl (host side, sequential)
+
 int Model::dbg_save(const char* name, const void* p, size_t bytes, hipStream_t st) {
   if (!debug) return 0;
+  if (g_dbg_dual_slot >= 0) {  // only the stages named in ROMA_DEBUG_ONLY (comma separated), only for the chosen sub-batch
+    static const std::string only = std::string(",") + (getenv("ROMA_DEBUG_ONLY") ? getenv("ROMA_DEBUG_ONLY") : "") + ",";
+    if (g_dbg_cur_slot != g_dbg_dual_slot || only.find(std::string(",") + name + ",") == std::string::npos) return 0;
+  }
   auto it = dbg.find(name);
   if (it == dbg.end() || it->second.second != bytes) {
     if (it != dbg.end()) (void)hipFree(it->second.first);
@@ -556,7 +565,7 @@ int Model::match_streams(int B, const float* ima, const float* imb, const float*
                          float* cert, hipStream_t st) {
   static const int env_streams = getenv("ROMA_STREAMS") ? atoi(getenv("ROMA_STREAMS")) : 0;
   static const bool serial_env = getenv("ROMA_STREAMS_SERIAL") && atoi(getenv("ROMA_STREAMS_SERIAL")) != 0;
-  const int ns = debug ? 1 : std::min(std::min(env_streams > 0 ? env_streams : n_streams, (int)MAX_STREAMS), B);
+  const int ns = (debug && g_dbg_dual_slot < 0) ? 1 : std::min(std::min(env_streams > 0 ? env_streams : n_streams, (int)MAX_STREAMS), B);
   if (ns <= 1) return match_impl(B, ima, imb, ima_hr, imb_hr, warp, cert, st, false, arena, persist);
   if (int rc = ensure_side_streams(ns)) return rc;
   // fork: the side streams start after everything already queued on the caller's stream (inputs); join at the end
@@ -747,6 +756,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
   auto AL = [&](size_t elems, size_t es) { return arena.alloc(elems * es); };
   // determinism trace: checksum of a stage's output, XORed into this sub-batch stream's table
   const int tslot = (&arena == &this->arena) ? 0 : (int)(&arena - side_arena) + 1;
+  g_dbg_cur_slot = tslot;
   const bool tracing = trace_on && !dry;
   if (tracing) {
     if (!trace_dev[tslot]) {
@@ -1006,6 +1016,8 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         ia.feat = pf; ia.ldf = ldf; ia.flow = flow; ia.d = d0; ia.ldd = r.Cp; ia.emb_w = r.emb_w; ia.emb_b = r.emb_b;
         ia.B = ndp; ia.H = hs; ia.W = ws; ia.C = r.Cf; ia.E = r.E; ia.Kcorr = r.K; ia.nimg = nimg; ia.shift = shift;
         ia.disp_scale = (float)(40.0 / 32.0 * scale_factor); ia.dt = act_dt;
+        if (tracing)
+          if (int rc = CK(tp + "_flow_before", flow, (size_t)M * 2 * 4)) return rc;
         RUN(refiner_input_launch(ia, st));
         if (r.radius) {
           LocalCorrArgs lc;
@@ -1018,11 +1030,33 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         }
         if (debug && !dry) {
           const std::string nm = std::string("p") + (up ? "2" : "1") + "_din" + SCALES[si];
-          if ((size_t)M * r.Cp * esz <= ((size_t)64 << 20))
+          if ((size_t)M * r.Cp * esz <= ((size_t)(g_dbg_dual_slot >= 0 ? 512 : 64) << 20))
             if (int rc = dbg_save(nm.c_str(), d0, (size_t)M * r.Cp * esz, st)) return rc;
+          if (g_dbg_dual_slot >= 0 && ins == 1)
+            if (int rc = dbg_save((std::string("p") + (up ? "2" : "1") + "_flowin1").c_str(), flow, (size_t)M * 2 * 4, st)) return rc;
         }
         void *dcur = d0, *dalt = d1;
         if (int rc = CK(tp + "_din", d0, (size_t)M * r.Cp * esz)) return rc;
+        if (tracing) {  // diagnostic re-reads: are the inputs of the stage still what they were, is d0 stable?
+          if (int rc = CK(tp + "_proj_again", pf, (size_t)nimg * hw * ldf * esz)) return rc;
+          if (int rc = CK(tp + "_flow_again", flow, (size_t)M * 2 * 4)) return rc;
+          if (int rc = CK(tp + "_din_again", d0, (size_t)M * r.Cp * esz)) return rc;
+          if (esz == 2 && r.E > 0) {  // which part of d deviates: x | x_hat | displacement embedding | rest; which directed pair
+            auto CKC = [&](const std::string& name, const void* p, long rows, int c0, int c1) -> int {
+              if (trace_n[tslot] >= TRACE_MAX) return 0;
+              const int k = trace_n[tslot]++;
+              if ((int)trace_names[tslot].size() <= k) trace_names[tslot].push_back(name);
+              else trace_names[tslot][k] = name;
+              return checksum_cols_launch(p, rows, r.Cp, c0, c1, trace_dev[tslot] + k, st);
+            };
+            if (int rc = CKC(tp + "_din_x", d0, M, 0, r.Cf)) return rc;
+            if (int rc = CKC(tp + "_din_xhat", d0, M, r.Cf, 2 * r.Cf)) return rc;
+            if (int rc = CKC(tp + "_din_emb", d0, M, 2 * r.Cf, 2 * r.Cf + r.E)) return rc;
+            if (int rc = CKC(tp + "_din_rest", d0, M, 2 * r.Cf + r.E, r.Cp)) return rc;
+            for (int b = 0; b < ndp; ++b)
+              if (int rc = CKC(tp + "_din_pair" + std::to_string(b), off(d0, (long)b * hw * r.Cp), hw, 0, r.Cp)) return rc;
+          }
+        }
         const bool fused = fuse_refiner_blocks && refiner_block_supported(r.Cp, act_dt);
         // (Running the nine-block chain over GROUPS of pairs whose ping-pong buffers fit the 256 MiB Infinity Cache was
         // measured in round 3 and is slower: 97.4 ms/step whole batch, 98.6 / 99.3 / 101.3 with 400 / 200 / 100 MiB
