@@ -135,7 +135,8 @@ int roma_destroy(roma_handle_t h);
  * kernel / wave-private ring kernel for launches >= 64 M elements (default) / ring kernel for every shape it takes;
  * "rb24w" 1 / 0 = C = 24 fused block: wave-private kernel (default) / two-barrier workgroup kernel; "rb144_1b" 1 / 0 = C = 144
  * fused block: one barrier per row (default) / two; "gemm8p_sched" 1 / 0 = K-loop schedule of the 8-phase GEMM: k-half
- * phases (default) / quadrant phases (bit-identical results).  Every alternative computes the same values (the stencil / block
+ * phases (default) / quadrant phases (bit-identical results); "ws1x1" 1 / 0 = the N = K = 576 refiner 1x1 on the
+ * weight-stationary kernel (default) / on the 256 x 192 tile kernel (bit-identical results).  Every alternative computes the same values (the stencil / block
  * kernels bit for bit); -1 restores the default (or the environment variable of the same name in upper case, ROMA_...). */
 int roma_tuning(const char* key, int value);
 /* measuring tool (tools/bench_gemm_ablation.py): after a GEMM launched with the "gemm_dbg" trace bit (32768), copies the

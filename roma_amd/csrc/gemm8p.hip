@@ -611,7 +611,11 @@ int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
   if (a.N >= 384) {
     const long w256 = ((a.N + 255) / 256) * 256, w192 = ((a.N + 191) / 192) * 192;
     tile256 = !(w192 < w256);
-    if (!tile256) return gemm6p_try_launch(a, stream);  // 256 x 192 tiles (gemm6p.hip)
+    if (!tile256) {
+      const int rc = ws1x1_try_launch(a, stream);  // C = 576 refiner 1x1: weight-stationary (ws1x1.hip)
+      if (rc <= 0) return rc;
+      return gemm6p_try_launch(a, stream);  // 256 x 192 tiles (gemm6p.hip)
+    }
   } else if (a.N > 192 && a.N <= 256) {
     tile256 = true;
   }

@@ -477,6 +477,29 @@ def test_dma_ring_kernels_keep_their_queue(built_lib, bdir):
         # allowance for the younger output stores either (a store can retire before an older load; the 1-in-1000 stale-row
         # reads of profiles/r03_v20_determinism_stress.log)
         assert waits and set(waits) == {15 if f == "dwconv_ring.o" else 9}, (f, waits)
+    # ws1x1.hip: weights in 144 registers, chunk ring with counted waits: no spills / scratch, and between the step's barrier
+    # and the loop's back edge no vmcnt wait at all (round 4: the wait-count pass carried "global load pending" on the weight
+    # registers into the loop and drained the ring in front of the first MFMA of every step)
+    ws = os.path.join(build, "ws1x1.o")
+    ks = kernel_resources.kernels(ws)
+    assert len(ks) == 2 and all(k["spill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 256 for k in ks), ks
+    dis = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", extract_code_object(ws)], capture_output=True, text=True,
+                         check=True).stdout
+    for kern in re.split(r"\n(?=[0-9a-f]+ <_Z)", dis):
+        if "ws1x1_kernel" not in kern.split("\n")[0]:
+            continue
+        lines = kern.split("\n")
+        w12 = [i for i, ln in enumerate(lines) if "s_waitcnt vmcnt(12)" in ln]
+        assert len(w12) == 1, len(w12)
+        bar = [i for i, ln in enumerate(lines) if "s_barrier" in ln and i > w12[0]]  # [0] = the step's ring barrier
+        pre = [int(m.group(1)) for ln in lines[bar[0] - 12:bar[0]] for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", ln)] if m]
+        assert sorted(pre) == [0, 6, 12], pre  # the three exact allowances of the step's wait
+        body = []
+        for ln in lines[bar[0]:]:
+            body.append(ln)
+            if re.search(r"s_cbranch_\w+ 6[0-9]{4}\b|s_branch 6[0-9]{4}\b", ln):
+                break
+        assert sum("v_mfma" in ln for ln in body) == 36 and not any("s_waitcnt vmcnt" in ln for ln in body), "vmcnt wait inside the step"
     att = [k for k in kernel_resources.kernels(objs["attention.o"]) if "attn_h16_v2_kernel" in k["name"]]
     assert len(att) == 8 and all(k["spill"] == 0 for k in att), att
     assert all(k["vgpr"] <= (168 if "<64" in k["name"] else 256) for k in att), att  # 3 / 2 workgroups per CU

@@ -219,6 +219,37 @@ def test_gemm8p_matches_classic_and_reference(lib, M, N, K, act, out_f32, sched)
     assert torch.allclose(out[:2048].cpu().double(), ref, atol=2e-3 if out_f32 else 0.03, rtol=1e-4 if out_f32 else 1e-2)
 
 
+@pytest.mark.parametrize("M,act", [(65536, 0), (74656, 1), (313600, 0), (65536 + 32 * 113, 1), (746496, 1)])
+def test_ws1x1_matches_tile_kernels_and_reference(lib, M, act):
+    """ws1x1.hip (weight-stationary N = K = 576 refiner 1x1: W in registers, pixel chunks through a two-stage LDS-DMA ring,
+    one- and two-stream workgroups) accumulates in the GEMM kernels' k order: bit-identical to gemm6p and to the classic
+    kernel, repeated launches agree (ring / barrier races), f64 reference on a sample of rows.  M values: the smallest it
+    takes, streams with an odd number of chunks and ragged last streams, the two model shapes."""
+    import ctypes as C
+    N = K = 576
+    A, W, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, std=K ** -0.5).bfloat16(), rnd(N, seed=3)
+    Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
+    outs = {}
+    try:
+        for name, g8, ws in (("classic", 0, 0), ("gemm6p", 1, 0), ("ws1x1", 1, 1), ("ws1x1_again", 1, 1)):
+            lib.roma_tuning(b"gemm8p", g8)
+            lib.roma_tuning(b"ws1x1", ws)
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            ok(lib, lib.roma_op_gemm(P(Ad), K, P(Wd), K, P(out), N, M, N, K, 1, 0, 0, 0, P(bd), None, None, 0, act, 1.0, BF16, BF16, None))
+            torch.cuda.synchronize()
+            outs[name] = out
+    finally:
+        lib.roma_tuning(b"gemm8p", -1)
+        lib.roma_tuning(b"ws1x1", -1)
+    for name in ("gemm6p", "ws1x1", "ws1x1_again"):
+        assert torch.equal(outs[name].view(torch.int16), outs["classic"].view(torch.int16)), (
+            name, float((outs[name].float() - outs["classic"].float()).abs().max()))
+    rows = torch.cat([torch.arange(0, 96), torch.arange(M // 2 - 40, M // 2 + 40), torch.arange(M - 96, M)])
+    ref = A[rows].double() @ W.double().T + b.double()
+    ref = F.relu(ref) if act == 1 else ref
+    assert torch.allclose(outs["ws1x1"][rows.cuda()].cpu().double(), ref, atol=0.03, rtol=1e-2)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 70, 70, 256, 512), (3, 56, 60, 128, 256), (2, 72, 70, 64, 256), (1, 108, 108, 512, 512)])
 @pytest.mark.parametrize("sched", [1, 0])
 def test_conv3x3_gemm8p_matches_classic_and_reference(lib, B, H, W, Cin, Cout, sched):
