@@ -12,7 +12,8 @@
 // The sample is then put in DRAW order (ascending race key = the order sequential draws would have produced them, which is
 // what torch.multinomial returns): callers that truncate or stride the result (`matches[:N]`) get a random subset, not the
 // spatially ordered one the compaction leaves.  k <= 40 000 in match(): an all-pairs rank (k^2 compares from LDS tiles) is
-// ~30 us and needs no sort.
+// ~30 us and needs no sort; above 65 536 (sample(num = 100 000) asks for k = 400 000) the same order comes from a bitonic
+// network over the packed (key, index) words - see ORDER_ALLPAIRS_MAX.
 #include "sampling.h"
 
 #include <stdint.h>
@@ -128,8 +129,76 @@ __global__ __launch_bounds__(256) void race_order_kernel(const float* __restrict
   if (i < k) out[rank] = mi;
 }
 
+// k > ORDER_ALLPAIRS_MAX (sample(num) beyond ~16 000 matches: k = 4 * num): k^2 compares would take seconds at k = 400 000.
+// The selected (key bits, index) pairs - one 64-bit word each, ordered exactly like the all-pairs rule (key, then index) - go
+// through a global-memory bitonic network instead: log2(P) (log2(P) + 1) / 2 passes over P = 2^ceil(log2 k) words (190 launches
+// of ~5 us at k = 400 000; the stages that fit one workgroup's 2048 words run fused in LDS).  Same result as the all-pairs
+// rank for every k; the switch is on size only.
+constexpr long ORDER_ALLPAIRS_MAX = 65536;
+
+static long order_pow2(long k) {
+  long p = 2048;
+  while (p < k) p <<= 1;
+  return p;
+}
+
+__global__ __launch_bounds__(256) void race_pack_kernel(const float* __restrict__ keys, const long long* __restrict__ sel, long k, long P,
+                                                        unsigned long long* __restrict__ comp) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  unsigned long long v = ~0ull;  // padding sorts last
+  if (i < k) {
+    const long long m = sel[i];
+    v = ((unsigned long long)__float_as_uint(keys[m]) << 32) | (unsigned long long)(unsigned)m;  // n < 2^31
+  }
+  comp[i] = v;
+}
+
+// one compare-exchange pass of the network at distance j inside sorted runs of length kk (global memory)
+__global__ __launch_bounds__(256) void bitonic_pass_kernel(unsigned long long* __restrict__ d, long j, long kk) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per pair
+  const long i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+  const unsigned long long a = d[i], b = d[l];
+  const bool asc = (i & kk) == 0;
+  if ((a > b) == asc) {
+    d[i] = b;
+    d[l] = a;
+  }
+}
+
+// every pass with distance j <= 1024 of the runs kk0 .. kk1 (kk0 <= kk1): 2048 consecutive words per workgroup in LDS.
+// kk0 = 2, kk1 = 2048 sorts each 2048-word block; kk0 = kk1 = kk > 2048 finishes the passes j = 1024 .. 1 of run length kk.
+__global__ __launch_bounds__(256) void bitonic_lds_kernel(unsigned long long* __restrict__ d, long kk0, long kk1) {
+  __shared__ unsigned long long v[2048];
+  const long base = (long)blockIdx.x * 2048;
+  for (int t = threadIdx.x; t < 2048; t += 256) v[t] = d[base + t];
+  __syncthreads();
+  for (long kk = kk0; kk <= kk1; kk <<= 1) {
+    for (int j = (int)(kk > 2048 ? 1024 : kk >> 1); j >= 1; j >>= 1) {
+      for (int t = threadIdx.x; t < 1024; t += 256) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+        const unsigned long long a = v[i], b = v[l];
+        const bool asc = ((base + i) & kk) == 0;
+        if ((a > b) == asc) {
+          v[i] = b;
+          v[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = threadIdx.x; t < 2048; t += 256) d[base + t] = v[t];
+}
+
+__global__ __launch_bounds__(256) void race_unpack_kernel(const unsigned long long* __restrict__ comp, long k, long long* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < k) out[i] = (long long)(comp[i] & 0xffffffffull);
+}
+
 size_t multinomial_workspace_bytes(long n, long k) {
-  return sizeof(SelState) + 2048 * sizeof(unsigned) + (size_t)n * sizeof(float) + (size_t)(k > 0 ? k : 0) * sizeof(long long) + 16;
+  size_t b = sizeof(SelState) + 2048 * sizeof(unsigned) + (size_t)n * sizeof(float) + (size_t)(k > 0 ? k : 0) * sizeof(long long) + 16;
+  if (k > ORDER_ALLPAIRS_MAX) b += (size_t)order_pow2(k) * sizeof(unsigned long long) + 16;
+  return b;
 }
 
 int multinomial_launch(const float* weights, long n, long k, unsigned long long seed, long long* out, void* ws, size_t ws_bytes,
@@ -159,7 +228,26 @@ int multinomial_launch(const float* weights, long n, long k, unsigned long long 
   }
   hipLaunchKernelGGL(race_compact_kernel, dim3(gn), dim3(256), 0, s, keys, n, st, sel, k);
   ROMA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(race_order_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, s, keys, sel, k, out);
+  if (k <= ORDER_ALLPAIRS_MAX) {
+    hipLaunchKernelGGL(race_order_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, s, keys, sel, k, out);
+    ROMA_LAUNCH_CHECK();
+    return 0;
+  }
+  const long P = order_pow2(k);
+  unsigned long long* comp = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(sel + k) + 15) & ~(uintptr_t)15);
+  hipLaunchKernelGGL(race_pack_kernel, dim3((unsigned)(P / 256)), dim3(256), 0, s, keys, sel, k, P, comp);
+  ROMA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bitonic_lds_kernel, dim3((unsigned)(P / 2048)), dim3(256), 0, s, comp, 2l, 2048l);
+  ROMA_LAUNCH_CHECK();
+  for (long kk = 4096; kk <= P; kk <<= 1) {
+    for (long j = kk >> 1; j >= 2048; j >>= 1) {
+      hipLaunchKernelGGL(bitonic_pass_kernel, dim3((unsigned)(P / 512)), dim3(256), 0, s, comp, j, kk);
+      ROMA_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bitonic_lds_kernel, dim3((unsigned)(P / 2048)), dim3(256), 0, s, comp, kk, kk);
+    ROMA_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(race_unpack_kernel, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, s, comp, k, out);
   ROMA_LAUNCH_CHECK();
   return 0;
 }

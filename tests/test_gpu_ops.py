@@ -954,6 +954,30 @@ def test_multinomial_without_replacement():
     assert big[:300].float().std() > 0.2 * n  # the first 300 of 3000 are spread over the whole index range
 
 
+def test_multinomial_large_k_keeps_the_draw_order():
+    """k > 65 536 (sample(num) of 100 000 asks for 400 000): the draw order comes from the bitonic network instead of the all-pairs
+    rank.  The race keys depend on (seed, index) only, so the first k' entries of a draw of k ARE the draw of k' with the same
+    seed - checked against the all-pairs form at k' = 3 000 and 65 536, for a k that is and one that is not a power of two."""
+    from roma_amd import multinomial
+    g = torch.Generator().manual_seed(11)
+    n = 600000
+    w = torch.rand(n, generator=g) ** 2
+    w[::5] = 0.0
+    wd = w.cuda()
+    for k in (70000, 131072, 400000):
+        gen = torch.Generator().manual_seed(77)
+        big = multinomial(wd, k, generator=gen)
+        assert big.shape == (k,) and len(torch.unique(big)) == k and bool((w[big.cpu()] > 0).all())
+        for kp in (3000, 65536):
+            gen = torch.Generator().manual_seed(77)
+            assert torch.equal(multinomial(wd, kp, generator=gen), big[:kp]), (k, kp)
+    # more draws than positive weights: the zero-weight entries (key = +inf) complete the sample behind every positive one
+    npos = int((w > 0).sum())
+    gen = torch.Generator().manual_seed(3)
+    allp = multinomial(wd, npos + 1000, generator=gen).cpu()
+    assert len(torch.unique(allp)) == npos + 1000 and bool((w[allp[:npos]] > 0).all()) and bool((w[allp[npos:]] == 0).all())
+
+
 def test_match_keypoints_vs_reference_golden():
     """RegressionMatcher.match_keypoints through roma_op_sample_warp_at + roma_op_mutual_nn: index-exact against the
     reference's own output (tests/golden/keypoints_reference.npz) for both parameter sets, plus the return variants."""
