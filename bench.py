@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARIES = ("profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json")
+PMC_SUMMARIES = ("profiles/r04_pmc_summary.json", "profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json")
 
 
 def pmc_traffic(kernel):
@@ -51,16 +51,26 @@ def pmc_traffic(kernel):
     want = "void roma::" + base + ("<" + ", ".join(conv.get(t, t) for t in targs) + ">" if targs else "")
     if base == "gemm8p_kernel" and len(targs) == 4:    # profile scope <in,out,form,epilogue> -> <TOUT, CONV, EPI, DMAMF>
         epi = {"none": 0, "relu": 1, "gelu": 2, "res_bf16": 3, "qkv": 4}[targs[3]]
-        want = f"void roma::gemm8p_kernel<{conv[targs[1]]}, {conv[targs[2]]}, {epi}, false>"
+        want = f"void roma::gemm8p_kernel<{conv[targs[1]]}, {conv[targs[2]]}, {epi}, false"  # (+ ", SCHED, ABL>" since round 4)
     elif base == "gemm6p_kernel" and len(targs) == 4:  # -> <TOUT, ACT>
         act = {"none": 0, "relu": 1}[targs[3]]
         want = f"void roma::gemm6p_kernel<{conv[targs[1]]}, {act}>"
+    elif base == "ws1x1_kernel" and len(targs) == 2:   # -> <ACT>
+        want = "void roma::ws1x1_kernel<%d>" % {"none": 0, "relu": 1}[targs[1]]
     for rel in PMC_SUMMARIES:
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
         pm = json.load(open(path))
-        f, w = pm.get("FETCH_SIZE", {}).get(want), pm.get("WRITE_SIZE", {}).get(want)
+        def pick(table):  # exact name, else the instantiation(s) that start with it (trailing template arguments added later)
+            for exact in (want, want + ">"):
+                if exact in table:
+                    return table[exact]
+            hits = [v for k, v in table.items() if k.startswith(want + ",")]
+            if not hits:
+                return None
+            return {"launches": sum(h["launches"] for h in hits), "sum_kb": sum(h["sum_kb"] for h in hits)}
+        f, w = pick(pm.get("FETCH_SIZE", {})), pick(pm.get("WRITE_SIZE", {}))
         if f and w and f["launches"]:
             return (2.0 * f["sum_kb"] / f["launches"] + w["sum_kb"] / w["launches"]) * 1024.0, rel
     return None, None

@@ -1,7 +1,7 @@
 """Determinism stress of the sub-batch stream split (GPU box): repeated match() with 2 HIP streams against the
 single-stream result of the same handle; reports the runs / pairs / bounding boxes that differ.
 
-    python tools/stress_streams.py --pairs 3 --runs 400 [--fuse 0|1] [--amp bf16|f16|mixed|f32] [--trace]
+    python tools/stress_streams.py --pairs 3 --runs 400 [--fuse 0|1] [--amp bf16|f16|mixed|f32] [--seed S] [--trace]
 Kernel-selection switches come from the environment (ROMA_GEMM8P, ROMA_LC_MODE, ROMA_RI_VEC, ROMA_STREAMS_SERIAL ...),
 so one GPU visit can run a matrix of configurations (tools/r02_visit2.sh)."""
 import argparse
@@ -20,6 +20,7 @@ ap.add_argument("--runs", type=int, default=400)
 ap.add_argument("--fuse", type=int, default=1)
 ap.add_argument("--amp", default="bf16")
 ap.add_argument("--res", type=int, nargs=2, default=[112, 168])
+ap.add_argument("--seed", type=int, default=7, help="seed of the synthetic image pairs")
 ap.add_argument("--trace", action="store_true", help="per-stage checksums: name the first stage that deviates from the majority")
 args = ap.parse_args()
 
@@ -28,7 +29,7 @@ sd, dsd = synthetic.make_matcher_state_dict(0), synthetic.make_dinov2_state_dict
 NB = args.pairs
 amp = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16, "mixed": torch.bfloat16}[args.amp]
 env = {k: v for k, v in os.environ.items() if k.startswith("ROMA_")}
-inp = {k: v.cuda() for k, v in synthetic.make_inputs(NB, args.res[0], args.res[1], seed=7).items()}
+inp = {k: v.cuda() for k, v in synthetic.make_inputs(NB, args.res[0], args.res[1], seed=args.seed).items()}
 m = roma_model((args.res[0],) * 2, True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=amp, symmetric=True,
                upsample_res=(args.res[1],) * 2, max_batch=NB, decoder_dtype=torch.float16 if args.amp == "mixed" else None)
 lib = m._lib  # the library of this mode
