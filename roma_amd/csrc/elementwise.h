@@ -44,8 +44,8 @@ int rownorm_launch(const void* in, long ld, int dt, float* norms, long M, int C,
 // (row-major, x fastest); columns j >= h*w are zero.  Ft: [Dg, npad]
 int gp_basis_launch(const float* w, const float* b, float* Ft, int Dg, int h, int wdt, int npad, hipStream_t s);
 
-// batched square transpose (f32): out[b][j][i] = in[b][i][j], n x n with leading dim ld
-int transpose_launch(const float* in, float* out, int n, long ld, int batch, hipStream_t s);
+// batched square transpose (f32): out[b][j][i] = in[b][i][j], n x n with leading dim ld; batch strides default to n * ld
+int transpose_launch(const float* in, float* out, int n, long ld, int batch, hipStream_t s, long stride_in = 0, long stride_out = 0);
 
 // Cholesky of one 64x64 diagonal block per batch item, in place (lower), plus its inverse and inverse^T.
 // A: [batch][n][ld]; block k starts at (64k,64k).  Linv/LinvT: [batch][nblk][64][64]

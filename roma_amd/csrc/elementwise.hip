@@ -388,10 +388,10 @@ int gp_basis_launch(const float* w, const float* b, float* Ft, int Dg, int h, in
 }
 
 // ------------------------------------------------------------------ batched square transpose
-__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, int n, long ld) {
+__global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* out, int n, long ld, long stride_in, long stride_out) {
   __shared__ float tile[32][33];
-  const float* ib = in + (long)blockIdx.z * n * ld;
-  float* ob = out + (long)blockIdx.z * n * ld;
+  const float* ib = in + (long)blockIdx.z * stride_in;
+  float* ob = out + (long)blockIdx.z * stride_out;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
   for (int j = ty; j < 32; j += 8)
@@ -401,9 +401,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* in, float* 
     if (x0 + j < n && y0 + tx < n) ob[(long)(x0 + j) * ld + y0 + tx] = tile[tx][j];
 }
 
-int transpose_launch(const float* in, float* out, int n, long ld, int batch, hipStream_t s) {
+int transpose_launch(const float* in, float* out, int n, long ld, int batch, hipStream_t s, long stride_in, long stride_out) {
   dim3 grid((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32), (unsigned)batch);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, n, ld);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, n, ld, stride_in > 0 ? stride_in : (long)n * ld,
+                     stride_out > 0 ? stride_out : (long)n * ld);
   ROMA_LAUNCH_CHECK();
   return 0;
 }

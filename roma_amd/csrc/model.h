@@ -157,6 +157,10 @@ int gp_posterior(const void* pf, long ldf, int act_dt, int B, bool symmetric, in
                  const float* gp_b, float* mu, long ld_mu, Arena& arena, hipStream_t st, bool dry);
 
 // Batched SPD solve via blocked Cholesky (see include/roma_hip.h roma_op_cholesky_solve_t)
-int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, int n, int d, int batch, hipStream_t st);
+// strideA / strideR: batch strides of A and Rt in floats (0 = dense: n * n and d * n).  When Rt is stored right behind A
+// (Rt == A + n * n, strideA == strideR: one (n + d) x n matrix per item) the forward substitution is folded into the
+// factorisation loop - see cholesky_solve_t.
+int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, int n, int d, int batch, hipStream_t st,
+                     long strideA = 0, long strideR = 0);
 
 }  // namespace roma

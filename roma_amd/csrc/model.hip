@@ -604,20 +604,32 @@ int Model::match_streams(int B, const float* ima, const float* imb, const float*
 //   panel  L[i,k]  = A[i,k] Linv_kk^T ; trailing A[i,j] -= L[i,k] L[j,k]^T (lower tiles only)
 //   fwd    Yt[:,k] = Rt[:,k] Linv_kk^T ; Rt[:,i>k] -= Yt[:,k] L[i,k]^T
 //   bwd    Xt[:,k] = Rt[:,k] Linv_kk   ; Rt[:,j<k] -= Xt[:,k] L[k,j]      (via LT = L^T)
-int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, int n, int d, int batch, hipStream_t st) {
+// Round 4 - the augmented form.  The forward substitution does to the d rows of Rt exactly what the factorisation does to the
+// rows of A below the diagonal block: multiply the column block k by Linv_kk^T, then subtract its product with L[j,k]^T from the
+// column blocks j > k.  When the caller stores Rt right behind A (one (n + d) x n matrix per item), the panel and the trailing
+// GEMM of step k simply run over mrem + d rows and the 2 * nblk - 1 launches of the forward loop disappear from the GP's
+// launch-latency-bound chain (~0.75 ms of 10 .. 25 us launches at n = 1600); same operations on every element in the same
+// order, so the result is bit-identical to the separate loop.
+int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, int n, int d, int batch, hipStream_t st,
+                     long strideA, long strideR) {
   ROMA_REQUIRE(n % 64 == 0 && n > 0 && d % 4 == 0, "cholesky_solve: n must be a multiple of 64, d of 4");
   const int nblk = n / 64;
-  const long sA = (long)n * n, sR = (long)d * n, sL = (long)nblk * 4096;
+  const long sA = strideA > 0 ? strideA : (long)n * n, sR = strideR > 0 ? strideR : (long)d * n, sL = (long)nblk * 4096;
+  const long sLT = (long)n * n;  // LT is always dense
+  static const bool aug_env = !(getenv("ROMA_GP_AUG") && atoi(getenv("ROMA_GP_AUG")) == 0);  // A/B: 0 = always the separate forward loop
+  const bool aug = aug_env && Rt == A + (long)n * n && (batch == 1 || (sA == sR && sA >= (long)(n + d) * n));
+  const int extra = aug ? d : 0;
   for (int k = 0; k < nblk; ++k) {
     if (int rc = chol_diag_launch(A, n, sA, Linv, LinvT, k, nblk, batch, st)) return rc;
     const int mrem = n - (k + 1) * 64;
-    if (mrem <= 0) break;
+    if (mrem + extra <= 0) break;
     GemmArgs g;
     g.A = A + (long)(k + 1) * 64 * n + k * 64; g.lda = n; g.sA = sA;
     g.W = Linv + (long)k * 4096; g.ldw = 64; g.sW = sL;
     g.C = const_cast<float*>(static_cast<const float*>(g.A)); g.ldc = n; g.sC = sA;
-    g.M = mrem; g.N = 64; g.K = 64; g.batch = batch;
+    g.M = mrem + extra; g.N = 64; g.K = 64; g.batch = batch;
     if (int rc = gemm_launch(g, st)) return rc;
+    if (mrem <= 0) break;
     GemmArgs t;
     t.A = g.A; t.lda = n; t.sA = sA;
     t.W = g.A; t.ldw = n; t.sW = sA;
@@ -625,11 +637,11 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
     t.C = Ct; t.ldc = n; t.sC = sA;
     t.res = Ct; t.ldr = n; t.sR = sA;
     t.alpha = -1.f; t.lower_only = 1;
-    t.M = mrem; t.N = mrem; t.K = 64; t.batch = batch;
+    t.M = mrem + extra; t.N = mrem; t.K = 64; t.batch = batch;
     if (int rc = gemm_launch(t, st)) return rc;
   }
-  if (int rc = transpose_launch(A, LT, n, n, batch, st)) return rc;
-  for (int k = 0; k < nblk; ++k) {  // forward
+  if (int rc = transpose_launch(A, LT, n, n, batch, st, sA, sLT)) return rc;
+  for (int k = 0; k < nblk && !aug; ++k) {  // forward (separate right-hand sides only)
     GemmArgs g;
     g.A = Rt + k * 64; g.lda = n; g.sA = sR;
     g.W = Linv + (long)k * 4096; g.ldw = 64; g.sW = sL;
@@ -657,7 +669,7 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
     if (k == 0) break;
     GemmArgs u;
     u.A = Rt + k * 64; u.lda = n; u.sA = sR;
-    u.W = LT + k * 64; u.ldw = n; u.sW = sA;
+    u.W = LT + k * 64; u.ldw = n; u.sW = sLT;
     u.C = Rt; u.ldc = n; u.sC = sR;
     u.res = Rt; u.ldr = n; u.sR = sR;
     u.alpha = -1.f;
@@ -687,13 +699,16 @@ int gp_posterior(const void* pf, long ldf, int act_dt, int B, bool symmetric, in
   auto AL = [&](size_t elems, size_t es) { return arena.alloc(elems * es); };
   auto off = [&](const void* p, long elems) -> const void* { return static_cast<const char*>(p) + elems * (long)esz; };
   float* norms = (float*)AL((size_t)nimg * n, 4);
-  float* Kyy = (float*)AL((size_t)nimg * npad * npad, 4);
+  // K_yy and the right-hand sides F^T of an image in ONE (npad + 512) x npad matrix: cholesky_solve_t then runs the forward
+  // substitution inside the factorisation loop
+  const long saug = (long)(npad + 512) * npad;
+  float* Kyy = (float*)AL((size_t)nimg * saug, 4);
+  float* Rt = Kyy + (long)npad * npad;  // image j: Kyy + j * saug, Rt + j * saug
   float* LT = (float*)AL((size_t)nimg * npad * npad, 4);
   float* Kxy = (float*)AL((size_t)ndp * n * npad, 4);
   float* Linv = (float*)AL((size_t)nimg * nblk * 4096, 4);
   float* LinvT = (float*)AL((size_t)nimg * nblk * 4096, 4);
   float* Ft = (float*)AL((size_t)512 * npad, 4);
-  float* Rt = (float*)AL((size_t)nimg * 512 * npad, 4);
   GP_RUN(rownorm_launch(pf, ldf, act_dt, norms, (long)nimg * n, 512, st));
   // support images actually needed: symmetric -> all, else images [B, 2B)
   const int j0 = symmetric ? 0 : B, nj = symmetric ? nimg : B;
@@ -701,13 +716,13 @@ int gp_posterior(const void* pf, long ldf, int act_dt, int B, bool symmetric, in
     GemmArgs g;  // K_yy + sigma^2 I  (cosine kernel, CosKernel matcher.py:191-200)
     g.A = off(pf, (long)j0 * n * ldf); g.lda = ldf; g.sA = (long)n * ldf;
     g.W = g.A; g.ldw = ldf; g.sW = g.sA;
-    g.C = Kyy + (long)j0 * npad * npad; g.ldc = npad; g.sC = (long)npad * npad;
+    g.C = Kyy + (long)j0 * saug; g.ldc = npad; g.sC = saug;
     g.M = n; g.N = n; g.K = 512; g.batch = nj; g.in_dt = act_dt; g.out_dt = DT_F32; g.mode = EPI_COSK;
     g.nx = norms + (long)j0 * n; g.ny = g.nx; g.sNx = n; g.sNy = n; g.inv_t = 1.0f / 0.2f; g.diag_add = 0.1f;
     GP_RUN(gemm_launch(g, st));
   }
-  GP_RUN(pad_identity_launch(Kyy + (long)j0 * npad * npad, npad, (long)npad * npad, n, npad, nj, st));
-  if (!dry) ROMA_CHECK_HIP(hipMemsetAsync(Kxy, 0, (size_t)ndp * n * npad * 4, st));
+  GP_RUN(pad_identity_launch(Kyy + (long)j0 * saug, npad, saug, n, npad, nj, st));
+  if (!dry && npad != n) ROMA_CHECK_HIP(hipMemsetAsync(Kxy, 0, (size_t)ndp * n * npad * 4, st));  // (pad columns only: the GEMM writes the rest)
   for (int half = 0; half < (symmetric ? 2 : 1); ++half) {
     GemmArgs g;  // K_xy for directed pairs [half*B, half*B + B): x = image i, y = image (i + B) % nimg
     const int i0 = half * B, s0 = (i0 + shift) % nimg;
@@ -720,14 +735,14 @@ int gp_posterior(const void* pf, long ldf, int act_dt, int B, bool symmetric, in
   }
   GP_RUN(gp_basis_launch(gp_w, gp_b, Ft, 512, th, tw, npad, st));
   for (int j = j0; j < j0 + nj; ++j)
-    if (!dry) ROMA_CHECK_HIP(hipMemcpyAsync(Rt + (long)j * 512 * npad, Ft, (size_t)512 * npad * 4, hipMemcpyDeviceToDevice, st));
-  GP_RUN(cholesky_solve_t(Kyy + (long)j0 * npad * npad, Rt + (long)j0 * 512 * npad, LT + (long)j0 * npad * npad,
-                          Linv + (long)j0 * nblk * 4096, LinvT + (long)j0 * nblk * 4096, npad, 512, nj, st));
+    if (!dry) ROMA_CHECK_HIP(hipMemcpyAsync(Rt + (long)j * saug, Ft, (size_t)512 * npad * 4, hipMemcpyDeviceToDevice, st));
+  GP_RUN(cholesky_solve_t(Kyy + (long)j0 * saug, Rt + (long)j0 * saug, LT + (long)j0 * npad * npad,
+                          Linv + (long)j0 * nblk * 4096, LinvT + (long)j0 * nblk * 4096, npad, 512, nj, st, saug, saug));
   for (int half = 0; half < (symmetric ? 2 : 1); ++half) {
     GemmArgs g;  // mu = K_xy alpha
     const int i0 = half * B, s0 = (i0 + shift) % nimg;
     g.A = Kxy + (long)i0 * n * npad; g.lda = npad; g.sA = (long)n * npad;
-    g.W = Rt + (long)s0 * 512 * npad; g.ldw = npad; g.sW = (long)512 * npad;
+    g.W = Rt + (long)s0 * saug; g.ldw = npad; g.sW = saug;
     g.C = mu + (long)i0 * n * ld_mu; g.ldc = ld_mu; g.sC = (long)n * ld_mu;
     g.M = n; g.N = 512; g.K = npad; g.batch = B;
     GP_RUN(gemm_launch(g, st));

@@ -445,6 +445,34 @@ def test_cholesky_solve(lib, n, d, batch):
     assert torch.allclose(torch.tril(Ad.cpu().double()), Lref, atol=1e-4)
 
 
+@pytest.mark.parametrize("n,d", [(64, 512), (320, 512), (1600, 512)])
+def test_cholesky_solve_augmented_storage_is_bit_identical(lib, n, d):
+    """Round 4: with F^T stored right behind A (one (n + d) x n matrix, what gp_posterior allocates) the forward substitution runs
+    inside the factorisation loop - the same operations on every element in the same order, so X, the factor and the block
+    inverses must equal the separate-buffer form bit for bit."""
+    y = rnd(1, n, 48, seed=11)
+    yn = y / y.norm(dim=-1, keepdim=True)
+    A = (torch.exp((yn @ yn.transpose(1, 2) - 1.0) / 0.2) + 0.1 * torch.eye(n))[0]
+    Ft = rnd(d, n, seed=12)
+    outs = []
+    for aug in (False, True):
+        buf = torch.empty(((n + d) * n + 4096,), device="cuda")
+        Ad = buf[:n * n].view(n, n)
+        Ad.copy_(A)
+        Fd = buf[n * n:(n + d) * n].view(d, n) if aug else torch.empty((d, n), device="cuda")
+        Fd.copy_(Ft)
+        LT = torch.empty((n, n), device="cuda")
+        Linv = torch.empty((n // 64, 64, 64), device="cuda")
+        LinvT = torch.empty_like(Linv)
+        ok(lib, lib.roma_op_cholesky_solve_t(P(Ad), P(Fd), P(LT), P(Linv), P(LinvT), n, d, 1, None))
+        torch.cuda.synchronize()
+        outs.append((Fd.clone(), torch.tril(Ad).clone(), Linv.clone(), LT.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    ref = torch.cholesky_solve(Ft.t().double(), torch.linalg.cholesky(A.double()))
+    assert torch.allclose(outs[1][0].cpu().t().double(), ref, atol=2e-4, rtol=1e-4)
+
+
 def test_cls_to_flow_reference_golden(lib):
     g = np.load(os.path.join(GOLDEN, "ops_reference.npz"))
     cls = torch.from_numpy(g["c2f_cls"])  # [B,4096,H,W]
