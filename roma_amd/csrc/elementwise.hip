@@ -415,8 +415,14 @@ int transpose_launch(const float* in, float* out, int n, long ld, int batch, hip
 // reads, rows are stride-65 so lane-parallel accesses are conflict free.  The previous 256-thread version spent
 // 127 us per call on 192 __syncthreads(); the blocked Cholesky issues 25 such calls on the GP's critical path.
 // (A fully unrolled register/readlane variant was correct but ~70 KB of straight-line code: instruction-fetch bound.)
-__global__ __launch_bounds__(64) void chol_diag_kernel(float* A, long ld, long strideA, float* Linv, float* LinvT,
-                                                       int k, int nblk) {
+// Round 4: TWO waves in a pipeline.  Row r of the inverse only needs columns <= r of the factor, and column j is final the
+// moment the factorisation has finished its step j - so wave 1 runs the forward substitutions one row behind wave 0's column
+// steps instead of after them (wave 0 publishes its progress in LDS; the LDS executes a wave's operations in order, so a
+// plain flag store behind a step's writes and a flag poll in front of a row's reads are all the ordering needed), and all four
+// waves share the 16 KB load and the 48 KB write-back.  53 -> ~33 us per call on the GP's launch-latency-bound chain (25 calls);
+// arithmetic and its order unchanged: bit-identical results.
+__global__ __launch_bounds__(256) void chol_diag_kernel(float* A, long ld, long strideA, float* Linv, float* LinvT,
+                                                        int k, int nblk) {
   // 68-float rows: 16-byte aligned and conflict free for lane-per-row ds_read_b128 (bank = 4 * lane).  The inner loops
   // move 4 columns per LDS operation (row piece of this lane + a broadcast piece of the transposed copy): the scalar
   // version issued ~10k dependent single-dword LDS operations per call and took 123 us on the GP's critical path.
@@ -424,53 +430,70 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(float* A, long ld, long s
   __shared__ __attribute__((aligned(16))) float L[64 * S];   // L[i][c]   (lane i owns row i)
   __shared__ __attribute__((aligned(16))) float LT[64 * S];  // LT[j][c] = L[c][j]   (broadcast source)
   __shared__ __attribute__((aligned(16))) float XT[64 * S];  // XT[c][t] = X[t][c]   (lane c owns row c)
+  __shared__ int progress;  // last finished column step of the factorisation (relaxed workgroup-scope atomics: plain ds_read / ds_write)
   float* Ab = A + (long)blockIdx.x * strideA + ((long)k * 64) * ld + (long)k * 64;
-  const int i = threadIdx.x;
-  for (int idx = i; idx < 64 * 16; idx += 64) {  // coalesced float4 loads
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = tid & 63;
+  for (int idx = tid; idx < 64 * 16; idx += 256) {  // coalesced float4 loads
     const int row = idx >> 4, c4 = idx & 15;
     *reinterpret_cast<f32x4*>(&L[row * S + c4 * 4]) = *reinterpret_cast<const f32x4*>(Ab + (long)row * ld + c4 * 4);
   }
+  if (tid == 0) progress = -1;
+  __syncthreads();
+  if (wave == 0) {
 #pragma unroll
-  for (int jb = 0; jb < 4; ++jb) {  // columns in four bands: a band's steps touch column groups >= 16 jb only
-    for (int j = 16 * jb; j < 16 * jb + 16; ++j) {
-      const float d = sqrtf(L[j * S + j]);
-      const float lij = (i == j) ? d : L[i * S + j] / d;
-      L[i * S + j] = lij;   // rows < j: harmless garbage in the strictly upper part
-      LT[j * S + i] = lij;  // column j of the factor, contiguous
-      // a_ic -= l_ij * l_cj for c > j.  Every column group of the band's range every time (selects, no trip count that
-      // depends on j): the LDS operations of a step are independent and pipeline, instead of ~150 cycles of latency per
-      // group; the compile-time band start drops the 37 % of the groups that lie wholly left of column j.
+    for (int jb = 0; jb < 4; ++jb) {  // columns in four bands: a band's steps touch column groups >= 16 jb only
+      for (int j = 16 * jb; j < 16 * jb + 16; ++j) {
+        const float d = sqrtf(L[j * S + j]);
+        const float lij = (i == j) ? d : L[i * S + j] / d;
+        L[i * S + j] = lij;   // rows < j: harmless garbage in the strictly upper part
+        LT[j * S + i] = lij;  // column j of the factor, contiguous
+        // column j is final: let the inverse take row j.  (The LDS executes one wave's operations in order, so the two stores
+        // above land before this one without a wait; the empty asm keeps the COMPILER from moving them.)
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(&progress, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        // a_ic -= l_ij * l_cj for c > j.  Every column group of the band's range every time (selects, no trip count that
+        // depends on j): the LDS operations of a step are independent and pipeline, instead of ~150 cycles of latency per
+        // group; the compile-time band start drops the 37 % of the groups that lie wholly left of column j.
 #pragma unroll
-      for (int c = 16 * jb; c < 64; c += 4) {
-        f32x4 a = *reinterpret_cast<const f32x4*>(&L[i * S + c]);
-        const f32x4 lc = *reinterpret_cast<const f32x4*>(&LT[j * S + c]);  // same address in every lane: broadcast
+        for (int c = 16 * jb; c < 64; c += 4) {
+          f32x4 a = *reinterpret_cast<const f32x4*>(&L[i * S + c]);
+          const f32x4 lc = *reinterpret_cast<const f32x4*>(&LT[j * S + c]);  // same address in every lane: broadcast
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = (c + u > j) ? a[u] - lij * lc[u] : a[u];
-        *reinterpret_cast<f32x4*>(&L[i * S + c]) = a;
+          for (int u = 0; u < 4; ++u) a[u] = (c + u > j) ? a[u] - lij * lc[u] : a[u];
+          *reinterpret_cast<f32x4*>(&L[i * S + c]) = a;
+        }
+      }
+    }
+  } else if (wave == 1) {
+    // inverse: lane c solves L x = e_c by forward substitution; x lives in XT[c][.].  Four interleaved partial sums
+    // (t mod 4) keep the dependent-FMA chain at 16 instead of 64 per row.  Row r reads L[r][t <= r] only: final once the
+    // factorisation has published step r (the entries right of the diagonal it may see half-updated are masked out).
+    const int c = i;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {  // rows in four bands: row r only needs the unknowns t < r, i.e. groups < 16 (rb + 1)
+      for (int r = 16 * rb; r < 16 * rb + 16; ++r) {
+        while (__hip_atomic_load(&progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < r) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");  // the reads below are issued after the flag has been seen
+        f32x4 part = {(r == c) ? 1.f : 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 16 * (rb + 1); t += 4) {
+          const f32x4 lr = *reinterpret_cast<const f32x4*>(&L[r * S + t]);   // broadcast
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(&XT[c * S + t]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) part[u] = (t + u < r) ? part[u] - lr[u] * xv[u] : part[u];
+        }
+        XT[c * S + r] = ((part[0] + part[1]) + (part[2] + part[3])) / L[r * S + r];
       }
     }
   }
-  // inverse: lane c solves L x = e_c by forward substitution; x lives in XT[c][.].  Four interleaved partial sums
-  // (t mod 4) keep the dependent-FMA chain at 16 instead of 64 per row.
-  const int c = i;
-#pragma unroll
-  for (int rb = 0; rb < 4; ++rb) {  // rows in four bands: row r only needs the unknowns t < r, i.e. groups < 16 (rb + 1)
-    for (int r = 16 * rb; r < 16 * rb + 16; ++r) {
-      f32x4 part = {(r == c) ? 1.f : 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 16 * (rb + 1); t += 4) {
-        const f32x4 lr = *reinterpret_cast<const f32x4*>(&L[r * S + t]);   // broadcast
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(&XT[c * S + t]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) part[u] = (t + u < r) ? part[u] - lr[u] * xv[u] : part[u];
-      }
-      XT[c * S + r] = ((part[0] + part[1]) + (part[2] + part[3])) / L[r * S + r];
-    }
-  }
+  __syncthreads();
   float* Li = Linv + ((long)blockIdx.x * nblk + k) * 4096;
   float* LiT = LinvT + ((long)blockIdx.x * nblk + k) * 4096;
   // write-back, 16 bytes per lane: the factor (upper part zeroed), Linv^T rows (= XT rows) and Linv (transposed read)
-  for (int idx = i; idx < 64 * 16; idx += 64) {
+  for (int idx = tid; idx < 64 * 16; idx += 256) {
     const int row = idx >> 4, c4 = (idx & 15) * 4;
     f32x4 lv = *reinterpret_cast<const f32x4*>(&L[row * S + c4]);
     f32x4 xt = *reinterpret_cast<const f32x4*>(&XT[row * S + c4]);  // XT[row][c4..] = X[c4..][row] = LinvT[row][c4..]
@@ -489,7 +512,7 @@ __global__ __launch_bounds__(64) void chol_diag_kernel(float* A, long ld, long s
 
 int chol_diag_launch(float* A, long ld, long strideA, float* Linv, float* LinvT, int k, int nblk, int batch,
                      hipStream_t s) {
-  hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)batch), dim3(64), 0, s, A, ld, strideA, Linv, LinvT, k, nblk);
+  hipLaunchKernelGGL(chol_diag_kernel, dim3((unsigned)batch), dim3(256), 0, s, A, ld, strideA, Linv, LinvT, k, nblk);
   ROMA_LAUNCH_CHECK();
   return 0;
 }

@@ -20,6 +20,10 @@ struct GemmArgs {
   long lda = 0, ldw = 0, ldc = 0;
   long sA = 0, sW = 0, sC = 0;  // batch strides in elements
   int M = 0, N = 0, K = 0, batch = 1;
+  // second batch level (gemm_kernel only; batch2 > 1 keeps the problem off the persistent / 8-phase paths): item z of the
+  // batch * batch2 launched uses offsets (z / batch2) * s? + (z % batch2) * s?2 - e.g. (image, diagonal block) of the GP solve
+  int batch2 = 1;
+  long sA2 = 0, sW2 = 0, sC2 = 0, sR2 = 0;
   int in_dt = DT_F32, out_dt = DT_F32;
   float alpha = 1.f;
   const float* bias = nullptr;   // [N]

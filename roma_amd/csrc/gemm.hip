@@ -64,8 +64,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
   long li = blockIdx.x / 8;
   if (li >= per_xcd || (long)xcd * per_xcd + li >= nblk) return;
 
-  const TIN* Ab = reinterpret_cast<const TIN*>(a.A) + (long)bz * a.sA;
-  const TIN* Wb = reinterpret_cast<const TIN*>(a.W) + (long)bz * a.sW;
+  const int bz1 = bz / a.batch2, bz2 = bz - bz1 * a.batch2;  // two batch levels (batch2 = 1: bz1 = bz, bz2 = 0)
+  const TIN* Ab = reinterpret_cast<const TIN*>(a.A) + (long)bz1 * a.sA + (long)bz2 * a.sA2;
+  const TIN* Wb = reinterpret_cast<const TIN*>(a.W) + (long)bz1 * a.sW + (long)bz2 * a.sW2;
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
   // ---- per-lane DMA descriptors: lane -> (row = 8q + lane/8, slot = lane%8), source chunk = slot ^ swizzle(row)
@@ -328,8 +329,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int l31e = lane_e & 31, he = lane_e >> 5;
-  TOUT* Cb = reinterpret_cast<TOUT*>(a.C) + (long)bz * a.sC;
-  const float* Rb = a.res ? a.res + (long)bz * a.sR : nullptr;
+  TOUT* Cb = reinterpret_cast<TOUT*>(a.C) + (long)bz1 * a.sC + (long)bz2 * a.sC2;
+  const float* Rb = a.res ? a.res + (long)bz1 * a.sR + (long)bz2 * a.sR2 : nullptr;
   const bool vecC = ((a.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cb) & 15) == 0);
   const bool vecR = Rb && ((a.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(Rb) & 15) == 0);
 
@@ -509,16 +510,16 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   long gx = ((nblk + 7) / 8) * 8;
   // (the 4-wave tiles serve the small / HBM-bound problems: several short-lived workgroups per CU overlap their
   //  store drain with each other better than one persistent workgroup that waits on its own stores)
-  if (!a.lower_only && a.batch == 1 && WM * WN == 8) {
+  if (!a.lower_only && a.batch * a.batch2 == 1 && WM * WN == 8) {
     const long occ = std::max<long>(1, std::min<long>(8, (160 * 1024) / (long)lds));
     gx = std::min<long>(gx, 256 * occ);
   }
-  dim3 grid((unsigned)gx, 1, (unsigned)a.batch);
+  dim3 grid((unsigned)gx, 1, (unsigned)(a.batch * a.batch2));
   char pname[96];
   snprintf(pname, sizeof pname, "gemm_kernel<%s,%s,%d,%d,%d,%d,%s>", sizeof(TIN) == 4 ? "f32" : ROMA_H16_NAME,
            sizeof(TOUT) == 4 ? "f32" : ROMA_H16_NAME, WM, WN, TM, TN, CONV ? "conv3x3" : "dense");
   // algorithmic FLOPs: the caller's M (a.M may have been padded to npad tokens per image for the QKV epilogue)
-  ProfScope ps(pname, 2.0 * (double)(a.m_alg > 0 ? a.m_alg : a.M) * (a.n_alg > 0 ? a.n_alg : a.N) * (a.k_alg > 0 ? a.k_alg : a.K) * a.batch *
+  ProfScope ps(pname, 2.0 * (double)(a.m_alg > 0 ? a.m_alg : a.M) * (a.n_alg > 0 ? a.n_alg : a.N) * (a.k_alg > 0 ? a.k_alg : a.K) * a.batch * a.batch2 *
                           (a.lower_only ? 0.5 : 1.0), "flop", stream);
   // the > 64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: one flag per device ordinal
   static bool attr_set[64] = {false};
@@ -540,7 +541,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 template <typename TIN, typename TOUT, bool CONV>
 static int launch_shape(const GemmArgs& a, hipStream_t stream) {
   if (a.N <= 32) return launch_cfg<TIN, TOUT, 4, 1, 1, 1, CONV>(a, stream);       // 128 x 32
-  const bool big_m = (long)a.M * a.batch >= 8192 && a.M >= 1024;
+  const bool big_m = (long)a.M * a.batch * a.batch2 >= 8192 && a.M >= 1024;
   if (big_m && a.N >= 384) {
     const long w256 = ((a.N + 255) / 256) * 256, w192 = ((a.N + 191) / 192) * 192;
     if (w192 < w256) return launch_cfg<TIN, TOUT, 4, 2, 2, 3, CONV>(a, stream);    // 256 x 192
@@ -560,7 +561,7 @@ static int launch_shape(const GemmArgs& a, hipStream_t stream) {
   // profiles/r02_final_bench_coarse.json).  128 x 64 tiles double the workgroups; three fit a CU (48 KiB of LDS each), so
   // all of them are resident at once and a CU interleaves the waves of 1-2 tiles.  ROMA_GEMM_SMALLM=0 switches it off (A/B).
   static const bool smallm_env = !(getenv("ROMA_GEMM_SMALLM") && atoi(getenv("ROMA_GEMM_SMALLM")) == 0);
-  const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch;
+  const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.batch * a.batch2;
   if (smallm_env && !a.lower_only && tiles128 < 320) return launch_cfg<TIN, TOUT, 4, 1, 1, 2, CONV>(a, stream);  // 128 x 64
   return launch_cfg<TIN, TOUT, 2, 2, 2, 2, CONV>(a, stream);                      // 128 x 128
 }
@@ -576,11 +577,12 @@ int gemm_launch(const GemmArgs& a0, hipStream_t stream) {
   static const bool nt_env = !(getenv("ROMA_GEMM_NT") && atoi(getenv("ROMA_GEMM_NT")) == 0);
   if (nt_env && !(a.dbg & 2048)) a.dbg |= 1024;
   const int ce = a.in_dt == DT_F32 ? 4 : 8;
-  ROMA_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "gemm: empty problem");
+  ROMA_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0 && a.batch2 > 0, "gemm: empty problem");
+  ROMA_REQUIRE(a.batch2 == 1 || (a.mode == EPI_STD && !a.res_bf16 && a.conv_c == 0), "gemm: the second batch level serves plain f32 / 16-bit problems only");
   ROMA_REQUIRE(a.K % ce == 0, "gemm: K must be a multiple of the 16-byte chunk");
   ROMA_REQUIRE(a.ldw % ce == 0 && (reinterpret_cast<uintptr_t>(a.W) & 15) == 0, "gemm: W not 16-byte aligned");
   ROMA_REQUIRE((reinterpret_cast<uintptr_t>(a.A) & 15) == 0, "gemm: A not 16-byte aligned");
-  ROMA_REQUIRE(a.sA % ce == 0 && a.sW % ce == 0, "gemm: batch strides must keep 16-byte alignment");
+  ROMA_REQUIRE(a.sA % ce == 0 && a.sW % ce == 0 && a.sA2 % ce == 0 && a.sW2 % ce == 0, "gemm: batch strides must keep 16-byte alignment");
   if (a.bias) ROMA_REQUIRE((reinterpret_cast<uintptr_t>(a.bias) & 15) == 0, "gemm: bias not 16-byte aligned");
   if (a.scale) ROMA_REQUIRE((reinterpret_cast<uintptr_t>(a.scale) & 15) == 0, "gemm: scale not 16-byte aligned");
   if (a.res_bf16) {  // only the staged bf16 row-writer knows this residual: refuse anything that would bypass it

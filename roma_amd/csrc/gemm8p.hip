@@ -597,7 +597,7 @@ int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
   const int use = g_gemm_tuning[0] >= 0 ? g_gemm_tuning[0] : use_env;
   if (!use) return 1;
   if ((long)a.M * 1 >= (1L << 31) - 512) return 1;
-  if (a.in_dt != DT_BF16 || a.batch != 1 || a.lower_only || a.alpha != 1.0f) return 1;
+  if (a.in_dt != DT_BF16 || a.batch != 1 || a.batch2 != 1 || a.lower_only || a.alpha != 1.0f) return 1;
   if (a.K % 64 != 0 || a.K < 4 * 64 || a.K > 32704) return 1;
   const bool conv = a.conv_c > 0;
   if (conv && (a.conv_c % 64 != 0 || a.conv_c > 512)) return 1;

@@ -659,6 +659,36 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
     u.M = d; u.N = mrem; u.K = 64; u.batch = batch;
     if (int rc = gemm_launch(u, st)) return rc;
   }
+  static const bool bwd_env = !(getenv("ROMA_GP_BWD2") && atoi(getenv("ROMA_GP_BWD2")) == 0);  // A/B: 0 = two launches per backward step
+  if (bwd_env && nblk > 1) {
+    // Backward substitution with ONE launch per step.  X_k = R_k Linv_kk and R_j -= X_k L[k,j] (j < k) re-associate to
+    // R_j -= R_k (Linv_kk L[k,j]): the products M_k = Linv_kk L[k, :k] do not depend on the right-hand sides, so they are formed
+    // for all k at once (in place over L^T: LT[:, block k] <- LT[:, block k] LinvT_kk, one launch with the second batch
+    // level over k), the chain is the nblk - 1 update GEMMs on the not-yet-scaled R_k, and all X_k = R_k Linv_kk follow in one
+    // launch at the end.  2 + nblk - 1 launches instead of 2 nblk - 1 on the GP's launch-latency-bound chain.
+    GemmArgs m;
+    m.A = LT; m.lda = n; m.sA = sLT; m.sA2 = 64;
+    m.W = Linv; m.ldw = 64; m.sW = sL; m.sW2 = 4096;
+    m.C = LT; m.ldc = n; m.sC = sLT; m.sC2 = 64;
+    m.M = n; m.N = 64; m.K = 64; m.batch = batch; m.batch2 = nblk;
+    if (int rc = gemm_launch(m, st)) return rc;
+    for (int k = nblk - 1; k >= 1; --k) {
+      GemmArgs u;
+      u.A = Rt + k * 64; u.lda = n; u.sA = sR;
+      u.W = LT + k * 64; u.ldw = n; u.sW = sLT;
+      u.C = Rt; u.ldc = n; u.sC = sR;
+      u.res = Rt; u.ldr = n; u.sR = sR;
+      u.alpha = -1.f;
+      u.M = d; u.N = k * 64; u.K = 64; u.batch = batch;
+      if (int rc = gemm_launch(u, st)) return rc;
+    }
+    GemmArgs x;
+    x.A = Rt; x.lda = n; x.sA = sR; x.sA2 = 64;
+    x.W = LinvT; x.ldw = 64; x.sW = sL; x.sW2 = 4096;
+    x.C = Rt; x.ldc = n; x.sC = sR; x.sC2 = 64;
+    x.M = d; x.N = 64; x.K = 64; x.batch = batch; x.batch2 = nblk;
+    return gemm_launch(x, st);
+  }
   for (int k = nblk - 1; k >= 0; --k) {  // backward
     GemmArgs g;
     g.A = Rt + k * 64; g.lda = n; g.sA = sR;

@@ -281,7 +281,7 @@ static int launch_ws(const GemmArgs& a, hipStream_t stream) {
 int ws1x1_try_launch(const GemmArgs& a, hipStream_t stream) {
   if (!(ws_mode() & 1)) return 1;
   if (a.N != WS_N || a.K != WS_K || a.lda != WS_K || a.ldw != WS_K || a.ldc != WS_N) return 1;
-  if (a.in_dt != DT_BF16 || a.out_dt != DT_BF16 || a.batch != 1 || a.conv_c > 0 || a.mode != EPI_STD) return 1;
+  if (a.in_dt != DT_BF16 || a.out_dt != DT_BF16 || a.batch != 1 || a.batch2 != 1 || a.conv_c > 0 || a.mode != EPI_STD) return 1;
   if (a.res || a.res_bf16 || a.scale || a.qkv_pad || a.alpha != 1.0f || !a.bias) return 1;
   if (a.act != ACT_NONE && a.act != ACT_RELU) return 1;
   if (a.M % WS_PX != 0 || a.M < 64 * 1024) return 1;  // whole 32-pixel chunks; small problems stay on the tile kernels
