@@ -129,7 +129,7 @@ int roma_destroy(roma_handle_t h);
  * route the large bf16 GEMMs to the 8-phase kernel or keep them on the one-barrier-per-slab kernel (-1 = environment
  * ROMA_GEMM8P, default on); "gemm_dbg" = experiment bits of the GEMM kernels (-1 = environment ROMA_GEMM_DBG);
  * "lc_mode" = local correlation: 0 tiled LDS form with a per-tile gather work list (default), 1 every tile on the gather
- * list, 2 the per-pixel kernel of round 1, 3 the VALU tile kernel (-1 = environment ROMA_LC_MODE); "conv64" = bit mask of the
+ * list, 2 the per-pixel kernel of round 1 (-1 = environment ROMA_LC_MODE); "conv64" = bit mask of the
  * weight-stationary VGG front-end kernels; "attn_xcd" 1 / 0 = attention work items in per-XCD bands; "attn_exp2" 1 / 0 = tools
  * only: force the 2^x softmax of the 16-bit attention kernel on / off (it assumes q pre-scaled by log2 e); "dw_ring" 0 / 1 / 2 = depthwise 5x5: register-prefetch
  * kernel / wave-private ring kernel for launches >= 64 M elements (default) / ring kernel for every shape it takes;

@@ -656,7 +656,7 @@ static int check_common(const LocalCorrArgs& a, int ce) {
   return 0;
 }
 
-int g_lc_mode = -1;  // roma_tuning("lc_mode"): -1 / 0 = tiled (MFMA all-pairs for 16-bit features) + work list (default), 1 = every tile to the gather list, 2 = legacy per-pixel launch, 3 = tiled with the VALU dot kernel of round 2
+int g_lc_mode = -1;  // roma_tuning("lc_mode"): -1 / 0 = tiled (MFMA all-pairs for 16-bit features) + work list (default), 1 = every tile to the gather list, 2 = per-pixel launch (the form every other radius uses)
 
 template <int R, typename T, typename TOUT, bool MFMA>
 static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
@@ -689,14 +689,9 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   ROMA_LAUNCH_CHECK();
   // gather list: one query per wave, four per workgroup.  (Eight waves per workgroup - to share the two dependent scalar
   // loads at the head of every workgroup - were measured SLOWER on the benchmark model's incoherent warps: 1.86 vs 1.60 ms
-  // at r = 2, 0.96 vs 0.91 at r = 3, profiles/r03_final_visit.log; ROMA_LC_LISTW=8 keeps the variant for A/B.)
-  static const int listw_env = getenv("ROMA_LC_LISTW") ? atoi(getenv("ROMA_LC_LISTW")) : 4;
-  if (listw_env != 8)
-    hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT, 4>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
-                       stream, a);
-  else
-    hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT, 8>), dim3((unsigned)tiles * 8u), dim3(512), (size_t)8 * a.C * sizeof(float),
-                       stream, a);
+  // at r = 2, 0.96 vs 0.91 at r = 3, profiles/r03_final_visit.log; the variant was removed in round 4.)
+  hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT, 4>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
+                     stream, a);
   ROMA_LAUNCH_CHECK();
   if (own_ws) ROMA_CHECK_HIP(hipFreeAsync(a.ws, stream));
   return 0;
@@ -721,10 +716,6 @@ static int launch_window_r(const LocalCorrArgs& a, hipStream_t stream) {
     if (mode != 2 && a.C % cc == 0) {
       if (a.in_dt == DT_F32 && a.out_dt == DT_F32) return launch_tiled<R, float, float, false>(a, stream);
       if (a.in_dt == DT_F32) return launch_tiled<R, float, bf16_t, false>(a, stream);
-      if (mode == 3) {  // A/B: the VALU (v_dot2) tile kernel of round 2 for 16-bit features
-        if (a.out_dt == DT_F32) return launch_tiled<R, bf16_t, float, false>(a, stream);
-        return launch_tiled<R, bf16_t, bf16_t, false>(a, stream);
-      }
       if (a.out_dt == DT_F32) return launch_tiled<R, bf16_t, float, true>(a, stream);
       return launch_tiled<R, bf16_t, bf16_t, true>(a, stream);
     }

@@ -7,7 +7,7 @@
              L2 / Infinity Cache whatever the kernel does -> the tiles go to the per-query gather work list
 
 Modes (roma_tuning "lc_mode"): 0 = tiled (16-bit features: all-pairs on the matrix core, round 3) + work list (default),
-3 = tiled with the v_dot2 kernel of round 2, 1 = every tile forced onto the gather work list (isolates the list kernel
+1 = every tile forced onto the gather work list (isolates the list kernel
 against the per-pixel kernel on identical work), 2 = the per-pixel kernel of round 1.
 Reports ms and ALGORITHMIC GB/s = (f0 + f1 read once + warp + outputs) / time.
 
@@ -52,8 +52,8 @@ def run(r, c, h, w, B, regime, dt):
     es = 2.0 if dt == BF16 else 4.0
     alg_bytes = B * h * w * (2.0 * c * es + 8.0 + K * es)
     res = {}
-    names = {0: "tiled", 3: "tiled_valu_round2", 1: "all_to_gather_list", 2: "per_pixel"}
-    for mode in (0, 3, 1, 2):
+    names = {0: "tiled", 1: "all_to_gather_list", 2: "per_pixel"}
+    for mode in (0, 1, 2):
         lib.roma_tuning(b"lc_mode", mode)
 
         def call():
