@@ -35,7 +35,7 @@ echo "== PMC: SQ"
 bash tools/pmc_sq_round.sh > "$OUT/pmc_sq_round.log" 2>&1; tail -14 "$OUT/pmc_sq_round.log" | cut -c1-200
 cp gpurun_out/pmc_sq_summary.json "$OUT/" 2>/dev/null
 echo "== determinism stress at the benchmark size (two streams vs one, bit-exact)"
-for seed in 7 8 9; do timeout 300 python tools/stress_streams.py --pairs 8 --res 560 864 --runs 20 --amp bf16 --seed $seed 2>&1 | tail -1 | cut -c1-260; done | tee "$OUT/stress.log"
-timeout 300 python tools/stress_streams.py --pairs 8 --res 560 864 --runs 20 --amp mixed 2>&1 | tail -1 | cut -c1-260 | tee -a "$OUT/stress.log"
-timeout 300 python tools/stress_streams.py --pairs 8 --res 560 864 --runs 6 --amp f32 2>&1 | tail -1 | cut -c1-260 | tee -a "$OUT/stress.log"
+for seed in 7 8 9; do timeout 300 python tools/stress_streams.py --pairs 8 --res 560 864 --runs 100 --amp bf16 --seed $seed 2>&1 | tail -1 | cut -c1-260; done | tee "$OUT/stress.log"
+timeout 300 python tools/stress_streams.py --pairs 8 --res 560 864 --runs 100 --amp mixed 2>&1 | tail -1 | cut -c1-260 | tee -a "$OUT/stress.log"
+timeout 300 python tools/stress_streams.py --pairs 8 --res 560 864 --runs 20 --amp f32 2>&1 | tail -1 | cut -c1-260 | tee -a "$OUT/stress.log"
 echo "== done"
