@@ -574,12 +574,8 @@ int Model::match_streams(int B, const float* ima, const float* imb, const float*
   const size_t px = (size_t)Ho * Wo * (cfg.symmetric ? 2 : 1);
   ROMA_CHECK_HIP(hipEventRecord(ev_fork, st));
   int rc = 0, b0 = 0;
-  // experiment switch (not an option of the product): ROMA_STREAM_SPLIT0 = k gives sub-batch 0 k pairs and the side stream the rest
-  // (two streams only; the side arena is planned for max_batch / 2 pairs, so k >= B - max_batch / 2)
-  static const int split0_env = getenv("ROMA_STREAM_SPLIT0") ? atoi(getenv("ROMA_STREAM_SPLIT0")) : 0;
-  const int split0 = (ns == 2 && split0_env >= B - cfg.max_batch / 2 && split0_env < B) ? split0_env : 0;
   for (int i = 0; i < ns; ++i) {  // balanced contiguous split; part 0 (the largest) stays on the caller's stream
-    const int bi = split0 ? (i == 0 ? split0 : B - split0) : B / ns + (i < B % ns ? 1 : 0);
+    const int bi = B / ns + (i < B % ns ? 1 : 0);
     hipStream_t si = i == 0 ? st : side[i - 1];
     if (i > 0) ROMA_CHECK_HIP(hipStreamWaitEvent(si, ev_fork, 0));
     if (i > 0 && serial_env) {  // diagnostic: same streams and arenas, but no overlap - sub-batch i starts after i - 1 ended
