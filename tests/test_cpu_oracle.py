@@ -341,6 +341,22 @@ def test_every_ctypes_call_site_passes_the_declared_number_of_arguments():
     assert seen > 100 and not bad, bad
 
 
+def test_stream_overlap_analysis_of_the_committed_two_stream_trace():
+    """tools/stream_overlap.py on the committed rocprofv3 kernel trace of the two-stream bench (profiles/r04_final_*): both HIP
+    queues are inside kernels for the whole step, and the time both sub-batches spend in the GP's launch-latency-bound chain at
+    the same moment - the number DESIGN.md section 4 quotes - is what the tool prints."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stream_overlap.py"),
+                          os.path.join(ROOT, "profiles", "r04_final_bench_bf16_2stream_kernel_trace.csv.gz")], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"last step: ([\d.]+) ms wall .* (\d+) kernels on queues \[(\d+), (\d+)\]", out.stdout)
+    assert m and 70 < float(m.group(1)) < 130 and int(m.group(2)) > 900, out.stdout[:400]
+    gp = re.search(r"gp_chain \+ gp_chain\s+([\d.]+)", out.stdout)
+    assert gp and 2.0 < float(gp.group(1)) < 5.0, out.stdout
+    both = re.search(r"2 queue\(s\) in a kernel ([\d.]+) ms", out.stdout)
+    assert both and float(both.group(1)) > 0.95 * float(m.group(1))
+
+
 def test_library_exports_every_declared_symbol(built_lib):
     """include/roma_hip.h <-> libroma_hip.so <-> ctypes table: same symbol set; no compute without a GPU."""
     from roma_amd import _lib

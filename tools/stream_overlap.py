@@ -1,6 +1,6 @@
 """Who runs next to whom: concurrency analysis of a rocprofv3 --kernel-trace CSV of the two-stream bench (tools/r04_final.sh).
 
-    python tools/stream_overlap.py <..._kernel_trace.csv>
+    python tools/stream_overlap.py <..._kernel_trace.csv[.gz]>
 
 For the last complete step of the trace (between the final_epilogue kernels of consecutive match() calls):
   * per HIP queue: number of kernels, sum of their durations, gaps between consecutive kernels;
@@ -14,6 +14,8 @@ For the last complete step of the trace (between the final_epilogue kernels of c
 """
 import collections
 import csv
+import gzip
+import io
 import re
 import sys
 
@@ -35,7 +37,8 @@ def klass(name):
 
 def main(path):
     ev = []
-    for r in csv.DictReader(open(path)):
+    fh = io.TextIOWrapper(gzip.open(path, "rb")) if path.endswith(".gz") else open(path)
+    for r in csv.DictReader(fh):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], int(r["Queue_Id"])))
     ev.sort()
     fin = [e for s, e, n, q in ev if "final_epilogue" in n]
