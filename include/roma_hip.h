@@ -43,7 +43,9 @@ typedef struct {
   int symmetric;              /* matcher.py:801   */
   int upsample_preds;         /* matcher.py:836   */
   int attenuate_cert;         /* matcher.py:839   */
-  int precision;              /* ROMA_F32 (exact f32 MFMA; CPU-oracle parity) or the library's 16-bit code */
+  int precision;              /* ROMA_F32 (exact f32 MFMA; CPU-oracle parity), the library's 16-bit code, or - binary16 build
+                                 only - ROMA_MIXED: DINOv2 in bfloat16, everything else in binary16 (the policy of
+                                 tests/test_roma_upsample_inference_time.py:36-45 + roma_models.py:183-188) */
   int max_batch;              /* largest number of image pairs per roma_match call                 */
   int device;                 /* HIP device ordinal                                                */
 } roma_config_t;
