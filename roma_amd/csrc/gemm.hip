@@ -348,6 +348,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs a)
         continue;  // next tile
       }
     }
+    if constexpr (sizeof(TOUT) == 4 && TM * TN <= 6) {  // (not the 256 x 256 tile: it is at 256 registers and COSK problems never take it)
+      if (a.mode == EPI_COSK && vecC && (a.N & 3) == 0 && (a.sNy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.ny) & 15) == 0) {
+        if constexpr (NWAVES != 8) __builtin_amdgcn_s_barrier();
+        epi_staged_cosk<TM, TN>(acc, a, reinterpret_cast<float*>(Cb), a.nx + (long)bz * a.sNx, a.ny + (long)bz * a.sNy,
+                                smem + (NWAVES == 8 ? 2 * BUF : 0) + wave * SLICE, m0 + (long)wm * TM * 32, n0 + wn * TN * 32, lane_e);
+        if (!has_next) break;
+        continue;  // next tile
+      }
+    }
     bool staged = a.mode == EPI_STD && (reinterpret_cast<uintptr_t>(Cb) & 15) == 0;
     if constexpr (sizeof(TOUT) == 2)  // res_bf16: see gemm_launch; no per-column scale in the bf16 row writer
       staged = staged && Rb == nullptr && (a.ldc & 7) == 0 && (a.scale == nullptr || a.res_bf16 != nullptr);

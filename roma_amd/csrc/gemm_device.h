@@ -362,4 +362,63 @@ __device__ __forceinline__ void epi_staged_f32(const f32x16 (&acc)[TN][TM], cons
   }
 }
 
+// EPI_COSK with f32 output (the GP's Gram matrices, matcher.py:191-200: exp((x.y / (|x||y| + 1e-6) - 1) / T) + diag), staged like
+// epi_staged_f32.  Round 4: the generic epilogue wrote these 1600 x 1600 x 16 matrices straight from the MFMA layout - 32 rows x
+// 32 B per wave store, ~0.8 TB/s - which made a 42-GFLOP launch take 200 us.  Same arithmetic as the generic path (true
+// division, libm expf: the Gram matrix feeds a Cholesky with condition ~1e3, so no fast exp here): bit-identical results.
+// nxb / nyb: the batch item's row / column norms.  Tails are bounds-checked (n = 1600 is not a multiple of the tile).
+template <int TM, int TN>
+__device__ __forceinline__ void epi_staged_cosk(const f32x16 (&acc)[TN][TM], const GemmArgs& a, float* Cb, const float* nxb,
+                                                const float* nyb, char* ws, long mw0, int nw0, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int nw = nw0 + tn * 32;
+    f32x4 nyv[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int n = nw + 8 * rg + 4 * h;
+      nyv[rg] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if (n + 3 < a.N) {
+        nyv[rg] = *reinterpret_cast<const f32x4*>(nyb + n);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < a.N) nyv[rg][j] = nyb[n + j];
+      }
+      epi_consume(nyv[rg]);
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const long mw = mw0 + tm * 32;
+      const long mrow = mw + l31;
+      const float nxm = mrow < a.M ? nxb[mrow] : 1.f;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int n = nw + 8 * rg + 4 * h;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float c = (a.alpha * acc[tn][tm][4 * rg + j]) / (nxm * nyv[rg][j] + 1e-6f);
+          float kk = expf((c - 1.0f) * a.inv_t);
+          if (a.diag_add != 0.f && mrow == n + j) kk += a.diag_add;
+          v[j] = kk;
+        }
+        *reinterpret_cast<f32x4*>(ws + l31 * 128 + (((2 * rg + h) ^ (l31 & 7)) << 4)) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        const int row = c >> 3, ch = c & 7;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ws + row * 128 + ((ch ^ (row & 7)) << 4));
+        const long m = mw + row;
+        const int n = nw + ch * 4;
+        if (m >= a.M || n >= a.N) continue;
+        if (a.dbg & 1) continue;
+        *reinterpret_cast<f32x4*>(Cb + m * a.ldc + n) = v;  // N % 4 == 0: whole pieces only
+      }
+    }
+  }
+}
+
 }  // namespace roma
