@@ -249,8 +249,13 @@ class RegressionMatcher:
             b_hr = _pil_to_normalised(im_B, self.upsample_res)[None].to(device)
         elif self.upsample_preds and im_A_high_res is not None and im_B_high_res is not None:
             a_hr, b_hr = im_A_high_res.to(device), im_B_high_res.to(device)
-            if tuple(a_hr.shape[-2:]) != tuple(self.upsample_res):
-                self.upsample_res = tuple(a_hr.shape[-2:])
+            # The reference never touches self.upsample_res: it sizes the attenuation map and the output grid from the
+            # attribute (matcher.py:836-838, 904-911) and the upsample pass from the tensors, so tensors of another size end
+            # in a RuntimeError (shape mismatch at matcher.py:891-894).  Same exception here, raised before any work.
+            if tuple(a_hr.shape[-2:]) != tuple(self.upsample_res) or tuple(b_hr.shape[-2:]) != tuple(self.upsample_res):
+                raise RuntimeError(f"im_A_high_res / im_B_high_res are {tuple(a_hr.shape[-2:])} / {tuple(b_hr.shape[-2:])} "
+                                   f"but upsample_res is {tuple(self.upsample_res)}: the size of the high-resolution "
+                                   "tensors must match upsample_res (set the attribute before calling match())")
         elif self.upsample_preds:
             raise ValueError(f"Invalid upsample_preds and high_res inputs with {im_A_high_res=} and {im_B_high_res=}")
         if device.index is not None and device.index != self.device.index:

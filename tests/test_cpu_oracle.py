@@ -289,6 +289,53 @@ def test_tiny_oracle_vs_reference_golden_xfeat_architecture():
         assert float((c - torch.from_numpy(g[tag + "_cert"])).abs().max()) < 1e-5
 
 
+def test_path_route_transforms_and_oracle_vs_reference_golden(weights0):
+    """SURVEY 8a row a2 on the CPU: the product's host-side transform (roma_amd.matcher._pil_to_normalised - PIL bicubic
+    resize, /255, ImageNet mean / std) is bit-identical to what the reference's get_tuple_transform_ops produced for the
+    demo pair at both resolutions (utils/utils.py:164-173, matcher.py:812-816, 858-868; tests/golden/match_path.npz), and
+    the oracle on those tensors reproduces the reference's own match(path, path)."""
+    from PIL import Image
+    from oracle import roma_oracle as O
+    from roma_amd.matcher import _check_input, _pil_to_normalised
+    sd, dsd = weights0
+    g = np.load(os.path.join(GOLDEN, "match_path.npz"))
+    ims = [_check_input(os.path.join(GOLDEN, n)) for n in ("pair_A.png", "pair_B.png")]
+    assert ims[0].size == (640, 480) and ims[1].size == (618, 640) and all(im.mode == "RGB" for im in ims)
+    for tag, coarse, up in (("sq", (112, 112), (168, 168)), ("rect", (112, 140), (168, 196))):
+        t = {}
+        for nm, res in (("coarse", coarse), ("up", up)):
+            for ab, im in zip("AB", ims):
+                t[nm + ab] = _pil_to_normalised(im, res)
+                assert t[nm + ab].dtype == torch.float32
+                assert np.array_equal(t[nm + ab].numpy(), g[f"{tag}_{nm}_{ab}"]), (tag, nm, ab)
+        if tag == "sq":
+            w, c = O.match(t["coarseA"][None], t["coarseB"][None], sd, dsd, t["upA"][None], t["upB"][None])
+            assert float((w - torch.from_numpy(g["sq_warp"])).abs().max()) == 0.0
+            assert float((c - torch.from_numpy(g["sq_cert"])).abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):  # utils.py:659-661
+        _check_input(Image.new("L", (8, 8)))
+
+
+def test_tiny_oracle_match_from_path_vs_reference_golden():
+    """BASELINE config 1 as the reference runs it: TinyRoMa.match(path, path) on the demo pair - A 480 x 640, B 640 x 618 ->
+    640 x 608, so forward() takes the different-size branch (tiny.py:288-290); tests/golden/tiny_path_reference.npz
+    (tools/make_goldens.py tinyroma_path; XFeat layer list with seeded weights)."""
+    from PIL import Image
+    from oracle import tiny_oracle as T
+    from roma_amd import synthetic
+    g = np.load(os.path.join(GOLDEN, "tiny_path_reference.npz"))
+    sd, xf = synthetic.make_tiny_state_dict(0), synthetic.XFeatArch(0)
+    to_t = lambda n: torch.from_numpy(np.array(Image.open(os.path.join(GOLDEN, n)).convert("RGB"))).permute(2, 0, 1).float().div(255)[None]  # noqa: E731
+    a, b = to_t("pair_A.png"), to_t("pair_B.png")
+    assert a.shape[-2:] == (480, 640) and b.shape[-2:] == (640, 618)
+    for tag, exact in (("p", False), ("pe", True)):
+        w, c = T.match(a, b, xf, sd, exact)
+        assert tuple(w.shape[1:]) == tuple(g[f"{tag}_shape"])
+        assert float((w[0, ::4, ::4] - torch.from_numpy(g[f"{tag}_warp_sub"])).abs().max()) < 1e-5
+        assert float((c[0, ::4, ::4] - torch.from_numpy(g[f"{tag}_cert_sub"])).abs().max()) < 1e-5
+        assert np.allclose(w[0].double().sum(dim=(1, 2)).float().numpy(), g[f"{tag}_warp_rowsum"], atol=2e-3)
+
+
 def test_oracle_visualize_warp_vs_reference_golden():
     """oracle.visualize_warp against RegressionMatcher.visualize_warp of the reference (matcher.py:936-986): symmetric
     warp with tensor images, and the one-directional form with an image of another resolution."""

@@ -312,7 +312,6 @@ def test_non_square_and_pil_inputs(built_lib, weights0, tmp_path):
     from PIL import Image
     from oracle import roma_oracle as O
     from roma_amd import roma_model, synthetic
-    from roma_amd.matcher import _pil_to_normalised
     sd, dsd = weights0
     m = roma_model((112, 168), True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=torch.float32,
                    symmetric=True, upsample_res=(160, 240), max_batch=1)
@@ -322,7 +321,7 @@ def test_non_square_and_pil_inputs(built_lib, weights0, tmp_path):
     w_ref, c_ref = O.match(inp["im_A"], inp["im_B"], sd, dsd, inp["im_A_high_res"], inp["im_B_high_res"])
     assert warp.shape == (1, 160, 480, 4)
     assert (warp.cpu() - w_ref).abs().max() < TOL and (cert.cpu() - c_ref).abs().max() < TOL
-    # PIL / path inputs: B = 1, bicubic resize + ImageNet normalisation on the host
+    # the PIL and the path route are one route (B = 1, _check_input; matcher.py:530-547)
     g = np.random.Generator(np.random.PCG64(3))
     ims = [Image.fromarray(g.integers(0, 255, size=(90, 130, 3), dtype=np.uint8), "RGB") for _ in range(2)]
     pa, pb = str(tmp_path / "a.png"), str(tmp_path / "b.png")
@@ -331,9 +330,46 @@ def test_non_square_and_pil_inputs(built_lib, weights0, tmp_path):
     w1, c1 = m.match(ims[0], ims[1])
     w2, c2 = m.match(pa, pb)
     assert torch.equal(w1, w2) and torch.equal(c1, c2)
-    a, b = _pil_to_normalised(ims[0], (112, 168))[None], _pil_to_normalised(ims[1], (112, 168))[None]
-    ah, bh = _pil_to_normalised(ims[0], (160, 240))[None], _pil_to_normalised(ims[1], (160, 240))[None]
-    w_ref, c_ref = O.match(a, b, sd, dsd, ah, bh)
-    assert (w1.cpu() - w_ref).abs().max() < TOL and (c1.cpu() - c_ref).abs().max() < TOL
     with pytest.raises(NotImplementedError):  # utils.py:659-661
         m.match(ims[0].convert("L"), ims[1])
+    # tensors whose high-resolution size is not upsample_res: the reference fails with a RuntimeError (shape mismatch,
+    # matcher.py:891-894) and never rewrites the attribute - neither do we
+    bad = _to_dev(synthetic.make_inputs(1, (112, 168), (168, 252), seed=5))
+    with pytest.raises(RuntimeError):
+        m.match(d["im_A"], d["im_B"], im_A_high_res=bad["im_A_high_res"], im_B_high_res=bad["im_B_high_res"])
+    assert tuple(m.upsample_res) == (160, 240)
+
+
+@pytest.mark.parametrize("tag,coarse,up", [("sq", (112, 112), (168, 168)), ("rect", (112, 140), (168, 196))])
+def test_match_from_paths_vs_reference_golden(built_lib, weights0, tag, coarse, up):
+    """SURVEY 8a row a2, pinned on the REFERENCE: tests/golden/match_path.npz holds the unmodified reference's own
+    match(path, path) on the demo pair (tests/golden/pair_{A,B}.png = the decoded pixels of assets/sacre_coeur_{A,B}.jpg;
+    tools/make_goldens.py assets / match_path): _check_input, the coarse transform (matcher.py:806-816), the second transform
+    at the upsample resolution (matcher.py:853-868), B = 1.  f32 at the north-star tolerance; the PIL route gives the same
+    bits as the path route; `upsample_preds = False` afterwards (a mutable attribute, README.md:82-90) gives the reference's
+    coarse-only result from the same paths."""
+    from PIL import Image
+    from roma_amd import roma_model
+    sd, dsd = weights0
+    g = np.load(os.path.join(GOLDEN, "match_path.npz"))
+    pa, pb = os.path.join(GOLDEN, "pair_A.png"), os.path.join(GOLDEN, "pair_B.png")
+    m = roma_model(coarse, True, device="cuda:0", weights=sd, dinov2_weights=dsd, amp_dtype=torch.float32,
+                   symmetric=True, upsample_res=up, max_batch=1)
+    warp, cert = m.match(pa, pb)
+    torch.cuda.synchronize()
+    assert tuple(warp.shape) == g[f"{tag}_warp"].shape and tuple(cert.shape) == g[f"{tag}_cert"].shape
+    dw = np.abs(warp.cpu().numpy() - g[f"{tag}_warp"]).max()
+    dc = np.abs(cert.cpu().numpy() - g[f"{tag}_cert"]).max()
+    print(f"match(path, path) {tag}: max|dwarp|={dw:.3e} max|dcert|={dc:.3e}")
+    assert dw < TOL and dc < TOL
+    w2, c2 = m.match(Image.open(pa).convert("RGB"), Image.open(pb).convert("RGB"))
+    assert torch.equal(warp, w2) and torch.equal(cert, c2)
+    from pathlib import Path
+    w3, _ = m.match(Path(pa), Path(pb))  # os.PathLike as well as str
+    assert torch.equal(warp, w3)
+    if tag == "sq":
+        m.upsample_preds = False
+        wc, cc = m.match(pa, pb)
+        assert tuple(wc.shape) == g["sq_coarse_only_warp"].shape
+        assert np.abs(wc.cpu().numpy() - g["sq_coarse_only_warp"]).max() < TOL
+        assert np.abs(cc.cpu().numpy() - g["sq_coarse_only_cert"]).max() < TOL

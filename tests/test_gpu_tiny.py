@@ -107,6 +107,28 @@ def test_tiny_match_demo_size(built_lib):
     assert dw < TOL and dc < TOL
 
 
+@pytest.mark.parametrize("tag,exact", [("p", False), ("pe", True)])
+def test_tiny_match_from_path_on_the_demo_pair(built_lib, tag, exact):
+    """BASELINE config 1 as the reference runs it: match(path, path) -> match_from_path (tiny.py:193-198) on the demo pair
+    (tests/golden/pair_{A,B}.png = the decoded pixels of assets/sacre_coeur_{A,B}.jpg).  A is 480 x 640, B is 640 x 618 ->
+    640 x 608: the two images go through forward_single separately (tiny.py:288-290), the correlation volume is 4 800 x 6 080.
+    Against the reference's own run (tests/golden/tiny_path_reference.npz: 1/4 sub-sample + per-row sums of the full output)."""
+    from roma_amd import TinyRoMa, synthetic
+    g = np.load(os.path.join(GOLDEN, "tiny_path_reference.npz"))
+    m = TinyRoMa(xfeat=synthetic.XFeatArch(0), weights=synthetic.make_tiny_state_dict(0), device="cuda:0", exact_softmax=exact)
+    pa, pb = os.path.join(GOLDEN, "pair_A.png"), os.path.join(GOLDEN, "pair_B.png")
+    warp, cert = m.match(pa, pb)  # str -> match_from_path -> un-batched outputs
+    assert tuple(warp.shape) == tuple(g[f"{tag}_shape"]) == (480, 640, 4) and tuple(cert.shape) == (480, 640)
+    dw = float((warp[::4, ::4].cpu() - torch.from_numpy(g[f"{tag}_warp_sub"])).abs().max())
+    dc = float((cert[::4, ::4].cpu() - torch.from_numpy(g[f"{tag}_cert_sub"])).abs().max())
+    rs = float((warp.double().sum(dim=(0 + 1, 2)).float().cpu() - torch.from_numpy(g[f"{tag}_warp_rowsum"])).abs().max())
+    print(f"tiny match(path, path) {tag}: max|dwarp| = {dw:.2e}, max|dcert| = {dc:.2e}, max|d row sum| = {rs:.2e}")
+    assert dw < TOL and dc < TOL and rs < 640 * 4 * TOL
+    from pathlib import Path
+    w2, c2 = m.match(Path(pa), Path(pb))
+    assert torch.equal(warp, w2) and torch.equal(cert, c2)
+
+
 def test_tiny_rejects_cpu_and_missing_backbone(built_lib):
     from roma_amd import TinyRoMa, synthetic, tiny_roma_v1_outdoor
     with pytest.raises(Exception):

@@ -20,6 +20,9 @@ fixtures are what travels to the GPU box.  Usage:
     python tools/make_goldens.py vis           # RegressionMatcher.visualize_warp on a seeded warp + images
     python tools/make_goldens.py tinyroma      # TinyRoMa.match / forward with the seeded stand-in XFeat backbone
     python tools/make_goldens.py tinyroma_xfeat  # the same with a backbone of the real XFeat architecture; exact_softmax=True
+    python tools/make_goldens.py assets        # tests/golden/pair_{A,B}.png: the decoded pixels of assets/sacre_coeur_{A,B}.jpg
+    python tools/make_goldens.py match_path    # RegressionMatcher.match(path, path) / match(PIL, PIL): the transform route
+    python tools/make_goldens.py tinyroma_path # TinyRoMa.match(path, path) on the asset pair (A and B of different sizes)
 """
 import json
 import os
@@ -445,6 +448,79 @@ def tinyroma_xfeat_golden():
     print("tiny_xfeat_reference.npz", {k: v.shape for k, v in out.items()})
 
 
+ASSET_PAIR = ("sacre_coeur_A.jpg", "sacre_coeur_B.jpg")  # BASELINE config 1's pair: 640 x 480 and 618 x 640 (W x H), RGB
+
+
+def assets_golden():
+    """tests/golden/pair_A.png / pair_B.png: the decoded RGB pixels of the reference's demo pair (assets/sacre_coeur_*.jpg),
+    stored lossless so that the GPU box - which has no /root/reference - opens bit-identical pixels through the same
+    `Image.open(path).convert("RGB")` the reference's path route starts with (matcher.py:530-547)."""
+    from PIL import Image
+    for src, dst in zip(ASSET_PAIR, ("pair_A.png", "pair_B.png")):
+        im = Image.open(os.path.join("/root/reference/assets", src)).convert("RGB")
+        im.save(os.path.join(GOLD, dst), optimize=True)
+        back = np.array(Image.open(os.path.join(GOLD, dst)).convert("RGB"))
+        assert np.array_equal(back, np.array(im)), "PNG round trip must be lossless"
+        print(dst, im.size, os.path.getsize(os.path.join(GOLD, dst)) // 1024, "KiB")
+
+
+def match_path_golden():
+    """The reference's OWN match(path, path) (matcher.py:806-816 coarse transform, 853-868 upsample transform, B = 1,
+    _check_input) and match(PIL, PIL) on the demo pair, seeded weights, 112 -> 168 (cheap on CPU; the transform route is
+    resolution independent), plus a non-square configuration 112 x 140 -> 168 x 196 and a coarse-only run.  Stored: the
+    normalised tensors the reference's transforms produced (get_tuple_transform_ops, utils/utils.py:164-173) - the product's
+    _pil_to_normalised is held to them bit for bit on CPU - and warp / certainty."""
+    install_stubs()
+    from PIL import Image
+    from romatch.utils.utils import get_tuple_transform_ops
+    pa, pb = (os.path.join(GOLD, n) for n in ("pair_A.png", "pair_B.png"))
+    sd, dsd = synthetic.make_matcher_state_dict(0), synthetic.make_dinov2_state_dict(0)
+    out = {}
+    for tag, coarse, up in (("sq", (112, 112), (168, 168)), ("rect", (112, 140), (168, 196))):
+        m = build_reference_matcher(sd, dsd, coarse, up, symmetric=True, upsample_preds=True)
+        ims = (Image.open(pa).convert("RGB"), Image.open(pb).convert("RGB"))
+        for nm, res in (("coarse", coarse), ("up", up)):
+            ta, tb = get_tuple_transform_ops(resize=res, normalize=True)(ims)
+            out[f"{tag}_{nm}_A"], out[f"{tag}_{nm}_B"] = np32(ta), np32(tb)
+        t = time.time()
+        warp, cert = m.match(pa, pb)
+        print(f"match_path {tag}: {time.time() - t:.1f}s", tuple(warp.shape), tuple(cert.shape))
+        warp2, cert2 = m.match(*ims)  # the PIL route: same transforms, must be the same result
+        assert torch.equal(warp, warp2) and torch.equal(cert, cert2)
+        out[f"{tag}_warp"], out[f"{tag}_cert"] = np32(warp), np32(cert)
+        if tag == "sq":
+            m.upsample_preds = False  # mutable attribute (README.md:82-90): coarse-only from paths
+            warp, cert = m.match(pa, pb)
+            out["sq_coarse_only_warp"], out["sq_coarse_only_cert"] = np32(warp), np32(cert)
+    np.savez_compressed(os.path.join(GOLD, "match_path.npz"), **out)
+    print("match_path.npz", {k: v.shape for k, v in out.items()})
+
+
+def tinyroma_path_golden():
+    """BASELINE config 1 as the reference runs it: TinyRoMa.match(path, path) -> match_from_path (tiny.py:193-198: ToTensor,
+    no resize, no normalisation) on the demo pair.  A is 480 x 640, B is 640 x 618 -> 640 x 608 after preprocess_tensor, so
+    forward() takes the separate forward_single branch (tiny.py:288-290).  Backbone: the real XFeat layer list with seeded
+    weights (roma_amd.synthetic.XFeatArch; the hub checkpoint is unobtainable offline).  Outputs 1/4 sub-sampled."""
+    install_stubs()
+    from romatch.models.tiny import TinyRoMa
+    pa, pb = (os.path.join(GOLD, n) for n in ("pair_A.png", "pair_B.png"))
+    sd = synthetic.make_tiny_state_dict(0)
+    out = {}
+    for tag, exact in (("p", False), ("pe", True)):
+        model = TinyRoMa(xfeat=synthetic.XFeatArch(0), freeze_xfeat=True, exact_softmax=exact)
+        model.load_state_dict(sd, strict=True)
+        model.train(False)
+        with torch.inference_mode():
+            warp, cert = model.match(pa, pb)  # str -> match_from_path -> batched=False
+        assert warp.dim() == 3 and cert.dim() == 2
+        out[f"{tag}_shape"] = np.array(warp.shape)
+        out[f"{tag}_warp_sub"], out[f"{tag}_cert_sub"] = np32(warp[::4, ::4]), np32(cert[::4, ::4])
+        out[f"{tag}_warp_rowsum"] = np32(warp.double().sum(dim=(1, 2)).float())
+        out[f"{tag}_cert_rowsum"] = np32(cert.double().sum(dim=1).float())
+    np.savez_compressed(os.path.join(GOLD, "tiny_path_reference.npz"), **out)
+    print("tiny_path_reference.npz", {k: v.shape for k, v in out.items()})
+
+
 def vis_golden():
     """Reference RegressionMatcher.visualize_warp (matcher.py:936-986) on a seeded smooth symmetric warp, tensor images
     of the warp's resolution, and the non-symmetric form with images of a different resolution."""
@@ -471,4 +547,4 @@ def vis_golden():
 
 if __name__ == "__main__":
     for what in sys.argv[1:]:
-        {"contract": contract, "ops": ops, "ops_nearest": ops_nearest, "tiny": tiny, "small": small, "full": full, "odd": odd, "mega": mega, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden, "keypoints_ties": keypoints_ties_golden, "vis": vis_golden, "tinyroma": tinyroma_golden, "tinyroma_xfeat": tinyroma_xfeat_golden}[what]()
+        {"contract": contract, "ops": ops, "ops_nearest": ops_nearest, "tiny": tiny, "small": small, "full": full, "odd": odd, "mega": mega, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden, "keypoints_ties": keypoints_ties_golden, "vis": vis_golden, "tinyroma": tinyroma_golden, "tinyroma_xfeat": tinyroma_xfeat_golden, "assets": assets_golden, "match_path": match_path_golden, "tinyroma_path": tinyroma_path_golden}[what]()

@@ -6,9 +6,12 @@ smoke() may import this module.
 The image lacks cv2 / loguru / torchvision, which the reference imports at module
 top (romatch/utils/utils.py:3,6-7, romatch/models/encoders.py:3,
 romatch/models/model_zoo/roma_models.py:7).  We register stub modules that
-contribute NO arithmetic except the VGG19-BN *layer list* (cfg "E" of torchvision:
-Conv3x3(pad 1)+BatchNorm2d+ReLU / MaxPool2d(2,2)), which the reference slices as
-`features[:40]` (encoders.py:13).  All arithmetic is the reference's own code.
+contribute NO arithmetic to the tensor route except the VGG19-BN *layer list* (cfg "E" of
+torchvision: Conv3x3(pad 1)+BatchNorm2d+ReLU / MaxPool2d(2,2)), which the reference slices as
+`features[:40]` (encoders.py:13).  For the path / PIL route the three torchvision transforms
+the reference calls (Resize on a PIL image, ToTensor, Normalize) are restated from
+torchvision's published definitions (round 5; see install_stubs).  Everything else is the
+reference's own code.
 """
 import sys
 import types
@@ -73,14 +76,49 @@ def install_stubs():
 
     tvtf.InterpolationMode = InterpolationMode
 
-    class _Placeholder:
-        def __init__(self, *a, **k):
-            pass
+    # Path / PIL inputs (matcher.py:806-816, 853-868; tiny.py:193-198) go through three torchvision transforms.  torchvision
+    # is absent, so the stubs restate what the pinned torchvision does for a PIL input - nothing of the reference itself:
+    #   Resize(size, BICUBIC)(pil)  = pil.resize(size[::-1], PIL.Image.BICUBIC)      (transforms/_functional_pil.py resize)
+    #   ToTensor()(pil)             = uint8 HWC -> CHW, .to(float32).div(255)        (transforms/functional.py to_tensor)
+    #   Normalize(mean, std)(t)     = (t - mean[:, None, None]) / std[:, None, None] (functional.py normalize, float32)
+    class Resize:
+        def __init__(self, size, interpolation=InterpolationMode.BILINEAR, *a, **k):
+            self.size = (size, size) if isinstance(size, int) else tuple(size)
+            self.interpolation = interpolation
+
+        def __call__(self, im):
+            from PIL import Image
+            assert isinstance(im, Image.Image), "Resize stub: PIL input only (the path / PIL route of match())"
+            mode = {InterpolationMode.BICUBIC: Image.BICUBIC, InterpolationMode.BILINEAR: Image.BILINEAR}[self.interpolation]
+            return im.resize((self.size[1], self.size[0]), mode)
+
+    class Normalize:
+        def __init__(self, mean, std, inplace=False):
+            self.mean, self.std = mean, std
+
+        def __call__(self, t):
+            mean = torch.as_tensor(self.mean, dtype=t.dtype)[:, None, None]
+            std = torch.as_tensor(self.std, dtype=t.dtype)[:, None, None]
+            return (t.clone() - mean) / std
+
+    class ToTensor:
+        def __call__(self, im):
+            import numpy as np
+            a = torch.from_numpy(np.array(im, dtype=np.uint8, copy=True))
+            if a.dim() == 2:
+                a = a[:, :, None]
+            return a.permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
 
         def __call__(self, x):
-            raise NotImplementedError("torchvision transform placeholder (path/PIL inputs are not used by the goldens)")
+            for t in self.ts:
+                x = t(x)
+            return x
 
-    tvt.Resize = tvt.Normalize = tvt.ToTensor = tvt.Compose = _Placeholder
+    tvt.Resize, tvt.Normalize, tvt.ToTensor, tvt.Compose = Resize, Normalize, ToTensor, Compose
     tvt.functional = tvtf
     tv.models = tvm
     tv.transforms = tvt
