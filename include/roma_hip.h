@@ -5,6 +5,7 @@
  *                                                 -> roma_create / roma_set_tensor / roma_finalize
  *   - romatch/models/model_zoo/roma_models.py:204 strict load_state_dict       -> roma_set_tensor + roma_finalize
  *   - romatch/models/matcher.py:779-934           RegressionMatcher.match()    -> roma_match
+ *   - romatch/models/matcher.py:585-596, 631-670  forward / forward_symmetric / extract_backbone_features -> roma_forward
  *   - romatch/utils/local_correlation.py:22-35    local_corr.local_corr(...) (external fused-local-corr wheel)
  *                                                 -> roma_op_local_corr (plugin signature),
  *                                                    roma_op_local_corr_window (what local_correlation():77-143 needs)
@@ -110,6 +111,29 @@ int roma_set_option_f(roma_handle_t h, const char* key, double value);
  * upsample_preds == 0.  warp_out: [B,Ho,2*Wo,4] (symmetric) or [B,Ho,Wo,4]; cert_out: [B,Ho,2*Wo] / [B,Ho,Wo]. */
 int roma_match(roma_handle_t h, int B, const float* im_a, const float* im_b, const float* im_a_hr,
                const float* im_b_hr, float* warp_out, float* cert_out, void* stream);
+/* ONE decoder pass with its per-scale correspondences exposed: RegressionMatcher.forward / forward_symmetric in eval mode
+ * (matcher.py:631-670 -> Decoder.forward, matcher.py:395-527: corresps[s] = {"flow", "certainty"} for s = 16, 8, 4, 2, 1) and
+ * extract_backbone_features (matcher.py:585-596).  upsample = 0: the coarse pass over images at the handle's coarse resolution
+ * (scales 16 .. 1); upsample = 1: the upsample pass (matcher.py:870-889: scales 8 .. 1, no DINOv2 / GP) over images at the
+ * handle's upsample resolution, seeded with batch["corresps"] = (seed_flow, seed_cert) of ANY resolution, which Decoder.forward
+ * resizes bilinearly to the stride-8 grid (matcher.py:423-435).  symmetric selects forward_symmetric (decoder batch Bd = 2B:
+ * A->B then B->A) or forward (Bd = B).  Outputs are channels-last f32, the caller permutes: flow[i] [Bd, h_s, w_s, 2] (x, y),
+ * cert[i] [Bd, h_s, w_s] logits, i = 0 .. 4 for s = 16, 8, 4, 2, 1 (h_16 = H / 14, h_s = H / s otherwise); any pointer may be
+ * NULL (that output is skipped; index 0 is ignored in an upsample pass).  feat[i]: the two images' feature pyramid
+ * [2B, h_s, w_s, C_s] (C = 1024, 512, 256, 128, 64) in the handle's activation type (f32, or the library's 16-bit format).
+ * Runs on the caller's stream, one sub-batch (no stream split); B <= max_batch. */
+typedef struct {
+  int upsample;
+  int symmetric;
+  double scale_factor;      /* ConvRefiner displacement scale (matcher.py:805, 877-881); forward()'s default is 1 */
+  const float* seed_flow;   /* upsample pass only: [Bd, seed_h, seed_w, 2] f32 */
+  const float* seed_cert;   /* [Bd, seed_h, seed_w] f32 logits */
+  int seed_h, seed_w;
+  float* flow[5];
+  float* cert[5];
+  void* feat[5];
+} roma_forward_args_t;
+int roma_forward(roma_handle_t h, int B, const float* im_a, const float* im_b, const roma_forward_args_t* a, void* stream);
 /* debug stage capture (enabled by roma_set_option(h,"debug",1)): copies a named intermediate to HOST memory.
  * Returns the number of bytes available when dst == NULL. */
 long roma_debug_fetch(roma_handle_t h, const char* name, void* dst_host, long nbytes);

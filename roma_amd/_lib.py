@@ -26,6 +26,13 @@ class RomaConfig(C.Structure):
                 ("precision", C.c_int), ("max_batch", C.c_int), ("device", C.c_int)]
 
 
+class RomaForwardArgs(C.Structure):
+    """roma_forward_args_t (include/roma_hip.h)"""
+    _fields_ = [("upsample", C.c_int), ("symmetric", C.c_int), ("scale_factor", C.c_double),
+                ("seed_flow", C.c_void_p), ("seed_cert", C.c_void_p), ("seed_h", C.c_int), ("seed_w", C.c_int),
+                ("flow", C.c_void_p * 5), ("cert", C.c_void_p * 5), ("feat", C.c_void_p * 5)]
+
+
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 # symbol -> (restype, argtypes); mirrors include/roma_hip.h one to one
@@ -39,6 +46,7 @@ SIGNATURES = {
     "roma_set_option": (_i, [_vp, C.c_char_p, _i]),
     "roma_set_option_f": (_i, [_vp, C.c_char_p, C.c_double]),
     "roma_match": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "roma_forward": (_i, [_vp, _i, _vp, _vp, C.POINTER(RomaForwardArgs), _vp]),
     "roma_debug_fetch": (_l, [_vp, C.c_char_p, _vp, _l]),
     "roma_debug_trace": (_l, [_vp, _i, _vp, _l, C.c_char_p, _l]),
     "roma_debug_inject": (_i, [_vp, C.c_char_p, _vp, _l]),

@@ -163,6 +163,11 @@ int roma_match(roma_handle_t h, int B, const float* im_a, const float* im_b, con
   return h->m.match(B, im_a, im_b, im_a_hr, im_b_hr, warp_out, cert_out, S(stream));
 }
 
+int roma_forward(roma_handle_t h, int B, const float* im_a, const float* im_b, const roma_forward_args_t* a, void* stream) {
+  ROMA_REQUIRE(h, "roma_forward: null handle");
+  return h->m.forward(B, im_a, im_b, a, S(stream));
+}
+
 long roma_debug_fetch(roma_handle_t h, const char* name, void* dst_host, long nbytes) {
   if (!h || !name) return ROMA_ERR_ARG;
   auto it = h->m.dbg.find(name);

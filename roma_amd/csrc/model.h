@@ -136,6 +136,7 @@ class Model {
   int finalize();
   int match(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
             float* cert, hipStream_t st);
+  int forward(int B, const float* ima, const float* imb, const roma_forward_args_t* fw, hipStream_t st);
 
  private:
   int ensure_side_streams(int n);
@@ -144,8 +145,9 @@ class Model {
   int check_contract();
   int pack_weights();
   int load_peer();
+  // fw != nullptr: ONE pass (roma_forward) - per-scale outputs copied out, no epilogue
   int match_impl(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
-                 float* cert, hipStream_t st, bool dry, Arena& arena, Arena& persist);
+                 float* cert, hipStream_t st, bool dry, Arena& arena, Arena& persist, const roma_forward_args_t* fw = nullptr);
   int dbg_save(const char* name, const void* p, size_t bytes, hipStream_t st);
   template <typename F> int upload_f32(const std::vector<float>& v, F** out);
   int upload_act(const std::vector<float>& v, void** out);

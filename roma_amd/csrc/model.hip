@@ -561,6 +561,19 @@ int Model::match(int B, const float* ima, const float* imb, const float* ima_hr,
   return match_streams(B, ima, imb, ima_hr, imb_hr, warp, cert, st);
 }
 
+int Model::forward(int B, const float* ima, const float* imb, const roma_forward_args_t* fw, hipStream_t st) {
+  ROMA_REQUIRE(finalized, "roma_forward: call roma_finalize first");
+  ROMA_REQUIRE(B >= 1 && B <= cfg.max_batch, "roma_forward: batch size out of range (max_batch)");
+  ROMA_REQUIRE(ima && imb && fw, "roma_forward: null image / argument pointer");
+  if (fw->upsample) {
+    ROMA_REQUIRE(cfg.upsample_h > 0, "roma_forward: upsample pass on a handle without an upsample resolution");
+    ROMA_REQUIRE(fw->seed_flow && fw->seed_cert && fw->seed_h > 0 && fw->seed_w > 0,
+                 "roma_forward: the upsample pass needs batch[\"corresps\"] (seed_flow / seed_cert)");
+  }
+  ROMA_CHECK_HIP(hipSetDevice(cfg.device));
+  return match_impl(B, ima, imb, nullptr, nullptr, nullptr, nullptr, st, false, arena, persist, fw);
+}
+
 int Model::match_streams(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr, float* warp,
                          float* cert, hipStream_t st) {
   static const int env_streams = getenv("ROMA_STREAMS") ? atoi(getenv("ROMA_STREAMS")) : 0;
@@ -791,10 +804,12 @@ int gp_posterior(const void* pf, long ldf, int act_dt, int B, bool symmetric, in
   } while (0)
 
 int Model::match_impl(int B, const float* ima, const float* imb, const float* ima_hr, const float* imb_hr,
-                      float* warp_out, float* cert_out, hipStream_t st, bool dry, Arena& arena, Arena& persist) {
+                      float* warp_out, float* cert_out, hipStream_t st, bool dry, Arena& arena, Arena& persist,
+                      const roma_forward_args_t* fw) {
   const size_t esz = act_dt == DT_F32 ? 4 : 2;
   const int nimg = 2 * B;
-  const int ndp = cfg.symmetric ? 2 * B : B;
+  const bool sym = fw ? fw->symmetric != 0 : cfg.symmetric != 0;
+  const int ndp = sym ? 2 * B : B;
   const int shift = B;  // support image of directed pair i = (i + B) % nimg
   arena.reset();
   persist.reset();
@@ -852,17 +867,18 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
     return 0;
   };
 
-  for (int pass = 0; pass < (cfg.upsample_preds ? 2 : 1); ++pass) {
+  const int pass0 = fw ? (fw->upsample ? 1 : 0) : 0, pass1 = fw ? pass0 + 1 : (cfg.upsample_preds ? 2 : 1);
+  for (int pass = pass0; pass < pass1; ++pass) {
     const bool up = pass == 1;
     const int H = up ? cfg.upsample_h : cfg.coarse_h, W = up ? cfg.upsample_w : cfg.coarse_w;
-    const float* imA = up ? ima_hr : ima;
-    const float* imB = up ? imb_hr : imb;
+    const float* imA = (up && !fw) ? ima_hr : ima;  // roma_forward hands the pass's own images over as im_a / im_b
+    const float* imB = (up && !fw) ? imb_hr : imb;
     const size_t pass_mark = arena.mark();
     // =============================== encoder: VGG19-BN pyramid (encoders.py:17-27)
     void* feat[5] = {nullptr};  // index by log2(stride): 0 -> stride 1 ... 3 -> stride 8 ; [4] = stride 16 (DINOv2)
-    const int fh[4] = {H, H / 2, H / 4, H / 8}, fw[4] = {W, W / 2, W / 4, W / 8};
+    const int fh[4] = {H, H / 2, H / 4, H / 8}, fw_[4] = {W, W / 2, W / 4, W / 8};
     const int fc[4] = {64, 128, 256, 512};
-    for (int l = 0; l < 4; ++l) feat[l] = AL((size_t)nimg * fh[l] * fw[l] * fc[l], esz);
+    for (int l = 0; l < 4; ++l) feat[l] = AL((size_t)nimg * fh[l] * fw_[l] * fc[l], esz);
     {
       const size_t enc_mark = arena.mark();
       void* t0 = AL((size_t)nimg * H * W * 64, esz);
@@ -907,11 +923,15 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       arena.release(enc_mark);
     }
     for (int l = 0; l < 4; ++l)
-      if (int rc = CK((up ? "p2_feat" : "p1_feat") + std::to_string(1 << l), feat[l], (size_t)nimg * fh[l] * fw[l] * fc[l] * esz)) return rc;
+      if (int rc = CK((up ? "p2_feat" : "p1_feat") + std::to_string(1 << l), feat[l], (size_t)nimg * fh[l] * fw_[l] * fc[l] * esz)) return rc;
+    if (fw && !dry)  // extract_backbone_features (matcher.py:585-596): fw->feat[] is ordered 16, 8, 4, 2, 1
+      for (int l = 0; l < 4; ++l)
+        if (fw->feat[4 - l])
+          ROMA_CHECK_HIP(hipMemcpyAsync(fw->feat[4 - l], feat[l], (size_t)nimg * fh[l] * fw_[l] * fc[l] * esz, hipMemcpyDeviceToDevice, st));
     if (debug && !dry && !up) {
       for (int l = 0; l < 4; ++l) {
         const std::string nm = "feat" + std::to_string(1 << l);
-        if (int rc = dbg_save(nm.c_str(), feat[l], (size_t)nimg * fh[l] * fw[l] * fc[l] * esz, st)) return rc;
+        if (int rc = dbg_save(nm.c_str(), feat[l], (size_t)nimg * fh[l] * fw_[l] * fc[l] * esz, st)) return rc;
       }
     }
     // shared transformer scratch (DINOv2 rows >= decoder rows)
@@ -964,6 +984,8 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       if (int rc = CK("feat16", feat[4], (size_t)nimg * T * 1024 * esz)) return rc;
       if (debug && !dry)
         if (int rc = dbg_save("feat16", feat[4], (size_t)nimg * T * 1024 * esz, st)) return rc;
+      if (fw && !dry && fw->feat[0])
+        ROMA_CHECK_HIP(hipMemcpyAsync(fw->feat[0], feat[4], (size_t)nimg * T * 1024 * esz, hipMemcpyDeviceToDevice, st));
     }
 
     // =============================== decoder (matcher.py:395-527)
@@ -975,11 +997,17 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
     int ch = 0, cw = 0;  // current flow map size
     if (up) {
       ch = H / 8; cw = W / 8;
-      RUN(resize_bilinear_launch(flow_p1, flow, ndp, cfg.coarse_h, cfg.coarse_w, ch, cw, 2, st));
-      RUN(resize_bilinear_launch(cert_p1, cert, ndp, cfg.coarse_h, cfg.coarse_w, ch, cw, 1, st));
+      if (fw) {  // batch["corresps"] of the caller, any resolution (matcher.py:423-435)
+        RUN(resize_bilinear_launch(fw->seed_flow, flow, ndp, fw->seed_h, fw->seed_w, ch, cw, 2, st));
+        RUN(resize_bilinear_launch(fw->seed_cert, cert, ndp, fw->seed_h, fw->seed_w, ch, cw, 1, st));
+      } else {
+        RUN(resize_bilinear_launch(flow_p1, flow, ndp, cfg.coarse_h, cfg.coarse_w, ch, cw, 2, st));
+        RUN(resize_bilinear_launch(cert_p1, cert, ndp, cfg.coarse_h, cfg.coarse_w, ch, cw, 1, st));
+      }
     }
     double scale_factor = sqrt((double)H * (double)W / (560.0 * 560.0));  // matcher.py:805, 877-881
     if (!up && coarse_scale_factor > 0.0) scale_factor = coarse_scale_factor;
+    if (fw && fw->scale_factor > 0.0) scale_factor = fw->scale_factor;
     for (int si = up ? 1 : 0; si < 5; ++si) {
       const int ins = SCALE_INT[si];
       const int hs = ins == 16 ? th : H / ins, ws = ins == 16 ? tw : W / ins;
@@ -1005,7 +1033,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         const size_t gmark = arena.mark();
         float* tokens = (float*)AL((size_t)rows_t * 1024, 4);
         const size_t gmark2 = arena.mark();
-        if (int rc = gp_posterior(pf, ldf, act_dt, B, cfg.symmetric != 0, th, tw, gp_w, gp_b, tokens, 1024, arena, st, dry)) return rc;
+        if (int rc = gp_posterior(pf, ldf, act_dt, B, sym, th, tw, gp_w, gp_b, tokens, 1024, arena, st, dry)) return rc;
         arena.release(gmark2);
         RUN(copy2d_launch(pf, ldf, act_dt, tokens + 512, 1024, DT_F32, rows_t, 512, st));
         if (debug && !dry)
@@ -1133,6 +1161,10 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         if (int rc = dbg_save((pfx + "_flow" + SCALES[si]).c_str(), flow, (size_t)ndp * hw * 2 * 4, st)) return rc;
         if (int rc = dbg_save((pfx + "_cert" + SCALES[si]).c_str(), cert, (size_t)ndp * hw * 4, st)) return rc;
       }
+      if (fw && !dry) {  // corresps[ins] = {"flow", "certainty"} (matcher.py:496-512), before the resize to the next scale
+        if (fw->flow[si]) ROMA_CHECK_HIP(hipMemcpyAsync(fw->flow[si], flow, (size_t)ndp * hw * 2 * 4, hipMemcpyDeviceToDevice, st));
+        if (fw->cert[si]) ROMA_CHECK_HIP(hipMemcpyAsync(fw->cert[si], cert, (size_t)ndp * hw * 4, hipMemcpyDeviceToDevice, st));
+      }
       if (ins == 16 && !dry)
         ROMA_CHECK_HIP(hipMemcpyAsync(cert16_keep, cert, (size_t)ndp * hw * 4, hipMemcpyDeviceToDevice, st));
       arena.release(smark);
@@ -1156,6 +1188,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
     }
     arena.release(pass_mark);
   }
+  if (fw) return 0;
   // =============================== epilogue (matcher.py:839-850, 891-929)
   FinalArgs fa;
   fa.flow = cfg.upsample_preds ? flow_fin : flow_p1;

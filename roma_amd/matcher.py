@@ -283,6 +283,93 @@ class RegressionMatcher:
                                           ptr(warp), ptr(cert), C.c_void_p(stream)))
         return warp, cert
 
+    # ------------------------------------------------------------------ forward / forward_symmetric / backbone features
+    _SCALES = (16, 8, 4, 2, 1)
+    _FEAT_C = {16: 1024, 8: 512, 4: 256, 2: 128, 1: 64}
+
+    def _scale_hw(self, H, W, s):
+        return (H // 14, W // 14) if s == 16 else (H // s, W // s)
+
+    def _act_torch_dtype(self):
+        if self.amp_dtype == torch.float32:
+            return torch.float32
+        return torch.float16 if self._lib.h16 == "f16" else torch.bfloat16
+
+    @torch.inference_mode()
+    def _forward_pass(self, batch, symmetric, upsample, scale_factor, want_corresps=True, want_feats=False):
+        """One roma_forward call: the decoder pass of matcher.py:631-670 (and / or the feature pyramid of :585-596)."""
+        im_A, im_B = batch["im_A"], batch["im_B"]
+        if not (isinstance(im_A, torch.Tensor) and isinstance(im_B, torch.Tensor)) or not im_A.is_cuda:
+            raise _lib.RomaHipError("roma_amd.forward needs CUDA/HIP tensors; there is no CPU fallback")
+        b, c, H, W = im_A.shape
+        assert tuple(im_B.shape) == tuple(im_A.shape), "For batched images we assume same size"
+        dev = im_A.device
+        if upsample:
+            if (H, W) != tuple(self.upsample_res):
+                raise RuntimeError(f"forward(upsample=True): images are {(H, W)} but upsample_res is {tuple(self.upsample_res)}")
+            keep = self.upsample_preds
+            self.upsample_preds = True  # the handle must be planned for the upsample pass
+            try:
+                self._ensure_handle()
+            finally:
+                self.upsample_preds = keep
+        else:
+            self._ensure_handle((H, W) if (H, W) != (self.h_resized, self.w_resized) else None)
+        if b > self.max_batch:
+            raise ValueError(f"forward: batch {b} > max_batch {self.max_batch}")
+        lib = self._lib
+        for k in ("debug", "vit_bf16_residual", "trace"):
+            _lib.check(lib.roma_set_option(self._handle, k.encode(), int(bool(getattr(self, k)))), lib=lib)
+        bd = 2 * b if symmetric else b
+        fa = _lib.RomaForwardArgs()
+        fa.upsample, fa.symmetric, fa.scale_factor = int(bool(upsample)), int(bool(symmetric)), float(scale_factor)
+        keepalive = []
+        if upsample:
+            cor = batch.get("corresps")
+            if cor is None and want_corresps:
+                raise ValueError("forward(upsample=True) needs batch['corresps'] = {'flow', 'certainty'} (matcher.py:653-657)")
+            if cor is None:  # feature pyramid only: the decoder pass still runs (one schedule), on a zero seed
+                cor = {"flow": torch.zeros((bd, 2, 1, 1), device=dev), "certainty": torch.zeros((bd, 1, 1, 1), device=dev)}
+            sf = cor["flow"].to(dev, torch.float32).permute(0, 2, 3, 1).contiguous()        # [Bd, h, w, 2]
+            sc = cor["certainty"].to(dev, torch.float32).reshape(bd, *cor["certainty"].shape[-2:]).contiguous()
+            assert sf.shape[0] == bd and tuple(sc.shape[-2:]) == tuple(sf.shape[1:3])
+            fa.seed_flow, fa.seed_cert, fa.seed_h, fa.seed_w = sf.data_ptr(), sc.data_ptr(), sf.shape[1], sf.shape[2]
+            keepalive += [sf, sc]
+        flows, certs, feats = {}, {}, {}
+        for i, s in enumerate(self._SCALES):
+            if upsample and s == 16:
+                continue
+            hs, ws = self._scale_hw(H, W, s)
+            if want_corresps:
+                flows[s] = torch.empty((bd, hs, ws, 2), device=dev, dtype=torch.float32)
+                certs[s] = torch.empty((bd, hs, ws), device=dev, dtype=torch.float32)
+                fa.flow[i], fa.cert[i] = flows[s].data_ptr(), certs[s].data_ptr()
+            if want_feats:
+                feats[s] = torch.empty((2 * b, hs, ws, self._FEAT_C[s]), device=dev, dtype=self._act_torch_dtype())
+                fa.feat[i] = feats[s].data_ptr()
+        a, b_ = im_A.float().contiguous(), im_B.float().contiguous()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(lib.roma_forward(self._handle, b, C.c_void_p(a.data_ptr()), C.c_void_p(b_.data_ptr()), C.byref(fa),
+                                        C.c_void_p(stream)), lib=lib)
+        corresps = {s: {"certainty": certs[s][:, None], "flow": flows[s].permute(0, 3, 1, 2)} for s in flows}
+        pyramid = {s: f.permute(0, 3, 1, 2) for s, f in feats.items()}
+        return corresps, pyramid
+
+    def extract_backbone_features(self, batch, batched=True, upsample=False):
+        """matcher.py:585-596: {scale: [2B, C, h, w]} (A images then B images; NCHW views of the channels-last device
+        tensors, in the handle's activation dtype).  upsample=True returns the VGG scales only (encoders.py:56-68)."""
+        return self._forward_pass(batch, symmetric=False, upsample=upsample, scale_factor=1.0, want_corresps=False,
+                                  want_feats=True)[1]
+
+    def forward(self, batch, batched=True, upsample=False, scale_factor=1):
+        """matcher.py:631-651 in eval mode: corresps[s] = {"certainty" [B,1,h,w] logits, "flow" [B,2,h,w]} for A -> B."""
+        return self._forward_pass(batch, symmetric=False, upsample=upsample, scale_factor=scale_factor)[0]
+
+    def forward_symmetric(self, batch, batched=True, upsample=False, scale_factor=1):
+        """matcher.py:653-670: the same with the decoder batch doubled - entries [0, B) are A -> B, [B, 2B) are B -> A."""
+        return self._forward_pass(batch, symmetric=True, upsample=upsample, scale_factor=scale_factor)[0]
+
     def debug_fetch(self, name: str, dtype=np.float32) -> np.ndarray:
         """Intermediate tensor captured by the last match() when `self.debug` is set (tests only)."""
         lib = self._lib

@@ -373,3 +373,53 @@ def test_match_from_paths_vs_reference_golden(built_lib, weights0, tag, coarse, 
         assert tuple(wc.shape) == g["sq_coarse_only_warp"].shape
         assert np.abs(wc.cpu().numpy() - g["sq_coarse_only_warp"]).max() < TOL
         assert np.abs(cc.cpu().numpy() - g["sq_coarse_only_cert"]).max() < TOL
+
+
+def test_forward_apis_vs_reference_golden(tiny_model):
+    """RegressionMatcher.forward / forward_symmetric / extract_backbone_features (matcher.py:585-596, 631-670) through
+    roma_forward, against the unmodified reference's per-scale `corresps` (tests/golden/match_forward.npz,
+    tools/make_goldens.py forward): the symmetric coarse pass with match()'s scale factor, the upsample pass seeded with its
+    finest correspondences (matcher.py:870-889), the non-symmetric forward at B = 2 with the default scale_factor = 1, and the
+    feature pyramid.  f32; the keys of every corresps[s] are exactly the reference's eval-mode keys."""
+    import math
+    from roma_amd import synthetic
+    g = np.load(os.path.join(GOLDEN, "match_forward.npz"))
+    m = tiny_model
+    d = _to_dev(synthetic.make_inputs(1, 112, 168, seed=1))
+    worst = {}
+
+    def chk(tag, cor, scales):
+        assert sorted(cor.keys()) == sorted(scales)
+        for s_ in scales:
+            assert set(cor[s_].keys()) == {"certainty", "flow"}
+            ef = float((cor[s_]["flow"].cpu() - torch.from_numpy(g[f"{tag}_flow{s_}"])).abs().max())
+            ec = float((cor[s_]["certainty"].cpu() - torch.from_numpy(g[f"{tag}_cert{s_}"])).abs().max())
+            assert tuple(cor[s_]["flow"].shape) == g[f"{tag}_flow{s_}"].shape and tuple(cor[s_]["certainty"].shape) == g[f"{tag}_cert{s_}"].shape
+            worst[f"{tag}{s_}"] = (ef, ec)
+            assert ef < TOL and ec < TOL, (tag, s_, ef, ec)
+
+    cor = m.forward_symmetric({"im_A": d["im_A"], "im_B": d["im_B"]}, scale_factor=math.sqrt(112 * 112 / 560 ** 2))
+    chk("sym", cor, [16, 8, 4, 2, 1])
+    cu = m.forward_symmetric({"im_A": d["im_A_high_res"], "im_B": d["im_B_high_res"], "corresps": cor[1]}, upsample=True,
+                             batched=True, scale_factor=math.sqrt(168 * 168 / 560 ** 2))
+    chk("up", cu, [8, 4, 2, 1])
+    d2 = _to_dev(synthetic.make_inputs(2, 112, None, seed=7))
+    chk("fwd", m.forward({"im_A": d2["im_A"], "im_B": d2["im_B"]}), [16, 8, 4, 2, 1])
+    print("forward APIs, max |d flow| / |d certainty| per scale:", {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in worst.items()})
+    # match() == the two passes chained by hand + the epilogue's own tests: the finest upsample flow is what match() clamps
+    warp, _ = m.match(d["im_A"], d["im_B"], im_A_high_res=d["im_A_high_res"], im_B_high_res=d["im_B_high_res"])
+    a2b = cu[1]["flow"][:1].permute(0, 2, 3, 1).clamp(-1, 1)
+    assert float((warp[:, :, :168, 2:] - a2b).abs().max()) < 1e-6
+    fp = m.extract_backbone_features({"im_A": d["im_A"], "im_B": d["im_B"]})
+    sub = {16: 1, 8: 1, 4: 2, 2: 2, 1: 4}
+    assert sorted(fp.keys()) == [1, 2, 4, 8, 16]
+    for s_, f in fp.items():
+        assert tuple(f.shape) == tuple(g[f"feat{s_}_shape"])
+        ref = torch.from_numpy(g[f"feat{s_}"])
+        err = float((f[:, :, ::sub[s_], ::sub[s_]].float().cpu() - ref).abs().max())
+        assert err < 1e-4 * max(1.0, float(ref.abs().max())), (s_, err)
+    fu = m.extract_backbone_features({"im_A": d["im_A_high_res"], "im_B": d["im_B_high_res"]}, upsample=True)
+    assert sorted(fu.keys()) == list(g["feat_up_scales"])
+    assert float((fu[8].float().cpu() - torch.from_numpy(g["feat_up8"])).abs().max()) < 1e-4 * max(1.0, float(np.abs(g["feat_up8"]).max()))
+    with pytest.raises(ValueError):
+        m.forward({"im_A": d["im_A_high_res"], "im_B": d["im_B_high_res"]}, upsample=True)  # no batch["corresps"]

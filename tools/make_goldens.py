@@ -20,6 +20,7 @@ fixtures are what travels to the GPU box.  Usage:
     python tools/make_goldens.py vis           # RegressionMatcher.visualize_warp on a seeded warp + images
     python tools/make_goldens.py tinyroma      # TinyRoMa.match / forward with the seeded stand-in XFeat backbone
     python tools/make_goldens.py tinyroma_xfeat  # the same with a backbone of the real XFeat architecture; exact_softmax=True
+    python tools/make_goldens.py forward       # forward / forward_symmetric / extract_backbone_features (per-scale corresps)
     python tools/make_goldens.py assets        # tests/golden/pair_{A,B}.png: the decoded pixels of assets/sacre_coeur_{A,B}.jpg
     python tools/make_goldens.py match_path    # RegressionMatcher.match(path, path) / match(PIL, PIL): the transform route
     python tools/make_goldens.py tinyroma_path # TinyRoMa.match(path, path) on the asset pair (A and B of different sizes)
@@ -448,6 +449,44 @@ def tinyroma_xfeat_golden():
     print("tiny_xfeat_reference.npz", {k: v.shape for k, v in out.items()})
 
 
+def forward_golden():
+    """RegressionMatcher.forward / forward_symmetric / extract_backbone_features of the unmodified reference
+    (matcher.py:585-596, 631-670), 112 -> 168, seeded weights: the per-scale `corresps` dict of the coarse pass (symmetric,
+    the scale factor match() uses), of the upsample pass seeded with the coarse pass's finest correspondences (matcher.py:870-889),
+    of the non-symmetric forward at B = 2 with forward()'s default scale_factor = 1, and the feature pyramid."""
+    import math
+    sd, dsd = synthetic.make_matcher_state_dict(0), synthetic.make_dinov2_state_dict(0)
+    m = build_reference_matcher(sd, dsd, (112, 112), (168, 168), symmetric=True, upsample_preds=True)
+    out = {}
+    inp = synthetic.make_inputs(1, 112, 168, seed=1)
+    with torch.inference_mode():
+        sf = math.sqrt(112 * 112 / 560 ** 2)
+        cor = m.forward_symmetric({"im_A": inp["im_A"], "im_B": inp["im_B"]}, scale_factor=sf)
+        for s_, v in cor.items():
+            assert set(v.keys()) == {"certainty", "flow"}, v.keys()  # eval mode: nothing else (matcher.py:469-512)
+            out[f"sym_flow{s_}"], out[f"sym_cert{s_}"] = np32(v["flow"]), np32(v["certainty"])
+        sf2 = math.sqrt(168 * 168 / 560 ** 2)
+        cu = m.forward_symmetric({"im_A": inp["im_A_high_res"], "im_B": inp["im_B_high_res"], "corresps": cor[1]},
+                                 upsample=True, batched=True, scale_factor=sf2)
+        assert sorted(cu.keys()) == [1, 2, 4, 8]
+        for s_, v in cu.items():
+            out[f"up_flow{s_}"], out[f"up_cert{s_}"] = np32(v["flow"]), np32(v["certainty"])
+        inp2 = synthetic.make_inputs(2, 112, None, seed=7)
+        cf = m.forward({"im_A": inp2["im_A"], "im_B": inp2["im_B"]})  # batched=True, scale_factor=1 defaults
+        for s_, v in cf.items():
+            out[f"fwd_flow{s_}"], out[f"fwd_cert{s_}"] = np32(v["flow"]), np32(v["certainty"])
+        fp = m.extract_backbone_features({"im_A": inp["im_A"], "im_B": inp["im_B"]})
+        sub = {16: 1, 8: 1, 4: 2, 2: 2, 1: 4}
+        for s_, f in fp.items():
+            out[f"feat{s_}"] = np32(f[:, :, ::sub[s_], ::sub[s_]])
+            out[f"feat{s_}_shape"] = np.array(f.shape)
+        fu = m.extract_backbone_features({"im_A": inp["im_A_high_res"], "im_B": inp["im_B_high_res"]}, upsample=True)
+        out["feat_up_scales"] = np.array(sorted(fu.keys()))
+        out["feat_up8"] = np32(fu[8])
+    np.savez_compressed(os.path.join(GOLD, "match_forward.npz"), **out)
+    print("match_forward.npz", {k: v.shape for k, v in out.items()})
+
+
 ASSET_PAIR = ("sacre_coeur_A.jpg", "sacre_coeur_B.jpg")  # BASELINE config 1's pair: 640 x 480 and 618 x 640 (W x H), RGB
 
 
@@ -547,4 +586,4 @@ def vis_golden():
 
 if __name__ == "__main__":
     for what in sys.argv[1:]:
-        {"contract": contract, "ops": ops, "ops_nearest": ops_nearest, "tiny": tiny, "small": small, "full": full, "odd": odd, "mega": mega, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden, "keypoints_ties": keypoints_ties_golden, "vis": vis_golden, "tinyroma": tinyroma_golden, "tinyroma_xfeat": tinyroma_xfeat_golden, "assets": assets_golden, "match_path": match_path_golden, "tinyroma_path": tinyroma_path_golden}[what]()
+        {"contract": contract, "ops": ops, "ops_nearest": ops_nearest, "tiny": tiny, "small": small, "full": full, "odd": odd, "mega": mega, "full8": full8, "full8_indoor": full8_indoor, "full_coarse": full_coarse, "kde": kde_golden, "keypoints": keypoints_golden, "keypoints_ties": keypoints_ties_golden, "vis": vis_golden, "tinyroma": tinyroma_golden, "tinyroma_xfeat": tinyroma_xfeat_golden, "forward": forward_golden, "assets": assets_golden, "match_path": match_path_golden, "tinyroma_path": tinyroma_path_golden}[what]()
