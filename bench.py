@@ -200,6 +200,18 @@ def main():
         step()  # one-time work of the very first call (second-stream workspace allocation, function attributes) is never timed
     for _ in range(args.warmup):
         step()
+    solo = None
+    if world > 1:
+        # the N = 1 figure of THIS binary on THIS rank's GPU, for the scaling check: the same steps with no gather at all
+        # (every rank runs it at the same time, so host-side contention between the processes is included)
+        drain()
+        sync()
+        ns = max(1, min(args.steps, 5))
+        ts = time.perf_counter()
+        for _ in range(ns):
+            model.match(inp["im_A"], inp["im_B"], **kw)
+        sync()
+        solo = args.batch * ns / (time.perf_counter() - ts)
     if world > 1:
         drain()
         dist.barrier()
@@ -231,6 +243,9 @@ def main():
         per_rank = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(per_rank, torch.tensor([n_pairs / world * args.steps / dt_rank], device=dev, dtype=torch.float64))
         per_rank = [float(x.item()) for x in per_rank]
+        solo_all = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(solo_all, torch.tensor([solo], device=dev, dtype=torch.float64))
+        solo_all = [float(x.item()) for x in solo_all]
     step_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
     finite = bool(torch.isfinite(out[1]).all()) if out[1] is not None else True
 
@@ -255,6 +270,11 @@ def main():
     if world > 1:
         result["rccl_ranks"] = world
         result["pairs_per_s_per_rank"] = per_rank
+        result["ms_per_step_per_rank"] = [1e3 * args.batch / v for v in per_rank]
+        # what the root receives per step: (world - 1) shards of warp [b, H, 2W, 4] + certainty [b, H, 2W] f32
+        result["gather_bytes_per_step_into_rank0"] = int((world - 1) * (out[0][:args.batch].numel() + out[1][:args.batch].numel()) * 4) if rank == 0 else None
+        result["single_gpu_no_gather_pairs_per_s_per_rank"] = solo_all  # same binary, same GPUs, gather off (N = 1 yardstick)
+        result["gather_overhead_frac"] = 1.0 - (n_pairs * args.steps / dt) / sum(solo_all)
         result["gather_wait_ms_rank0"] = {"median": statistics.median(gather_ms) if gather_ms else None,
                                           "last": gather_ms[-1] if gather_ms else None}
         result["launched_by"] = "bench.py self-spawn" if os.environ.get("ROMA_BENCH_SPAWNED") else "external launcher"

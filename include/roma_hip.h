@@ -53,6 +53,14 @@ typedef struct {
 
 const char* roma_last_error(void);
 const char* roma_version(void);
+/* ABI stamp of the structures that cross the library boundary BETWEEN the two builds (roma_vit_args_t, roma_vit_block_t:
+ * a ROMA_MIXED handle of libroma_hip_f16.so calls roma_vit_forward of libroma_hip.so): ROMA_ABI_VERSION * 100000 +
+ * sizeof(roma_vit_args_t).  The sibling is refused unless the stamps are equal. */
+#define ROMA_ABI_VERSION 5
+int roma_abi_stamp(void);
+/* the 16-bit format as THIS library's own internal calls see it (== roma_h16_format() unless another library's symbols
+ * interpose: the sibling check of ROMA_MIXED and tests/test_cpu_oracle.py use it) */
+int roma_self_check(void);
 
 /* ---- DINOv2 ViT-L/14 as a stand-alone entry (dinov2.py:192-237: patch embed, cls + position embedding, 24 pre-norm
  * blocks, final LayerNorm, patch tokens).  Everything is a DEVICE pointer prepared by the caller: weights in THIS

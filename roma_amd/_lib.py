@@ -40,6 +40,8 @@ SIGNATURES = {
     "roma_last_error": (C.c_char_p, []),
     "roma_version": (C.c_char_p, []),
     "roma_h16_format": (_i, []),
+    "roma_abi_stamp": (_i, []),
+    "roma_self_check": (_i, []),
     "roma_create": (_i, [C.POINTER(RomaConfig), C.POINTER(_vp)]),
     "roma_set_tensor": (_i, [_vp, C.c_char_p, _i, C.POINTER(C.c_int64), _vp, _i]),
     "roma_finalize": (_i, [_vp]),

@@ -49,6 +49,7 @@ namespace roma {
 // ROMA_MIXED: the sibling bfloat16 library (once a mixed handle has loaded it) keeps its own switches and its own launch
 // profile; tuning calls and the profile of THIS library are forwarded / merged so that callers see one library.
 void* g_peer_lib = nullptr;  // set by Model::load_peer (model.hip)
+int g_mixed_handles = 0;      // live ROMA_MIXED handles (model.hip): the sibling follows roma_tuning / roma_profile_* only while > 0
 template <typename F> static F peer_sym(const char* name) {
   return g_peer_lib ? reinterpret_cast<F>(dlsym(g_peer_lib, name)) : nullptr;
 }
@@ -85,6 +86,10 @@ extern "C" {
 const char* roma_last_error(void) { return g_err.c_str(); }
 const char* roma_version(void) { return "roma_hip 0.3 (gfx950, 16-bit storage = " ROMA_H16_NAME ")"; }
 int roma_h16_format(void) { return ROMA_H16_CODE; }
+int roma_abi_stamp(void) { return ROMA_ABI_VERSION * 100000 + (int)sizeof(roma_vit_args_t); }
+// roma::internal_h16_code lives in ANOTHER translation unit (vit.hip) on purpose: a call inside one TU binds locally under
+// clang's default -fno-semantic-interposition, a cross-TU call goes through the PLT unless the library is linked -Bsymbolic
+int roma_self_check(void) { return roma::internal_h16_code(); }
 
 int roma_create(const roma_config_t* cfg, roma_handle_t* out) {
   ROMA_REQUIRE(cfg && out, "roma_create: null argument");
@@ -219,7 +224,15 @@ int roma_destroy(roma_handle_t h) {
 
 int roma_tuning(const char* key, int value) {
   ROMA_REQUIRE(key, "roma_tuning: null key");
-  if (auto f = peer_sym<int (*)(const char*, int)>("roma_tuning")) (void)f(key, value);
+  // ROMA_MIXED handles run DINOv2 in the bfloat16 sibling, so its switches follow - but only while such a handle is alive:
+  // the sibling is the same process-wide instance a pure-bf16 matcher uses (roma_amd loads it too), and a tuning call on
+  // the binary16 library must not silently retune an unrelated bf16 matcher once the last mixed handle is gone.
+  if (g_mixed_handles > 0)
+    if (auto f = peer_sym<int (*)(const char*, int)>("roma_tuning"))
+      if (int rc = f(key, value)) {
+        set_error(std::string("roma_tuning: the bfloat16 sibling library refused key ") + key);
+        return rc;
+      }
   const std::string k(key);
   if (k == "gemm8p") g_gemm_tuning[0] = value;
   else if (k == "gemm_dbg") g_gemm_tuning[1] = value;
@@ -258,7 +271,9 @@ long roma_debug_gemm_trace(unsigned int* dst_host, long nbytes) {
 }
 
 int roma_profile_enable(int on) {
-  if (auto f = peer_sym<int (*)(int)>("roma_profile_enable")) (void)f(on);
+  if (g_mixed_handles > 0)  // see roma_tuning
+    if (auto f = peer_sym<int (*)(int)>("roma_profile_enable"))
+      if (int rc = f(on)) return rc;
   for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   g_prof.clear();
   g_prof_on = on != 0;

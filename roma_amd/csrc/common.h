@@ -184,6 +184,8 @@ struct ProfScope {
   }
 };
 
+int internal_h16_code();  // vit.hip: this build's 16-bit code, for roma_self_check (api.hip)
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 

@@ -417,8 +417,8 @@ int transpose_launch(const float* in, float* out, int n, long ld, int batch, hip
 // (A fully unrolled register/readlane variant was correct but ~70 KB of straight-line code: instruction-fetch bound.)
 // Round 4: TWO waves in a pipeline.  Row r of the inverse only needs columns <= r of the factor, and column j is final the
 // moment the factorisation has finished its step j - so wave 1 runs the forward substitutions one row behind wave 0's column
-// steps instead of after them (wave 0 publishes its progress in LDS; the LDS executes a wave's operations in order, so a
-// plain flag store behind a step's writes and a flag poll in front of a row's reads are all the ordering needed), and all four
+// steps instead of after them (wave 0 publishes its progress in LDS with a release store behind a step's writes, wave 1 polls
+// it with an acquire load in front of a row's reads), and all four
 // waves share the 16 KB load and the 48 KB write-back.  53 -> ~33 us per call on the GP's launch-latency-bound chain (25 calls);
 // arithmetic and its order unchanged: bit-identical results.
 __global__ __launch_bounds__(256) void chol_diag_kernel(float* A, long ld, long strideA, float* Linv, float* LinvT,
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(float* A, long ld, long 
   __shared__ __attribute__((aligned(16))) float L[64 * S];   // L[i][c]   (lane i owns row i)
   __shared__ __attribute__((aligned(16))) float LT[64 * S];  // LT[j][c] = L[c][j]   (broadcast source)
   __shared__ __attribute__((aligned(16))) float XT[64 * S];  // XT[c][t] = X[t][c]   (lane c owns row c)
-  __shared__ int progress;  // last finished column step of the factorisation (relaxed workgroup-scope atomics: plain ds_read / ds_write)
+  __shared__ int progress;  // last finished column step of the factorisation (workgroup-scope release / acquire)
   float* Ab = A + (long)blockIdx.x * strideA + ((long)k * 64) * ld + (long)k * 64;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -449,11 +449,10 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(float* A, long ld, long 
         const float lij = (i == j) ? d : L[i * S + j] / d;
         L[i * S + j] = lij;   // rows < j: harmless garbage in the strictly upper part
         LT[j * S + i] = lij;  // column j of the factor, contiguous
-        // column j is final: let the inverse take row j.  (The LDS executes one wave's operations in order, so the two stores
-        // above land before this one without a wait; the empty asm keeps the COMPILER from moving them.)
-        asm volatile("" ::: "memory");
-        __hip_atomic_store(&progress, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("" ::: "memory");
+        // column j is final: let the inverse take row j.  Release / acquire at workgroup scope (round 5): one
+        // s_waitcnt lgkmcnt(0) in front of the flag store instead of relying on the LDS executing different waves' DS
+        // operations in one FIFO, which the memory model does not promise.
+        __hip_atomic_store(&progress, j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         // a_ic -= l_ij * l_cj for c > j.  Every column group of the band's range every time (selects, no trip count that
         // depends on j): the LDS operations of a step are independent and pipeline, instead of ~150 cycles of latency per
         // group; the compile-time band start drops the 37 % of the groups that lie wholly left of column j.
@@ -475,8 +474,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(float* A, long ld, long 
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {  // rows in four bands: row r only needs the unknowns t < r, i.e. groups < 16 (rb + 1)
       for (int r = 16 * rb; r < 16 * rb + 16; ++r) {
-        while (__hip_atomic_load(&progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < r) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");  // the reads below are issued after the flag has been seen
+        while (__hip_atomic_load(&progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < r) __builtin_amdgcn_s_sleep(1);
         f32x4 part = {(r == c) ? 1.f : 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 16 * (rb + 1); t += 4) {

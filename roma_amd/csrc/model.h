@@ -3,6 +3,7 @@
 // kernel schedule of RegressionMatcher.match() (romatch/models/matcher.py:779-934).
 #pragma once
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -10,6 +11,8 @@
 #include "common.h"
 
 namespace roma {
+
+extern std::mutex g_peer_mutex;  // guards the one-time load of the sibling library and the mixed-handle count (model.hip)
 
 struct HostTensor {
   std::vector<int64_t> shape;
@@ -125,6 +128,7 @@ class Model {
   hipEvent_t ev_fork = nullptr, ev_join[MAX_STREAMS - 1] = {nullptr};
   std::vector<void*> owned;  // device allocations to free
   std::map<std::string, std::pair<void*, size_t>> dbg;
+  int dbg_cur_slot = 0;  // sub-batch slot match_impl is currently enqueueing (ROMA_DEBUG_DUAL_SLOT diagnostics)
   // debug mode only (roma_debug_inject): device buffers that REPLACE a named intermediate of the next match() calls.
   // "gm_flow16" [ndp, T, 2] / "gm_cert16" [ndp, T] f32 overwrite the output of cls_to_flow_refine, so a parity test can
   // pin the (discontinuous) coarse arg-max to the oracle's and hold everything downstream to a continuous bound.

@@ -19,6 +19,10 @@
 
 namespace roma {
 
+std::mutex g_peer_mutex;
+extern void* g_peer_lib;  // api.hip: roma_tuning / roma_profile_* forward to the sibling library while a mixed handle lives
+extern int g_mixed_handles;
+
 static const int VGG_IDX[12] = {0, 3, 7, 10, 14, 17, 20, 23, 27, 30, 33, 36};
 static const int VGG_CH[12] = {64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512};
 static const char* SCALES[5] = {"16", "8", "4", "2", "1"};
@@ -37,15 +41,19 @@ Model::~Model() {
   for (void* p : owned) (void)hipFree(p);
   for (auto& kv : dbg) (void)hipFree(kv.second.first);
   for (auto& kv : inject) (void)hipFree(kv.second.first);
+  if (peer_lib) {
+    std::lock_guard<std::mutex> lk(g_peer_mutex);
+    --g_mixed_handles;
+  }
 }
 
-extern void* g_peer_lib;  // api.hip: roma_tuning / roma_profile_* forward to the sibling library once it is loaded
 
 // ROMA_MIXED: the bfloat16 build of this library (libroma_hip.so, next to this shared object) runs DINOv2.  Loaded once per
 // process with RTLD_LOCAL: both libraries export the same C ABI, each keeps its own symbols.
 int Model::load_peer() {
   static void* lib = nullptr;
   static int (*fwd)(const roma_vit_args_t*, void*) = nullptr;
+  std::lock_guard<std::mutex> lk(g_peer_mutex);  // handles may be created from several threads
   if (!lib) {
     ROMA_REQUIRE(roma_h16_format() == ROMA_F16, "ROMA_MIXED is a mode of the binary16 build (libroma_hip_f16.so)");
     Dl_info info;
@@ -53,22 +61,32 @@ int Model::load_peer() {
     std::string path(info.dli_fname);
     const size_t slash = path.find_last_of('/');
     path = (slash == std::string::npos ? std::string("") : path.substr(0, slash + 1)) + "libroma_hip.so";
-    void* l = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    // RTLD_LOCAL: its C ABI must not shadow ours; RTLD_DEEPBIND on top of the link-time -Bsymbolic (csrc/Makefile): the
+    // sibling's own definitions win over anything in the global scope - this library, when a C program linked it directly
+    void* l = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
     if (!l) {
       set_error("ROMA_MIXED: cannot load the bfloat16 library " + path + ": " + (dlerror() ? dlerror() : "?"));
       return ROMA_ERR_STATE;
     }
     auto fmt = reinterpret_cast<int (*)(void)>(dlsym(l, "roma_h16_format"));
+    auto self = reinterpret_cast<int (*)(void)>(dlsym(l, "roma_self_check"));
+    auto abi = reinterpret_cast<int (*)(void)>(dlsym(l, "roma_abi_stamp"));
     auto f = reinterpret_cast<int (*)(const roma_vit_args_t*, void*)>(dlsym(l, "roma_vit_forward"));
-    if (!fmt || !f || fmt() != ROMA_BF16) {
+    std::string why;
+    if (!fmt || !f || !self || !abi) why = "it does not export roma_h16_format / roma_self_check / roma_abi_stamp / roma_vit_forward (an older build)";
+    else if (fmt() != ROMA_BF16) why = "it is not the bfloat16 build";
+    else if (abi() != roma_abi_stamp()) why = "its ABI stamp " + std::to_string(abi()) + " differs from this library's " + std::to_string(roma_abi_stamp()) + " (stale build: roma_vit_args_t would be misread)";
+    else if (self() != ROMA_BF16) why = "its internal calls resolve into another library (symbol interposition: link both builds with -Wl,-Bsymbolic)";
+    if (!why.empty()) {
       dlclose(l);
-      set_error("ROMA_MIXED: " + path + " is not the bfloat16 build of this library version");
+      set_error("ROMA_MIXED: " + path + " cannot serve as the bfloat16 sibling: " + why);
       return ROMA_ERR_STATE;
     }
     lib = l;
     fwd = f;
     g_peer_lib = l;
   }
+  if (!peer_lib) ++g_mixed_handles;
   peer_lib = lib;
   peer_vit_forward = fwd;
   return 0;
@@ -528,13 +546,12 @@ int Model::ensure_side_streams(int n) {
 // diagnostics (tools/repro_mixed.py): ROMA_DEBUG_DUAL_SLOT = k keeps the sub-batch stream split on in debug mode and lets only
 // sub-batch k capture its stages (the capture table is per handle, not per stream)
 static const int g_dbg_dual_slot = getenv("ROMA_DEBUG_DUAL_SLOT") ? atoi(getenv("ROMA_DEBUG_DUAL_SLOT")) : -1;
-static int g_dbg_cur_slot = 0;  // set by match_impl (host side, sequential)
 
 int Model::dbg_save(const char* name, const void* p, size_t bytes, hipStream_t st) {
   if (!debug) return 0;
   if (g_dbg_dual_slot >= 0) {  // only the stages named in ROMA_DEBUG_ONLY (comma separated), only for the chosen sub-batch
     static const std::string only = std::string(",") + (getenv("ROMA_DEBUG_ONLY") ? getenv("ROMA_DEBUG_ONLY") : "") + ",";
-    if (g_dbg_cur_slot != g_dbg_dual_slot || only.find(std::string(",") + name + ",") == std::string::npos) return 0;
+    if (dbg_cur_slot != g_dbg_dual_slot || only.find(std::string(",") + name + ",") == std::string::npos) return 0;
   }
   auto it = dbg.find(name);
   if (it == dbg.end() || it->second.second != bytes) {
@@ -816,7 +833,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
   auto AL = [&](size_t elems, size_t es) { return arena.alloc(elems * es); };
   // determinism trace: checksum of a stage's output, XORed into this sub-batch stream's table
   const int tslot = (&arena == &this->arena) ? 0 : (int)(&arena - side_arena) + 1;
-  g_dbg_cur_slot = tslot;
+  dbg_cur_slot = tslot;  // (per handle: two handles may be in match() from two threads)
   const bool tracing = trace_on && !dry;
   if (tracing) {
     if (!trace_dev[tslot]) {

@@ -10,6 +10,16 @@
 
 namespace roma {
 
+// roma_self_check (api.hip): the format code as a CROSS-translation-unit internal call sees it
+int internal_h16_code() {
+#ifdef ROMA_H16_F16
+  return ROMA_F16;
+#else
+  return ROMA_BF16;
+#endif
+}
+
+
 #define VRUN(expr)          \
   do {                      \
     int _rc = (expr);       \

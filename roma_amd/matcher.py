@@ -148,6 +148,28 @@ class RegressionMatcher:
             self._cache.move_to_end(key)
             self._handle, self._built = self._cache[key], key
             return
+        try:
+            h = self._build_handle(key)
+        except _lib.RomaHipError:
+            raise
+        except (RuntimeError, AssertionError) as e:
+            # Peak residency while switching is handle_cache + 1 handles (each ~0.9 GB of packed weights + a workspace of
+            # ~12 GB at batch 8, 560 -> 864): the new handle is built before the old ones are evicted, so that a failed
+            # build leaves the matcher on its old, working handle.  If the build failed on the DEVICE (out of memory in
+            # roma_finalize) and older handles are still resident, release them and try once more.
+            if not self._cache or "hip" not in str(e).lower():
+                raise
+            self._release()
+            h = self._build_handle(key)
+        while len(self._cache) >= max(self.handle_cache, 1):
+            _, old = self._cache.popitem(last=False)
+            self._lib.roma_destroy(old)
+        self._handle = h
+        self._built = key
+        self._cache[key] = h
+
+    def _build_handle(self, key):
+        """roma_create + roma_set_tensor x 946 + roma_finalize for one configuration; raises and destroys on failure."""
         lib = self._lib
         uh, uw = key[2]
         cfg = _lib.RomaConfig(key[0], key[1], uh, uw, int(bool(self.symmetric)), int(bool(self.upsample_preds)),
@@ -168,13 +190,7 @@ class RegressionMatcher:
         except Exception:
             lib.roma_destroy(h)
             raise
-        # evict only now that the new handle exists (a failed build leaves the matcher on its old, working handle)
-        while len(self._cache) >= max(self.handle_cache, 1):
-            _, old = self._cache.popitem(last=False)
-            self._lib.roma_destroy(old)
-        self._handle = h
-        self._built = key
-        self._cache[key] = h
+        return h
 
     def _release(self):
         for h in getattr(self, "_cache", {}).values():

@@ -437,6 +437,27 @@ def test_c_abi_argument_validation_without_gpu(built_lib):
         assert rc != 0, "the HIP path must fail loudly without a GPU (no CPU fallback)"
 
 
+def test_both_builds_in_one_global_scope_keep_their_own_symbols(built_lib):
+    """libroma_hip.so and libroma_hip_f16.so export identical symbols (the 16-bit type is `unsigned
+    short` in both), so with one of them in the GLOBAL scope - a C program linking -lroma_hip_f16, or RTLD_GLOBAL - the other's
+    internal cross-TU calls would bind to it and a ROMA_MIXED handle would run binary16 kernels on bfloat16 data.  Both are
+    linked -Wl,-Bsymbolic; roma_self_check() answers with the format code a cross-translation-unit internal call sees.  Both
+    load orders, in fresh processes (dlopen needs no GPU).  The ABI stamps the mixed mode compares must agree."""
+    from roma_amd import _lib
+    prog = ("import ctypes, sys\n"
+            "a = ctypes.CDLL(sys.argv[1], mode=ctypes.RTLD_GLOBAL)\n"
+            "b = ctypes.CDLL(sys.argv[2], mode=ctypes.RTLD_GLOBAL)\n"
+            "print(a.roma_h16_format(), a.roma_self_check(), b.roma_h16_format(), b.roma_self_check(), a.roma_abi_stamp(), b.roma_abi_stamp())\n")
+    for first, second in (("f16", "bf16"), ("bf16", "f16")):
+        out = subprocess.run([sys.executable, "-c", prog, _lib.LIB_PATHS[first], _lib.LIB_PATHS[second]], capture_output=True,
+                             text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        fa, sa, fb, sb, abi_a, abi_b = (int(v) for v in out.stdout.split())
+        assert (fa, fb) == (_lib.H16_CODE[first], _lib.H16_CODE[second])
+        assert sa == fa and sb == fb, f"internal calls of one build bind into the other ({first} first): {out.stdout}"
+        assert abi_a == abi_b and abi_a // 100000 >= 5
+
+
 def test_product_never_imports_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "roma_amd")):
         for f in files:
@@ -497,6 +518,20 @@ def test_gloo_world2_gather(tmp_path):
         "W, Cc = pend.wait()\n"
         "if r == 0:\n"
         "    assert torch.equal(W[:, 0, 0, 0], torch.arange(6.) + 20)\n"
+        "# fewer pairs than ranks: rank 1's shard is EMPTY (count 0) - no deadlock, no division by zero, root gets the one pair\n"
+        "n = 1\n"
+        "s, c = shard_pairs(n, r, w)\n"
+        "assert (s, c) == ((0, 1) if r == 0 else (1, 0))\n"
+        "warp = torch.full((c, 4, 6, 4), 7.0)\n"
+        "cert = torch.full((c, 4, 6), 9.0)\n"
+        "for mode in (False, True):\n"
+        "    res = gather_results(warp, cert, n, async_op=mode)\n"
+        "    W, Cc = res.wait() if mode else res\n"
+        "    if r == 0:\n"
+        "        assert W.shape == (1, 4, 6, 4) and Cc.shape == (1, 4, 6) and float(W.min()) == 7.0 and float(Cc.max()) == 9.0\n"
+        "    else:\n"
+        "        assert W is None and Cc is None\n"
+        "if r == 0:\n"
         "    print('GATHER_OK')\n"
         "dist.destroy_process_group()\n")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
@@ -517,6 +552,8 @@ def test_bench_self_spawn_n2_dry_run():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["config"]["global_batch"] == 4 and r["rccl_ranks"] == 2
     assert r["launched_by"] == "bench.py self-spawn" and len(r["pairs_per_s_per_rank"]) == 2
+    assert len(r["ms_per_step_per_rank"]) == 2 and len(r["single_gpu_no_gather_pairs_per_s_per_rank"]) == 2
+    assert r["gather_bytes_per_step_into_rank0"] > 0 and r["gather_overhead_frac"] < 1.0
     assert abs(r["value"] - 4 * 3 / (r["ms_per_step"] * 3e-3)) < 1e-6 * r["value"]
 
 
