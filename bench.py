@@ -457,6 +457,14 @@ def main():
             # roma_models.py:183-188; VGG / decoder / refiners autocast to float16): the parity-bearing 16-bit line
             "mixed_bf16_dinov2_f16_rest_b8 (the reference timing script's policy)": side_config("mixed", True, 8, 10, 3, 0, 1, "match_full8.npz"),
         }
+        # The parity-bearing 16-bit line at the TOP level, next to the timed bf16 mode's `parity`: ROMA_MIXED is what the
+        # reference's own timing script computes (tests/test_roma_upsample_inference_time.py:45 + roma_models.py:183-188), runs
+        # at the speed of the bf16 mode and holds the continuous part of the pipeline to ~1.4e-3 of the reference's fp32 output.
+        mx = result["other_configs"]["mixed_bf16_dinov2_f16_rest_b8 (the reference timing script's policy)"]
+        result["parity_mixed_precision"] = {
+            "mode": "ROMA_MIXED: bfloat16 DINOv2 + binary16 VGG / decoder / refiners (amp_dtype=bfloat16, decoder_dtype=float16)",
+            "value": mx["value"], "unit": "image-pairs/s", "ms_per_step": mx["ms_per_step"], "same_workload_as_value": True,
+            **(mx.get("parity") or {})}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle (CPU restatement of the reference; the reference itself is not on the GPU box) on
@@ -485,7 +493,11 @@ def main():
                                   "checked_against_reference_golden": checked,
                                   "sample": f"1 symmetric pair {what}, fp32, torch CPU oracle: 1 warm-up + {len(times)} timed calls, "
                                             f"median {med:.1f} s (all: {', '.join(f'{t:.1f}' for t in times)})",
-                                  "host_cores_available": os.cpu_count()}
+                                  "host_cores_available": os.cpu_count(),
+                                  "why_not_all_cores": "more threads are SLOWER for this workload: the same call takes ~250 s with all "
+                                                       "256 hardware threads against 21-28 s with 32 (MKL / oneDNN at these sizes; "
+                                                       "measured in round 3, DESIGN.md section 5), so 32 is the fastest CPU "
+                                                       "configuration, not a handicap"}
 
     if rank == 0:
         print(json.dumps(result))
