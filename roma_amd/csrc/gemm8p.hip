@@ -573,8 +573,12 @@ static int gemm8p_sched_of(const GemmArgs& a) {
 }
 template <typename TOUT, bool CONV, int EPI>
 static int launch8p(const GemmArgs& a, hipStream_t stream, const char* epi_name) {
-  if (gemm8p_sched_of(a)) return launch8p_s<TOUT, CONV, EPI, false, 1>(a, stream, epi_name);
-  return launch8p_s<TOUT, CONV, EPI, false, 0>(a, stream, epi_name);
+#ifdef ROMA_TOOLS_BUILD  // the quadrant-phase schedule of rounds 2-3 (bit-identical; A/B only) is not in the shipped libraries
+  if (!gemm8p_sched_of(a)) return launch8p_s<TOUT, CONV, EPI, false, 0>(a, stream, epi_name);
+#else
+  ROMA_REQUIRE(gemm8p_sched_of(a) == 1, "gemm8p: the quadrant-phase schedule (gemm8p_sched = 0) is an A/B variant of tools builds (make TOOLS=1)");
+#endif
+  return launch8p_s<TOUT, CONV, EPI, false, 1>(a, stream, epi_name);
 }
 
 int gemm8p_trace_read(unsigned* host, long n) {
@@ -638,6 +642,7 @@ int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
     }
     if (a.act == ACT_GELU) return launch8p<bf16_t, false, E8_GELU>(a, stream, "gelu");
     if (a.act == ACT_RELU) return launch8p<bf16_t, false, E8_RELU>(a, stream, "relu");
+#ifdef ROMA_TOOLS_BUILD
     // A/B switch: LDS-DMA issued between the MFMAs instead of in the load block.  Measured (tools/bench_gemm_overhead.py bit 512, profiles/r02_v11_gemm_overhead.log):
     // neutral at K = 1024, -4 % at K = 4096, -15 % on the 3x3 convolution (its per-piece select sits between the MFMAs)
     if (a.dbg & 512) return launch8p_s<bf16_t, false, E8_NONE, true>(a, stream, "none");
@@ -652,6 +657,9 @@ int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
       set_error("gemm8p: no such ablation build");
       return -2;
     }
+#else
+    ROMA_REQUIRE(!(a.dbg & (512 | 32768)), "gemm8p: the DMA-between-MFMAs variant and the ablation / trace builds exist in tools builds only (make TOOLS=1)");
+#endif
     return launch8p<bf16_t, false, E8_NONE>(a, stream, "none");
   }
   if (a.out_dt == DT_F32) {

@@ -82,295 +82,15 @@ __device__ __forceinline__ void rb_glds16(const char* src, lds_u8* lds_wave_base
   __builtin_amdgcn_s_barrier();                             \
   asm volatile("" ::: "memory")
 
-template <int CP>
-__global__ __launch_bounds__(256, 2) void refiner_block_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
-                                                               const float* __restrict__ dww, const float* __restrict__ dwb,
-                                                               const bf16_t* __restrict__ pw, long ldpw,
-                                                               const float* __restrict__ pwb, int B, int H, int W, int SY,
-                                                               int nxg, int nblocks, int dbg) {
-  typedef RBCfg<CP> Cf;
-  constexpr int GC = Cf::GC, XQ = Cf::XQ, PX = Cf::PX, PXB = Cf::PXB, KS = Cf::KS, NR = Cf::NR, KW = Cf::KW;
-  constexpr int XROW = Cf::XROW, OROW = Cf::OROW, NDMA = Cf::NDMA, RSTRIDE = Cf::RSTRIDE;
-  // Two distinct LDS objects on purpose: the compiler orders plain LDS reads against in-flight LDS-DMA only when they
-  // may alias, so everything in `work` is read with ordinary code while `ring` (the DMA target) is read with inline asm.
-  __shared__ __attribute__((aligned(1024))) unsigned char ring[Cf::RING_BYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char work[Cf::WORK_BYTES];
-  lds_u8* const wk = (lds_u8*)work;
-  lds_f32* const wsm = (lds_f32*)wk;                         // [26][CP] depthwise taps + bias
-  lds_f32* const pbs = (lds_f32*)(wk + Cf::OFF_PWB);         // [CP] 1x1 bias
-  lds_u8* const Wt = wk + Cf::OFF_WT;                        // [TAIL][XROW] remainder-block 1x1 weights
-  lds_u8* const Xt = wk + Cf::OFF_XT;                        // [PXB*32][XROW] depthwise output row (bf16)
-  lds_u8* const Ot = wk + Cf::OFF_OT;                        // [PX][CP] block output row (bf16)
-
-  const int per_xcd = (nblocks + 7) / 8;  // each XCD owns a contiguous band of strips (vertical halo hits its own L2)
-  const long lb = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-  if (lb >= nblocks) return;
-  const int xg = (int)(lb % nxg);
-  long rr = lb / nxg;
-  const int yt = (H + SY - 1) / SY;
-  const int ys = (int)(rr % yt) * SY;
-  const int b = (int)(rr / yt);
-  const int tid = threadIdx.x;
-  const int wv = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-  const int x0 = xg * PX;
-  const int sy = min(SY, H - ys);
-  const int T = sy + 4;  // input rows ys-2 .. ys+sy+1
-  const int npx = min(PX, W - x0);
-
-  // ---- one-time staging (ordinary loads: they are all retired before the first DMA is issued)
-  {
-    constexpr int nvec = 26 * GC;
-#pragma unroll
-    for (int it = 0; it < (nvec + 255) / 256; ++it) {
-      const int i = tid + 256 * it;
-      if (i < nvec)
-        *(lds_f32x4*)(wsm + i * 4) =
-            *reinterpret_cast<const f32x4*>(i < 25 * GC ? dww + (long)i * 4 : dwb + (long)(i - 25 * GC) * 4);
-    }
-    if (tid < GC) *(lds_f32x4*)(pbs + tid * 4) = *reinterpret_cast<const f32x4*>(pwb + tid * 4);
-    constexpr int wslots = Cf::TAIL * (XROW / 16);
-    for (int i = tid; i < wslots; i += 256) {
-      const int n = i / (XROW / 16), sl = i - n * (XROW / 16);
-      u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-      if (sl < CP * 2 / 16) v = *reinterpret_cast<const u32x4_t*>(pw + (long)(32 * Cf::NBF + n) * ldpw + sl * 8);
-      *(lds_u32x4*)(Wt + n * XROW + sl * 16) = v;
-    }
-    for (int i = tid; i < PXB * 32 * XROW / 16; i += 256) *(lds_u32x4*)(Xt + i * 16) = u32x4_t{0u, 0u, 0u, 0u};
-  }
-  // weights of this wave's own 32-channel block stay in registers (A operand: row = channel, 8 consecutive k per lane)
-  u32x4_t wown[Cf::NBF ? KS : 1];
-  if constexpr (Cf::NBF > 0) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      wown[ks] = *reinterpret_cast<const u32x4_t*>(pw + (long)(32 * wv + l31) * ldpw + ks * 16 + hh * 8);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)  // make the compiler retire these loads here, not inside the pipelined loop
-      asm volatile("" : "+v"(wown[ks]));
-  }
-
-  // ---- DMA descriptors: wave wv issues the 1 KiB pieces wv, wv+4, .. of every input row; lane -> 16-byte chunk
-  const char* zsrc = reinterpret_cast<const char*>(g_rb_zero_page);
-  const char* inb = reinterpret_cast<const char*>(in + ((long)b * H * W) * CP);
-  const int qoff0 = (wv * 64 + lane) * 16;  // piece q of this wave starts 4 KiB * q further
-  bool qok[KW];
-#pragma unroll
-  for (int q = 0; q < KW; ++q) {
-    const int chunk = (wv + 4 * q) * 64 + lane;
-    const int x = x0 - 2 + chunk / (CP / 8);
-    qok[q] = chunk * 16 < Cf::IN_ROWB && x >= 0 && x < W;
-  }
-  const int kw = (NDMA - wv + 3) / 4;  // pieces this wave really issues per row
-#define ROMA_RB_ISSUE_ROW(RROW, SLOT)                                                                  \
-  {                                                                                                    \
-    const int yy_ = ys - 2 + (RROW);                                                                   \
-    const bool rok_ = (RROW) < T && yy_ >= 0 && yy_ < H;                                               \
-    const char* rb_ = inb + ((long)(rok_ ? yy_ : 0) * W + x0 - 2) * (CP * 2);                          \
-    _Pragma("unroll") for (int q = 0; q < KW; ++q) {                                                   \
-      if (wv + 4 * q < NDMA)                                                                           \
-        rb_glds16((rok_ && qok[q]) ? rb_ + qoff0 + q * 4096 : zsrc, (lds_u8*)ring + (SLOT) * RSTRIDE + (wv + 4 * q) * 1024); \
-    }                                                                                                  \
-  }
-
-  ROMA_RB_BARRIER();  // staged tiles visible; nothing of ours in flight yet
-#pragma unroll
-  for (int r = 0; r < NR; ++r) ROMA_RB_ISSUE_ROW(r, r);
-  if (kw == KW) ROMA_RB_WAIT_VM((NR - 1) * KW); else ROMA_RB_WAIT_VM((NR - 1) * (KW - 1));
-  ROMA_RB_BARRIER();  // input row 0 landed
-
-  const int cg = tid % GC, xq = tid / GC;
-  const int xb = x0 + xq * 4;
-  const bool active = xq < XQ && xb < W;
-  const int c = cg * 4;
-  const f32x4 bx = *(lds_f32x4*)(wsm + 25 * CP + c);
-  const f32x2 bias0 = f32x2{bx[0], bx[1]}, bias1 = f32x2{bx[2], bx[3]};
-  f32x2 acc[5][4][2];
-#pragma unroll
-  for (int s5 = 0; s5 < 5; ++s5)
-#pragma unroll
-    for (int px = 0; px < 4; ++px) {
-      acc[s5][px][0] = bias0;
-      acc[s5][px][1] = bias1;
-    }
-  const unsigned ring_lds = (unsigned)(size_t)((lds_u8*)ring);
-  const unsigned rd0 = ring_lds + (unsigned)((xq * 4 * CP + c) * 2);
-  bf16_t* obase = out + ((long)b * H * W) * CP;
-
-  int slot = 0;
-#pragma nounroll
-  for (int t = 0; t < T; ++t) {
-    const int o = t - 4;  // output row (relative to ys) finished by input row t
-    if (active && !(dbg & 1)) {
-      unsigned long long cr[8];
-      const unsigned ra = rd0 + (unsigned)slot * RSTRIDE;
-      asm volatile(
-          "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:%9\n\tds_read_b64 %2, %8 offset:%10\n\t"
-          "ds_read_b64 %3, %8 offset:%11\n\tds_read_b64 %4, %8 offset:%12\n\tds_read_b64 %5, %8 offset:%13\n\t"
-          "ds_read_b64 %6, %8 offset:%14\n\tds_read_b64 %7, %8 offset:%15\n\ts_waitcnt lgkmcnt(0)"
-          : "=&v"(cr[0]), "=&v"(cr[1]), "=&v"(cr[2]), "=&v"(cr[3]), "=&v"(cr[4]), "=&v"(cr[5]), "=&v"(cr[6]), "=&v"(cr[7])
-          : "v"(ra), "n"(CP * 2), "n"(CP * 4), "n"(CP * 6), "n"(CP * 8), "n"(CP * 10), "n"(CP * 12), "n"(CP * 14)
-          : "memory");
-      // Column-major tap order: for tap column kx only the 4-wide window v[kx..kx+3] of converted inputs is live
-      // (the other columns stay packed bf16), and the 5 weights of that column are read from LDS one column ahead.
-      // The scheduling fences stop the compiler from hoisting all 25 weight reads (100 VGPRs), which spilled.
-#define ROMA_RB_CVT(J)                                                                             \
-  {                                                                                                \
-    const uint32_t lo_ = (uint32_t)cr[J], hi_ = (uint32_t)(cr[J] >> 32);                           \
-    v[J][0] = f32x2{h16_lo(lo_), h16_hi(lo_)};               \
-    v[J][1] = f32x2{h16_lo(hi_), h16_hi(hi_)};               \
-  }
-      f32x2 v[8][2];
-      ROMA_RB_CVT(0) ROMA_RB_CVT(1) ROMA_RB_CVT(2)
-      f32x4 wq[2][5];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) wq[0][k] = *(lds_f32x4*)(wsm + ((4 - k) * 5 + 0) * CP + c);
-#pragma unroll
-      for (int kx = 0; kx < 5; ++kx) {
-        if (kx < 4) {
-#pragma unroll
-          for (int k = 0; k < 5; ++k)
-            wq[(kx + 1) & 1][k] = *(lds_f32x4*)(wsm + ((4 - k) * 5 + kx + 1) * CP + c);
-        }
-        ROMA_RB_CVT(kx + 3)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {  // acc[k] holds output row t - 4 + k (tap row ky = 4 - k)
-          const f32x4 wx = wq[kx & 1][k];
-          const f32x2 w0 = f32x2{wx[0], wx[1]}, w1 = f32x2{wx[2], wx[3]};
-#pragma unroll
-          for (int px = 0; px < 4; ++px) {
-            acc[k][px][0] = v[px + kx][0] * w0 + acc[k][px][0];
-            acc[k][px][1] = v[px + kx][1] * w1 + acc[k][px][1];
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#undef ROMA_RB_CVT
-      if (o >= 0) {
-        lds_u8* xrow = Xt + (xq * 4) * XROW + cg * 8;
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-          u32x2_t u;
-          u.x = pack_bf16x2(fmaxf(acc[0][px][0][0], 0.f), fmaxf(acc[0][px][0][1], 0.f));
-          u.y = pack_bf16x2(fmaxf(acc[0][px][1][0], 0.f), fmaxf(acc[0][px][1][1], 0.f));
-          *(lds_u32x2*)(xrow + px * XROW) = u;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-          acc[k][px][0] = acc[k + 1][px][0];
-          acc[k][px][1] = acc[k + 1][px][1];
-        }
-#pragma unroll
-      for (int px = 0; px < 4; ++px) {
-        acc[4][px][0] = bias0;
-        acc[4][px][1] = bias1;
-      }
-    }
-    ROMA_RB_BARRIER();  // B2: Xt complete; every wave is done reading ring slot `slot`
-    if (!(dbg & 8)) ROMA_RB_ISSUE_ROW(t + NR, slot);  // refill it with input row t + NR (zero page beyond the strip: keeps vmcnt uniform)
-    if (o >= 0 && !(dbg & 2)) {
-      // ---------------- 1x1 convolution of output row o on MFMA, out of LDS
-      if constexpr (Cf::NBF > 0) {
-        f32x16 oa[PXB];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 bq = *(lds_f32x4*)(pbs + 32 * wv + 8 * g + 4 * hh);
-#pragma unroll
-          for (int u = 0; u < PXB; ++u)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) oa[u][4 * g + j] = bq[j];
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-          for (int u = 0; u < PXB; ++u) {
-            const u32x4_t xf = *(lds_u32x4*)(Xt + (u * 32 + l31) * XROW + ks * 32 + hh * 16);
-            oa[u] = mfma_h16_32x32x16(wown[ks],
-                                                            xf, oa[u]);
-          }
-#pragma unroll
-        for (int u = 0; u < PXB; ++u) {
-          const int pxl = u * 32 + l31;
-          if (pxl < PX) {
-            lds_u8* orow = Ot + pxl * Cf::OPIX + (32 * wv + 4 * hh) * 2;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              u32x2_t q;
-              q.x = pack_bf16x2(oa[u][4 * g + 0], oa[u][4 * g + 1]);
-              q.y = pack_bf16x2(oa[u][4 * g + 2], oa[u][4 * g + 3]);
-              *(lds_u32x2*)(orow + g * 16) = q;
-            }
-          }
-        }
-      }
-      // remainder block (channels 32*NBF ..): its pixel blocks rotate over the waves
-#pragma unroll
-      for (int pb = 0; pb < PXB; ++pb) {
-        if (((pb + o) & 3) != wv) continue;
-        int lanev = lane;  // opaque copy: keeps the (loop-invariant) LDS addresses below from being hoisted into
-        asm volatile("" : "+v"(lanev));  // long-lived registers - this kernel sits exactly at the 256-VGPR budget
-        const int l31v = lanev & 31, hhv = lanev >> 5;
-        const int wrow = l31v < Cf::TAIL ? l31v : l31v - Cf::TAIL;  // rows >= TAIL of the MFMA tile are never stored
-        f32x16 ta;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-          if (8 * g + 4 * hhv < Cf::TAIL) bq = *(lds_f32x4*)(pbs + 32 * Cf::NBF + 8 * g + 4 * hhv);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) ta[4 * g + j] = bq[j];
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const u32x4_t wf = *(lds_u32x4*)(Wt + wrow * XROW + ks * 32 + hhv * 16);
-          const u32x4_t xf = *(lds_u32x4*)(Xt + (pb * 32 + l31v) * XROW + ks * 32 + hhv * 16);
-          ta = mfma_h16_32x32x16(wf, xf,
-                                                       ta);
-        }
-        const int pxl = pb * 32 + l31v;
-        if (pxl < PX) {
-          lds_u8* orow = Ot + pxl * Cf::OPIX + (32 * Cf::NBF + 4 * hhv) * 2;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            if (8 * g + 4 * hhv < Cf::TAIL) {
-              u32x2_t q;
-              q.x = pack_bf16x2(ta[4 * g + 0], ta[4 * g + 1]);
-              q.y = pack_bf16x2(ta[4 * g + 2], ta[4 * g + 3]);
-              *(lds_u32x2*)(orow + g * 16) = q;
-            }
-          }
-        }
-      }
-    }
-    // input row t+1 must have landed: the DMA issued after it may stay in flight - rows t+2 .. t+NR, kw pieces each.  (The
-    // output stores of the last iterations are younger than that DMA as well but must not be added to the allowance: vmcnt
-    // counts loads and stores together and a store can retire before an older load - dwconv_ring.hip.)
-    if (kw == KW) ROMA_RB_WAIT_VM((NR - 1) * KW); else ROMA_RB_WAIT_VM((NR - 1) * (KW - 1));
-    ROMA_RB_BARRIER();  // B3: Ot complete, input row t+1 visible to every wave
-    if (o >= 0 && !(dbg & 4)) {
-      // stream the row out: always exactly two 16-byte stores per lane (clamped duplicates keep the count uniform)
-      const int n16 = npx * (CP * 2 / 16);
-      bf16_t* orow = obase + ((long)(ys + o) * W + x0) * CP;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int j = min(tid + 256 * it, n16 - 1);
-        const int jp = j / (CP * 2 / 16), jc = j - jp * (CP * 2 / 16);  // piece -> (pixel, 16-byte column): un-pad
-        const u32x4_t q = *(lds_u32x4*)(Ot + jp * Cf::OPIX + jc * 16);
-        *reinterpret_cast<u32x4_t*>(orow + j * 8) = q;  // (non-temporal stores: no change here - the counted waits already
-                                                         //  leave the stores of the last NR - 1 rows in flight)
-      }
-    }
-    slot = slot + 1 == NR ? 0 : slot + 1;
-  }
-  ROMA_RB_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
-}
-#undef ROMA_RB_ISSUE_ROW
+#ifdef ROMA_TOOLS_BUILD
+#include "refiner_block_2b.inc"  // refiner_block_kernel<CP>: the two-barrier A/B reference (tools builds only)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
-// C = 144 with ONE barrier per image row (the default; roma_tuning("rb144_1b", 0) keeps the kernel above for A/B).
+// C = 144 with ONE barrier per image row (roma_tuning("rb144_1b", 0) selects the two-barrier kernel of refiner_block_2b.inc in a
+// tools build, for A/B).
 //
-// The kernel above needs two barriers per row: B2 (the depthwise tile Xt is complete / the ring slot is free) and B3 (the
+// The two-barrier kernel needs two barriers per row: B2 (the depthwise tile Xt is complete / the ring slot is free) and B3 (the
 // output tile Ot is complete before the whole workgroup streams it out / the next input row has landed).  Here
 //   * Xt is double buffered: row t's 1x1 reads Xt[t & 1] while the fastest wave may already write Xt[(t + 1) & 1];
 //   * every wave stores exactly what it computed - its own 32-channel slice of the row (64 B per pixel) and, when it is its
@@ -701,22 +421,27 @@ static int launch_cp(const void* in, void* out, const float* dw_w, const float* 
   const long nb = (long)B * ((H + SY - 1) / SY) * nxg;
   ROMA_REQUIRE(nb < (1l << 30), "refiner_block: grid too large");
   const int nblocks = (int)nb;
+  dim3 grid((unsigned)(((nblocks + 7) / 8) * 8));
+#ifdef ROMA_TOOLS_BUILD
   static const int dbg = getenv("ROMA_RB_DBG") ? atoi(getenv("ROMA_RB_DBG")) : 0;  // tuning ablations only
   if (dbg & 16) {
     int nb_cu = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_cu, refiner_block_kernel<CP>, 256, 0);
     fprintf(stderr, "refiner_block<%d>: %d workgroups/CU, grid %d\n", CP, nb_cu, nblocks);
   }
-  dim3 grid((unsigned)(((nblocks + 7) / 8) * 8));
   static const int env1b = getenv("ROMA_RB144_1B") ? atoi(getenv("ROMA_RB144_1B")) : 1;
-  if (CP == 144 && (g_rb144_1b >= 0 ? g_rb144_1b : env1b) && !dbg) {
-    hipLaunchKernelGGL(refiner_block144_1b_kernel, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, dw_w, dw_b,
-                       (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks);
+  if (CP == 24 || !(g_rb144_1b >= 0 ? g_rb144_1b : env1b) || dbg) {
+    hipLaunchKernelGGL(refiner_block_kernel<CP>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, dw_w, dw_b,
+                       (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks, dbg);
     ROMA_LAUNCH_CHECK();
     return 0;
   }
-  hipLaunchKernelGGL(refiner_block_kernel<CP>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, dw_w, dw_b,
-                     (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks, dbg);
+#else
+  ROMA_REQUIRE(CP == 144, "refiner_block: C = 24 runs on the wave-private kernel only (it declined these tensors: 16-byte aligned bf16 in / out / weights are required)");
+  ROMA_REQUIRE(g_rb144_1b != 0, "refiner_block: the two-barrier A/B kernel is not part of this build (make TOOLS=1)");
+#endif
+  hipLaunchKernelGGL(refiner_block144_1b_kernel, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, dw_w, dw_b,
+                     (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks);
   ROMA_LAUNCH_CHECK();
   return 0;
 }

@@ -292,7 +292,9 @@ int g_rb24_wave = -1;  // roma_tuning("rb24w", v): 1 = this kernel for C = 24 (d
 int refiner_block24_wave_try_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
                                     const float* pw_b, int B, int H, int W, int dt, hipStream_t s) {
   static const int env = getenv("ROMA_RB24W") ? atoi(getenv("ROMA_RB24W")) : 1;
-  if (!(g_rb24_wave >= 0 ? g_rb24_wave : env)) return 1;
+#ifdef ROMA_TOOLS_BUILD
+  if (!(g_rb24_wave >= 0 ? g_rb24_wave : env)) return 1;  // A/B: the two-barrier workgroup kernel (refiner_block_2b.inc)
+#endif
   if (dt != DT_BF16 || H < 1 || W < 1 || (long)W * RBW_C * 2 >= (1l << 31)) return 1;
   if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) return 1;
   if ((reinterpret_cast<uintptr_t>(pw) & 15) != 0 || ldpw % 8 != 0) return 1;

@@ -579,7 +579,7 @@ def test_hot_gemm_kernels_do_not_spill(built_lib, bdir):
     # production instantiations only: <..., SCHED, ABL = 0> (the ABL != 0 ablation builds of tools/bench_gemm_ablation.py
     # run without their epilogue and may spill there)
     k8 = [k for k in kernel_resources.kernels(objs["gemm8p.o"]) if k["name"].startswith("gemm8p_kernel<bf16") and k["name"].endswith(", 0>")]
-    assert len(k8) >= 12
+    assert len(k8) >= 6  # six epilogues of the one shipped schedule (round 5: the quadrant-phase variants are tools-only)
     for k in k8:
         limit = 8 if ", 3, " in k["name"] else 0  # E8_RESBF16
         assert k["spill"] <= limit, k
@@ -660,7 +660,8 @@ def test_isa_audit_counted_vmcnt_waits_leave_only_loads_in_flight(built_lib, bdi
                          timeout=900)
     assert out.returncode == 0 and "AUDIT OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     dma = sum(int(m.group(1)) for m in re.finditer(r"(\d+) LDS-DMA issues", out.stdout))
-    assert dma > 1500, dma  # the audit really saw the DMA kernels (gemm.o alone has 840 issues)
+    assert dma > 900, dma  # the audit really saw the DMA kernels (the five gemm_*.o families alone have ~750 issues; round 5
+    # removed the tools-only instantiations from the shipped build: 1 900 -> 1 061)
 
 
 @pytest.mark.parametrize("bdir", BUILD_DIRS)
@@ -684,10 +685,11 @@ def test_isa_audit_no_touch_of_registers_with_asm_lds_reads_in_flight(built_lib,
     not track; the construct is only correct if nothing touches those registers before our s_waitcnt (the round-1 f32
     "carried k-group" miscompile: compiler-made v_mov copies of in-flight registers, profiles/r02_f32_carry_isa_excerpt.txt).
     tools/audit_asm_reads.py checks that in the ISA of the objects the library is linked from - on every build."""
-    objs = [os.path.join(ROOT, "roma_amd", "csrc", bdir, f) for f in ("gemm.o", "gemm8p.o", "gemm6p.o", "conv64.o")]
+    objs = [os.path.join(ROOT, "roma_amd", "csrc", bdir, f) for f in ("gemm_f32.o", "gemm_f32_conv.o", "gemm_h16.o", "gemm_h16_conv.o", "gemm_h16f32.o", "gemm8p.o", "gemm6p.o", "conv64.o")]
     if not all(os.path.exists(o) for o in objs):
         pytest.skip("object files not present (library shipped pre-built)")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_reads.py")] + objs, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and "AUDIT OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
-    assert out.stdout.count("clean") >= 59  # 45 gemm.hip + the gemm8p / gemm6p / conv64 instantiations were actually inspected
+    # the five gemm_kernel families (46 instantiations) + the gemm8p / gemm6p / conv64 kernels were actually inspected
+    assert out.stdout.count("clean") >= 50, out.stdout.count("clean")

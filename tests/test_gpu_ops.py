@@ -194,12 +194,12 @@ def test_conv3x3_implicit_gemm(lib, dt, B, H, W, Cin, Cout):
     (16384, 576, 512, 0, True),      # f32 output
     (100000, 384, 320, 1, False),    # many tiles per persistent workgroup, K = 5 tiles (odd: both LDS buffers start a tile)
 ])
-@pytest.mark.parametrize("sched", [1, 0])
+@pytest.mark.parametrize("sched", [1])
 def test_gemm8p_matches_classic_and_reference(lib, M, N, K, act, out_f32, sched):
     """Both main loops accumulate in the same k order, so the 8-phase kernel must reproduce the classic kernel BIT FOR
     BIT (any race / mis-synchronised LDS-DMA shows up as a difference); the result is also checked against f64, and the
-    8-phase launch is repeated (timing-dependent hazards).  sched: the K-loop schedule of gemm8p (1 = k-half phases, the
-    default; 0 = quadrant phases) - gemm6p shapes ignore it."""
+    8-phase launch is repeated (timing-dependent hazards).  sched: the K-loop schedule of gemm8p (1 = k-half phases; the
+    quadrant-phase schedule 0 of rounds 2-3 is compiled into tools builds only since round 5) - gemm6p shapes ignore it."""
     A, W, b = rnd(M, K, seed=1).bfloat16(), rnd(N, K, seed=2, std=K ** -0.5).bfloat16(), rnd(N, seed=3)
     Ad, Wd, bd = A.cuda(), W.cuda(), b.cuda()
     dto = F32 if out_f32 else BF16
@@ -251,7 +251,7 @@ def test_ws1x1_matches_tile_kernels_and_reference(lib, M, act):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 70, 70, 256, 512), (3, 56, 60, 128, 256), (2, 72, 70, 64, 256), (1, 108, 108, 512, 512)])
-@pytest.mark.parametrize("sched", [1, 0])
+@pytest.mark.parametrize("sched", [1])
 def test_conv3x3_gemm8p_matches_classic_and_reference(lib, B, H, W, Cin, Cout, sched):
     """3x3 implicit GEMM on the 8-phase kernel (per-tap validity masks, zero page): bitwise vs the classic kernel and
     against torch conv2d (image borders, ragged last m-tile)."""
@@ -723,22 +723,20 @@ def test_dwconv5x5_ring_repeated_launches_under_load(lib):
     assert bad == 0, f"{bad} of 200 launches differ"
 
 
-@pytest.mark.parametrize("Cp,key", [(24, b"rb24w"), (144, b"rb144_1b")])
-def test_refiner_block_repeated_launches_under_load(lib, Cp, key):
+@pytest.mark.parametrize("Cp", [24, 144])
+def test_refiner_block_repeated_launches_under_load(lib, Cp):
     """refiner_block24_wave_kernel / refiner_block144_1b_kernel order their rings with counted vmcnt waits (and one barrier
-    per row); a wrong count shows up as a timing dependent mismatch, so: 150 launches against the two-barrier workgroup
-    kernel's result while a GEMM runs on a second stream."""
+    per row); a wrong count shows up as a timing dependent mismatch, so: 150 launches while a GEMM runs on a second stream,
+    every one bit-identical to the same kernel's result on an otherwise idle GPU (rounds 3-4 compared with the two-barrier
+    workgroup kernel, which left the shipped library in round 5; test_refiner_block_fused holds the values to torch f64)."""
     B, H, W = (4, 211, 333) if Cp == 24 else (3, 150, 187)
     x = rnd(B, H, W, Cp, seed=1).to(torch.bfloat16).cuda()
     w, b = (rnd(25, Cp, seed=2, std=0.2)).cuda(), rnd(Cp, seed=3).cuda()
     pw, pb = rnd(Cp, Cp, seed=4, std=Cp ** -0.5).to(torch.bfloat16).cuda(), rnd(Cp, seed=5).cuda()
     ref = torch.empty_like(x)
-    lib.roma_tuning(key, 0)
-    try:
-        ok(lib, lib.roma_op_refiner_block(P(x), P(ref), P(w), P(b), P(pw), P(pb), B, H, W, Cp, BF16, None))
-        torch.cuda.synchronize()
-    finally:
-        lib.roma_tuning(key, -1)
+    torch.cuda.synchronize()
+    ok(lib, lib.roma_op_refiner_block(P(x), P(ref), P(w), P(b), P(pw), P(pb), B, H, W, Cp, BF16, None))
+    torch.cuda.synchronize()
     A = rnd(8192, 1024, seed=6).to(torch.bfloat16).cuda()
     Wg = rnd(1024, 1024, seed=7, std=0.03).to(torch.bfloat16).cuda()
     Cg = torch.empty((8192, 1024), device="cuda", dtype=torch.bfloat16)
@@ -780,17 +778,19 @@ def test_refiner_block_fused(lib, Cp, B, H, W):
         outs.append(out)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     out = outs[0]
-    # the default kernels (C = 24: wave-private, C = 144: one barrier per row) against the two-barrier workgroup kernel:
-    # same arithmetic, same bits
+    # the A/B variants left the shipped library in round 5 (make TOOLS=1 brings them back): asking for one fails loudly
     key = b"rb24w" if Cp == 24 else b"rb144_1b"
     lib.roma_tuning(key, 0)
     try:
-        o2 = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=torch.bfloat16)
-        ok(lib, lib.roma_op_refiner_block(P(xin), P(o2), P(wp), P(b.cuda()), P(pw.cuda()), P(pb.cuda()), B, H, W, Cp, BF16, None))
-        torch.cuda.synchronize()
+        o2 = torch.empty((B, H, W, Cp), device="cuda", dtype=torch.bfloat16)
+        rc = lib.roma_op_refiner_block(P(xin), P(o2), P(wp), P(b.cuda()), P(pw.cuda()), P(pb.cuda()), B, H, W, Cp, BF16, None)
+        if rc == 0:  # a tools build: the two-barrier kernel ran and must give the same bits
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int16), o2.view(torch.int16))
+        else:
+            assert Cp == 144 and b"TOOLS" in lib.roma_last_error()
     finally:
         lib.roma_tuning(key, -1)
-    assert torch.equal(out.view(torch.int16), o2.view(torch.int16))
     got = out.cpu().double()
     assert torch.isfinite(got).all()
     # bf16 output rounding (2^-8 relative) + the occasional 1-ulp flip of the bf16 intermediate

@@ -114,7 +114,7 @@ def audit_listing(text):
 
 
 def main(objs=None):
-    objs = objs or [os.path.join(ROOT, "roma_amd", "csrc", "build", f) for f in ("gemm.o", "gemm8p.o", "gemm6p.o", "conv64.o")]
+    objs = objs or [os.path.join(ROOT, "roma_amd", "csrc", "build", f) for f in ("gemm_f32.o", "gemm_f32_conv.o", "gemm_h16.o", "gemm_h16_conv.o", "gemm_h16f32.o", "gemm8p.o", "gemm6p.o", "conv64.o")]
     bad = 0
     for obj in objs:
         rep = audit_listing(disassemble(obj))
