@@ -42,7 +42,8 @@ int rownorm_launch(const void* in, long ld, int dt, float* norms, long M, int C,
 
 // GP Fourier basis, transposed: Ft[d, j] = cos(8*pi*(w[d,0]*x_j + w[d,1]*y_j + b[d])), j over the h x w grid
 // (row-major, x fastest); columns j >= h*w are zero.  Ft: [Dg, npad]
-int gp_basis_launch(const float* w, const float* b, float* Ft, int Dg, int h, int wdt, int npad, hipStream_t s);
+int gp_basis_launch(const float* w, const float* b, float* Ft, int Dg, int h, int wdt, int npad, hipStream_t s, int copies = 1,
+                    long stride = 0);  // copies > 1: the same basis written `copies` times, `stride` floats apart
 
 // batched square transpose (f32): out[b][j][i] = in[b][i][j], n x n with leading dim ld; batch strides default to n * ld
 int transpose_launch(const float* in, float* out, int n, long ld, int batch, hipStream_t s, long stride_in = 0, long stride_out = 0);

@@ -362,9 +362,12 @@ int rownorm_launch(const void* in, long ld, int dt, float* norms, long M, int C,
 }
 
 // ------------------------------------------------------------------ GP Fourier basis (transposed)
+// One copy per support image (blockIdx.y; copies `stride` floats apart): the GP stores F^T right behind each image's K_yy, and
+// 16 back-to-back hipMemcpyAsync of one master copy cost more launches than recomputing 0.8 M cosines per image (round 5).
 __global__ __launch_bounds__(256) void gp_basis_kernel(const float* w, const float* b, float* Ft, int Dg, int h, int wd,
-                                                       int npad) {
+                                                       int npad, long stride) {
   const long total = (long)Dg * npad;
+  float* out = Ft + (long)blockIdx.y * stride;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int j = (int)(idx % npad);
     const int d = (int)(idx / npad);
@@ -375,14 +378,15 @@ __global__ __launch_bounds__(256) void gp_basis_kernel(const float* w, const flo
       const float z = w[d * 2 + 0] * cx + w[d * 2 + 1] * cy + b[d];
       v = cosf((float)(8.0 * 3.14159265358979323846) * z);
     }
-    Ft[idx] = v;
+    out[idx] = v;
   }
 }
 
-int gp_basis_launch(const float* w, const float* b, float* Ft, int Dg, int h, int wdt, int npad, hipStream_t s) {
+int gp_basis_launch(const float* w, const float* b, float* Ft, int Dg, int h, int wdt, int npad, hipStream_t s, int copies,
+                    long stride) {
   const long total = (long)Dg * npad;
-  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 65536));
-  hipLaunchKernelGGL(gp_basis_kernel, grid, dim3(256), 0, s, w, b, Ft, Dg, h, wdt, npad);
+  dim3 grid((unsigned)std::min<long>((total + 255) / 256, 65536), (unsigned)std::max(copies, 1));
+  hipLaunchKernelGGL(gp_basis_kernel, grid, dim3(256), 0, s, w, b, Ft, Dg, h, wdt, npad, stride);
   ROMA_LAUNCH_CHECK();
   return 0;
 }

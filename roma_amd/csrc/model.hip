@@ -768,7 +768,6 @@ int gp_posterior(const void* pf, long ldf, int act_dt, int B, bool symmetric, in
   float* Kxy = (float*)AL((size_t)ndp * n * npad, 4);
   float* Linv = (float*)AL((size_t)nimg * nblk * 4096, 4);
   float* LinvT = (float*)AL((size_t)nimg * nblk * 4096, 4);
-  float* Ft = (float*)AL((size_t)512 * npad, 4);
   GP_RUN(rownorm_launch(pf, ldf, act_dt, norms, (long)nimg * n, 512, st));
   // support images actually needed: symmetric -> all, else images [B, 2B)
   const int j0 = symmetric ? 0 : B, nj = symmetric ? nimg : B;
@@ -793,9 +792,7 @@ int gp_posterior(const void* pf, long ldf, int act_dt, int B, bool symmetric, in
     g.nx = norms + (long)i0 * n; g.ny = norms + (long)s0 * n; g.sNx = n; g.sNy = n; g.inv_t = 1.0f / 0.2f;
     GP_RUN(gemm_launch(g, st));
   }
-  GP_RUN(gp_basis_launch(gp_w, gp_b, Ft, 512, th, tw, npad, st));
-  for (int j = j0; j < j0 + nj; ++j)
-    if (!dry) ROMA_CHECK_HIP(hipMemcpyAsync(Rt + (long)j * saug, Ft, (size_t)512 * npad * 4, hipMemcpyDeviceToDevice, st));
+  GP_RUN(gp_basis_launch(gp_w, gp_b, Rt + (long)j0 * saug, 512, th, tw, npad, st, nj, saug));  // F^T behind every image's K_yy
   GP_RUN(cholesky_solve_t(Kyy + (long)j0 * saug, Rt + (long)j0 * saug, LT + (long)j0 * npad * npad,
                           Linv + (long)j0 * nblk * 4096, LinvT + (long)j0 * nblk * 4096, npad, 512, nj, st, saug, saug));
   for (int half = 0; half < (symmetric ? 2 : 1); ++half) {
@@ -863,16 +860,21 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
 
   // ---- results that live across the two passes
   float* cert16_keep = (float*)AL((size_t)ndp * T, 4);
-  float* flow_p1 = (float*)AL((size_t)ndp * cfg.coarse_h * cfg.coarse_w * 2, 4);
-  float* cert_p1 = (float*)AL((size_t)ndp * cfg.coarse_h * cfg.coarse_w, 4);
+  // The flow / certainty ping-pong buffers of BOTH passes live outside the per-pass scratch: the coarse pass's finest
+  // correspondences seed the upsample pass and the last pass's feed the epilogue where they are - round 5: no device-to-device
+  // copies at the end of a pass (2 x 72 MB + 2 x 30 MB per sub-batch and call before).
   const int Hfin = cfg.upsample_preds ? cfg.upsample_h : cfg.coarse_h;
   const int Wfin = cfg.upsample_preds ? cfg.upsample_w : cfg.coarse_w;
-  float* flow_fin = flow_p1;
-  float* cert_fin = cert_p1;
-  if (cfg.upsample_preds) {
-    flow_fin = (float*)AL((size_t)ndp * Hfin * Wfin * 2, 4);
-    cert_fin = (float*)AL((size_t)ndp * Hfin * Wfin, 4);
+  float *pp_flow[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *pp_cert[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  for (int ps = 0; ps < ((cfg.upsample_preds || (fw && fw->upsample)) ? 2 : 1); ++ps) {
+    const size_t px = (size_t)ndp * (ps ? cfg.upsample_h : cfg.coarse_h) * (ps ? cfg.upsample_w : cfg.coarse_w);
+    for (int i = 0; i < 2; ++i) {
+      pp_flow[ps][i] = (float*)AL(px * 2, 4);
+      pp_cert[ps][i] = (float*)AL(px, 4);
+    }
   }
+  float *flow_p1 = nullptr, *cert_p1 = nullptr;    // finest correspondences of the coarse pass (wherever the ping-pong ended)
+  float *flow_fin = nullptr, *cert_fin = nullptr;  // ... of the last pass
 
   // shared ViT block (vit.hip): DINOv2 goes through vit_forward / roma_vit_forward below, the coordinate decoder calls the
   // block directly (f32 residual stream)
@@ -1006,11 +1008,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
     }
 
     // =============================== decoder (matcher.py:395-527)
-    float* flowA = (float*)AL((size_t)ndp * H * W * 2, 4);
-    float* flowB = (float*)AL((size_t)ndp * H * W * 2, 4);
-    float* certA = (float*)AL((size_t)ndp * H * W, 4);
-    float* certB = (float*)AL((size_t)ndp * H * W, 4);
-    float *flow = flowA, *cert = certA, *flow_alt = flowB, *cert_alt = certB;
+    float *flow = pp_flow[pass][0], *cert = pp_cert[pass][0], *flow_alt = pp_flow[pass][1], *cert_alt = pp_cert[pass][1];
     int ch = 0, cw = 0;  // current flow map size
     if (up) {
       ch = H / 8; cw = W / 8;
@@ -1196,20 +1194,16 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       }
     }
     (void)ch; (void)cw;
-    // keep the finest flow / certainty of this pass
-    float* fdst = up ? flow_fin : flow_p1;
-    float* cdst = up ? cert_fin : cert_p1;
-    if (!dry) {
-      ROMA_CHECK_HIP(hipMemcpyAsync(fdst, flow, (size_t)ndp * H * W * 2 * 4, hipMemcpyDeviceToDevice, st));
-      ROMA_CHECK_HIP(hipMemcpyAsync(cdst, cert, (size_t)ndp * H * W * 4, hipMemcpyDeviceToDevice, st));
-    }
+    // the finest flow / certainty of this pass stay where they are
+    flow_fin = flow; cert_fin = cert;
+    if (!up) { flow_p1 = flow; cert_p1 = cert; }
     arena.release(pass_mark);
   }
   if (fw) return 0;
   // =============================== epilogue (matcher.py:839-850, 891-929)
   FinalArgs fa;
-  fa.flow = cfg.upsample_preds ? flow_fin : flow_p1;
-  fa.cert = cfg.upsample_preds ? cert_fin : cert_p1;
+  fa.flow = flow_fin;
+  fa.cert = cert_fin;
   fa.cert16 = cfg.attenuate_cert ? cert16_keep : nullptr;
   fa.warp = warp_out; fa.certainty = cert_out;
   fa.B = B; fa.H = Hfin; fa.W = Wfin; fa.h16 = th; fa.w16 = tw; fa.symmetric = cfg.symmetric;
