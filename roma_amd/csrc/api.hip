@@ -450,9 +450,9 @@ int roma_op_dwconv5x5(const void* in, void* out, const float* w, const float* bi
 int roma_op_refiner_block(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw,
                           const float* pw_b, int B, int H, int W, int Cp, int dt, void* stream) {
   if (refiner_block_wide_supported(Cp, DT(dt))) {  // C = 576: the wide fused block (refiner_block_wide.hip)
-    const int rc = refiner_block_wide_try_launch(in, out, dw_w, dw_b, pw, Cp, pw_b, B, H, W, Cp, DT(dt), S(stream));
+    const int rc = refiner_block_wide_try_launch(in, out, dw_w, dw_b, pw, Cp, pw_b, B, H, W, Cp, DT(dt), S(stream), true);
     if (rc <= 0) return rc;
-    set_error("roma_op_refiner_block: the C = 576 kernel declined these tensors (16-byte aligned bf16 in / out / weights) or rb_wide is off");
+    set_error("roma_op_refiner_block: the C = 576 kernel declined these tensors (16-byte aligned bf16 in / out / weights are required)");
     return ROMA_ERR_ARG;
   }
   return refiner_block_launch(in, out, dw_w, dw_b, pw, Cp, pw_b, B, H, W, Cp, DT(dt), S(stream));

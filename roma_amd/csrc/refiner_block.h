@@ -20,7 +20,7 @@ int refiner_block24_wave_try_launch(const void* in, void* out, const float* dw_w
 // (refiner_block_wide.hip).  0 = launched, 1 = not taken (caller runs dwconv5x5 + 1x1 GEMM), < 0 = error.
 bool refiner_block_wide_supported(int Cp, int dt);
 int refiner_block_wide_try_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
-                                  const float* pw_b, int B, int H, int W, int Cp, int dt, hipStream_t s);
+                                  const float* pw_b, int B, int H, int W, int Cp, int dt, hipStream_t s, bool force = false);
 extern int g_rb_wide;
 extern int g_rb24_wave;
 extern int g_rb144_1b;

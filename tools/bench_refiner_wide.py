@@ -52,11 +52,14 @@ def run(B, H, W, Cp, reps):
         assert lib.roma_op_gemm(P(t), Cp, P(pw), Cp, P(y2), Cp, M, Cp, Cp, 1, 0, 0, 0, P(pb), None, None, 0, 0, 1.0, BF16, BF16, None) == 0
 
     us_f = timed(fused, reps)
+    lib.roma_tuning(b"rb_wide", 2)  # the stencil as pairs of v_fma_f32 instead of v_pk_fma_f32
+    us_f2 = timed(fused, reps)
+    lib.roma_tuning(b"rb_wide", -1)
     us_d, us_p = timed(dw, reps), timed(pwc, reps)
     diff = (y1.float() - y2.float()).abs()
     same = float((y1.view(torch.int16) == y2.view(torch.int16)).float().mean())
     fl = 2.0 * M * Cp * Cp
-    print(f"B{B} {H}x{W} C={Cp}: fused {us_f:8.1f} us ({fl / us_f * 1e-6:6.0f} TFLOP/s of the 1x1, {4.0 * M * Cp / us_f * 1e-6:5.2f} TB/s in+out) | "
+    print(f"B{B} {H}x{W} C={Cp}: fused {us_f:8.1f} us [scalar-FMA stencil {us_f2:8.1f}] ({fl / us_f * 1e-6:6.0f} TFLOP/s of the 1x1, {4.0 * M * Cp / us_f * 1e-6:5.2f} TB/s in+out) | "
           f"dwconv {us_d:7.1f} + 1x1 {us_p:7.1f} = {us_d + us_p:8.1f} us | x{(us_d + us_p) / us_f:5.2f} | "
           f"identical bf16 {100 * same:6.2f} %, max |diff| {float(diff.max()):.3g} (|y| max {float(y2.float().abs().max()):.3g})", flush=True)
 
