@@ -105,6 +105,9 @@ int roma_set_tensor(roma_handle_t h, const char* name, int ndim, const int64_t* 
 int roma_finalize(roma_handle_t h);
 /* mutable attributes of RegressionMatcher (README.md:82-90): "symmetric", "upsample_preds", "attenuate_cert", "debug";
  * tuning: "fuse_refiner_blocks" (default 1; 0 = separate dwconv + GEMM kernels at every scale),
+ *         "compose_out_conv" (default 1: the last ConvRefiner block's 1x1 convolution and out_conv - two linear maps with
+ *         nothing in between, matcher.py:92-122, 175-178 - are evaluated as the ONE C -> 3 map composed at roma_finalize;
+ *         0 = the reference's two steps.  The results differ by rounding only),
  *         "vit_bf16_residual" (bf16 mode only, default 1: DINOv2 residual stream in bf16 like the reference's bf16
  *         backbone, encoders.py; 0 = keep it in f32),
  *         "streams" (1..4, default 2) / "dual_stream" (1 = 2 streams, 0 = 1): run a batch of >= 2 pairs as sub-batches on

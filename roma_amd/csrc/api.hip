@@ -135,6 +135,7 @@ int roma_set_option(roma_handle_t h, const char* key, int value) {
   } else if (k == "attenuate_cert") h->m.cfg.attenuate_cert = value ? 1 : 0;
   else if (k == "debug") h->m.debug = value != 0;
   else if (k == "fuse_refiner_blocks") h->m.fuse_refiner_blocks = value != 0;
+  else if (k == "compose_out_conv") h->m.compose_out_conv = value != 0;
   else if (k == "vit_bf16_residual") h->m.vit_bf16_residual = value != 0;
   else if (k == "dual_stream") h->m.n_streams = value != 0 ? 2 : 1;
   else if (k == "trace") h->m.trace_on = value != 0;

@@ -2,6 +2,8 @@
 // workspace (bump arena, planned by a dry run - no allocation inside roma_match) and the
 // kernel schedule of RegressionMatcher.match() (romatch/models/matcher.py:779-934).
 #pragma once
+#include <stdlib.h>
+
 #include <map>
 #include <mutex>
 #include <string>
@@ -50,6 +52,9 @@ struct RefinerW {
   float* dw_b[9] = {nullptr};
   Lin pw[9];
   float *out_w = nullptr, *out_b = nullptr;  // [3][Cp], [3]
+  // out_conv composed with the LAST block's 1x1 (two linear maps with nothing in between, matcher.py:92-122, 175-178):
+  // oc_w = out_w . pw[8] ([3][Cp], f32), oc_b = out_w . pw[8].b + out_b - the last block then needs no C x C GEMM at all
+  float *oc_w = nullptr, *oc_b = nullptr;
 };
 
 class Arena {
@@ -82,6 +87,10 @@ class Model {
   int (*peer_vit_forward)(const roma_vit_args_t*, void*) = nullptr;
   bool finalized = false;
   bool debug = false;
+  // The last ConvRefiner block's 1x1 convolution and out_conv are composed into ONE C -> 3 map at pack time (option
+  // "compose_out_conv", default 1): 1/9 of the refiners' 1x1 GEMM work and one pass over the block output disappear; the
+  // result differs from the two-step evaluation only by rounding (the 16-bit modes no longer round the dropped intermediate)
+  bool compose_out_conv = !(getenv("ROMA_COMPOSE_OUT") && atoi(getenv("ROMA_COMPOSE_OUT")) == 0);  // env: A/B runs
   bool fuse_refiner_blocks = true;  // bf16 mode: fused dw5x5+1x1 kernel at the narrow scales (option "fuse_refiner_blocks")
   // bf16 mode: DINOv2's residual stream in bf16, like the reference's bf16 backbone (encoders.py: dinov2 weights and
   // input are cast to amp_dtype); the decoder transformer keeps f32 (autocast leaves its residual f32).  Option

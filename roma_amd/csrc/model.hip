@@ -478,6 +478,30 @@ int Model::pack_weights() {
       memcpy(&ow[(size_t)o * r.Cp], &H(p + ".out_conv.weight")[(size_t)o * r.C], (size_t)r.C * sizeof(float));
     if (int rc = upload_f32(ow, &r.out_w)) return rc;
     if (int rc = upload_f32(H(p + ".out_conv.bias"), &r.out_b)) return rc;
+    {  // out_conv o (last block's 1x1): d -> out_w (pw8 d + b8) + out_b = (out_w pw8) d + (out_w b8 + out_b), accumulated in f64.
+      // pw8 enters as the kernels would see it (rounded to the 16-bit storage format in those modes, like autocast's weight cast)
+      const std::string bp = p + ".hidden_blocks.7";
+      const auto& pw8 = H(bp + ".3.weight");
+      const auto& pb8 = H(bp + ".3.bias");
+      const auto& ob = H(p + ".out_conv.bias");
+      std::vector<float> cw((size_t)3 * r.Cp, 0.f), cb(4, 0.f);
+      for (int o = 0; o < 3; ++o) {
+        for (int k = 0; k < r.C; ++k) {
+          double acc = 0.0;
+          for (int n = 0; n < r.C; ++n) {
+            float wv = pw8[(size_t)n * r.C + k];
+            if (act_dt != DT_F32) wv = bf16_to_f32(f32_to_bf16(wv));
+            acc += (double)ow[(size_t)o * r.Cp + n] * (double)wv;
+          }
+          cw[(size_t)o * r.Cp + k] = (float)acc;
+        }
+        double accb = (double)ob[o];
+        for (int n = 0; n < r.C; ++n) accb += (double)ow[(size_t)o * r.Cp + n] * (double)pb8[n];
+        cb[o] = (float)accb;
+      }
+      if (int rc = upload_f32(cw, &r.oc_w)) return rc;
+      if (int rc = upload_f32(cb, &r.oc_b)) return rc;
+    }
   }
   return 0;
 }
@@ -1149,7 +1173,16 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         // (Running the nine-block chain over GROUPS of pairs whose ping-pong buffers fit the 256 MiB Infinity Cache was
         // measured in round 3 and is slower: 97.4 ms/step whole batch, 98.6 / 99.3 / 101.3 with 400 / 200 / 100 MiB
         // groups - the smaller launches lose more than the cache hits win, profiles/r03_v1_ab_attn_map_refiner_groups.log.)
+        bool composed = false;
         for (int b = 0; b < 9; ++b) {
+          if (b == 8 && compose_out_conv && !fused) {  // (narrow scales keep the fused block: a generic dwconv + out pass is slower there)
+            // last block: depthwise + BN + ReLU only; its 1x1 lives inside the composed out_conv (RefinerW::oc_w)
+            RUN(dwconv5x5_launch(dcur, dalt, r.dw_w[b], r.dw_b[b], ndp, hs, ws, r.Cp, act_dt, st));
+            std::swap(dcur, dalt);
+            if (int rc = CK(tp + "_dw" + std::to_string(b), dcur, (size_t)M * r.Cp * esz)) return rc;
+            composed = true;
+            break;
+          }
           if (fused) {  // narrow scales: dw5x5 + 1x1 in one pass over HBM (refiner_block.hip)
             RUN(refiner_block_launch(dcur, dalt, r.dw_w[b], r.dw_b[b], r.pw[b].w, r.pw[b].ldw, r.pw[b].b, ndp, hs, ws,
                                      r.Cp, act_dt, st));
@@ -1177,7 +1210,8 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           if (int rc = CK(tp + "_blk" + std::to_string(b), dcur, (size_t)M * r.Cp * esz)) return rc;
         }
         const float sx = (float)ins / (4.0f * (float)W), sy = (float)ins / (4.0f * (float)H);
-        RUN(refiner_out_launch(dcur, r.Cp, act_dt, r.out_w, r.out_b, flow, cert, M, r.Cp, sx, sy, st));
+        RUN(refiner_out_launch(dcur, r.Cp, act_dt, composed ? r.oc_w : r.out_w, composed ? r.oc_b : r.out_b, flow, cert, M, r.Cp,
+                               sx, sy, st));
         if (int rc = CK(tp + "_flow", flow, (size_t)M * 2 * 4)) return rc;
         if (int rc = CK(tp + "_cert", cert, (size_t)M * 4)) return rc;
       }

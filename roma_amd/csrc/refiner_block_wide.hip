@@ -380,7 +380,7 @@ bool refiner_block_wide_supported(int Cp, int dt) { return dt == DT_BF16 && Cp =
 // 0 = launched, 1 = not taken (the caller runs dwconv5x5 + GEMM), < 0 = error
 int refiner_block_wide_try_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
                                   const float* pw_b, int B, int H, int W, int Cp, int dt, hipStream_t s, bool force) {
-  static const int env = getenv("ROMA_RB_WIDE") ? atoi(getenv("ROMA_RB_WIDE")) : 1;
+  static const int env = getenv("ROMA_RB_WIDE") ? atoi(getenv("ROMA_RB_WIDE")) : 0;  // measured slower than dwconv5x5 + ws1x1 (1 306 vs 978 us): off
   if (!force && !(g_rb_wide >= 0 ? g_rb_wide : env)) return 1;
   if (!refiner_block_wide_supported(Cp, dt) || H < 1 || W < 1 || B < 1) return 1;
   if ((long)H * W * Cp * 2 >= (1l << 32)) return 1;  // 32-bit byte offsets inside an image

@@ -119,6 +119,9 @@ class RegressionMatcher:
         # single-stream schedule: tests/test_gpu_match.py::test_stream_split_*).  False = one stream, half the workspace
         self.dual_stream = True
         self.trace = False  # tests / tools only: per-stage output checksums (debug_trace)
+        # the last ConvRefiner block's 1x1 and out_conv evaluated as one composed C -> 3 map (linear o linear; include/roma_hip.h
+        # "compose_out_conv"); False = the reference's two steps (results differ by rounding only)
+        self.compose_out_conv = os.environ.get("ROMA_COMPOSE_OUT", "1") != "0"
         self._weights = weights
         self._dinov2_weights = dinov2_weights
         self._handle = None
@@ -279,7 +282,7 @@ class RegressionMatcher:
                              "use one matcher (one handle) per GPU")
         self._ensure_handle(call_hw)
         lib = self._lib
-        for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug", "vit_bf16_residual", "dual_stream", "trace"):
+        for k in ("symmetric", "upsample_preds", "attenuate_cert", "debug", "vit_bf16_residual", "dual_stream", "trace", "compose_out_conv"):
             _lib.check(lib.roma_set_option(self._handle, k.encode(), int(bool(getattr(self, k)))), lib=lib)
         _lib.check(lib.roma_set_option_f(self._handle, b"coarse_scale_factor", float(scale_factor)), lib=lib)
         B = a.shape[0]
@@ -334,7 +337,7 @@ class RegressionMatcher:
         if b > self.max_batch:
             raise ValueError(f"forward: batch {b} > max_batch {self.max_batch}")
         lib = self._lib
-        for k in ("debug", "vit_bf16_residual", "trace"):
+        for k in ("debug", "vit_bf16_residual", "trace", "compose_out_conv"):
             _lib.check(lib.roma_set_option(self._handle, k.encode(), int(bool(getattr(self, k)))), lib=lib)
         bd = 2 * b if symmetric else b
         fa = _lib.RomaForwardArgs()

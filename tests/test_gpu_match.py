@@ -423,3 +423,25 @@ def test_forward_apis_vs_reference_golden(tiny_model):
     assert float((fu[8].float().cpu() - torch.from_numpy(g["feat_up8"])).abs().max()) < 1e-4 * max(1.0, float(np.abs(g["feat_up8"]).max()))
     with pytest.raises(ValueError):
         m.forward({"im_A": d["im_A_high_res"], "im_B": d["im_B_high_res"]}, upsample=True)  # no batch["corresps"]
+
+
+def test_composed_out_conv_equals_the_two_step_evaluation(tiny_model):
+    """The last ConvRefiner block ends in a 1x1 convolution and is followed directly by out_conv (matcher.py:92-122, 175-178):
+    two linear maps with nothing in between.  The library evaluates them as ONE C -> 3 map composed at roma_finalize (wide
+    scales; option "compose_out_conv", default on) - 1/9 of the refiners' 1x1 GEMM work disappears.  In f32 the composed and the
+    two-step evaluation agree to rounding (and both sit at 1e-6 of the reference golden, test_tiny_match_vs_reference_golden)."""
+    from roma_amd import synthetic
+    m = tiny_model
+    d = _to_dev(synthetic.make_inputs(1, 112, 168, seed=1))
+    kw = dict(im_A_high_res=d["im_A_high_res"], im_B_high_res=d["im_B_high_res"])
+    assert m.compose_out_conv
+    w1, c1 = m.match(d["im_A"], d["im_B"], **kw)
+    m.compose_out_conv = False
+    try:
+        w0, c0 = m.match(d["im_A"], d["im_B"], **kw)
+    finally:
+        m.compose_out_conv = True
+    dw, dc = float((w1 - w0).abs().max()), float((c1 - c0).abs().max())
+    print(f"composed vs two-step out_conv (f32): max|dwarp| = {dw:.2e}, max|dcert| = {dc:.2e}")
+    assert dw < 2e-6 and dc < 2e-5
+    assert not torch.equal(c1, c0)  # the switch really selects another evaluation order
