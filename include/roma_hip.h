@@ -250,6 +250,14 @@ int roma_op_dwconv5x5(const void* in, void* out, const float* w, const float* bi
  * workgroup); in/out [B,H,W,Cp] must not alias; pw bf16 [Cp][Cp], pw_b f32 [Cp]. */
 int roma_op_refiner_block(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw,
                           const float* pw_b, int B, int H, int W, int Cp, int dt, void* stream);
+/* The LAST block of a narrow ConvRefiner with its 1x1 composed with out_conv (two linear maps back to back, matcher.py:92-122,
+ * 175-178; "compose_out_conv"): delta[pixel] = {d flow x, d flow y, d certainty, 0} (f32 [B*H*W][4]) instead of a block output.
+ * pw_final: 16-bit [8][Cp], rows 0-2 = 16-bit head and rows 4-6 = 16-bit remainder of the composed [3][Cp] weights (rows 3, 7
+ * zero); bias_final f32 [Cp] (composed bias in [0, 3), zeros behind).  bf16 / f16 only, Cp in {24, 144}. */
+int roma_op_refiner_block_final(const void* in, float* delta, const float* dw_w, const float* dw_b, const void* pw_final,
+                                const float* bias_final, int B, int H, int W, int Cp, int dt, void* stream);
+/* flow[i] += (sx, sy) * delta[i].xy, cert[i] += delta[i].z (the deltas above; flow [M][2], cert [M], f32) */
+int roma_op_refiner_apply_delta(const float* delta, float* flow, float* cert, long M, float sx, float sy, void* stream);
 /* Gaussian KDE of sampled matches (romatch/utils/kde.py:4-12; RegressionMatcher.sample, matcher.py:598-629):
  * density[i] = sum_j exp(-|x_i - x_{j*down}|^2 / (2 std^2)), x: DEVICE [n,4] f32.  half_inputs != 0 rounds the
  * coordinates to fp16 first (the reference's x.half()); accumulation is f32. */

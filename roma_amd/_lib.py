@@ -75,6 +75,8 @@ SIGNATURES = {
     "roma_op_refiner_input": (_i, [_vp, _l, _vp, _vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "roma_op_dwconv5x5": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "roma_op_refiner_block": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "roma_op_refiner_block_final": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "roma_op_refiner_apply_delta": (_i, [_vp, _vp, _vp, _l, _f, _f, _vp]),
     "roma_op_kde": (_i, [_vp, _l, _i, _f, _i, _vp, _vp]),
     "roma_op_sample_warp_at": (_i, [_vp, _vp, _i, _i, _vp, _l, _vp, _vp, _vp]),
     "roma_op_mutual_nn": (_i, [_vp, _l, _vp, _l, _vp, _f, _f, _vp, _vp, _vp, _vp]),

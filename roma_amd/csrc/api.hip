@@ -459,6 +459,17 @@ int roma_op_refiner_block(const void* in, void* out, const float* dw_w, const fl
   return refiner_block_launch(in, out, dw_w, dw_b, pw, Cp, pw_b, B, H, W, Cp, DT(dt), S(stream));
 }
 
+int roma_op_refiner_block_final(const void* in, float* delta, const float* dw_w, const float* dw_b, const void* pw_final,
+                                const float* bias_final, int B, int H, int W, int Cp, int dt, void* stream) {
+  ROMA_REQUIRE(in && delta && dw_w && dw_b && pw_final && bias_final, "roma_op_refiner_block_final: null pointer");
+  return refiner_block_final_launch(in, delta, dw_w, dw_b, pw_final, Cp, bias_final, B, H, W, Cp, DT(dt), S(stream));
+}
+
+int roma_op_refiner_apply_delta(const float* delta, float* flow, float* cert, long M, float sx, float sy, void* stream) {
+  ROMA_REQUIRE(delta && flow && cert && M >= 0, "roma_op_refiner_apply_delta: null pointer");
+  return refiner_apply_delta_launch(delta, flow, cert, M, sx, sy, S(stream));
+}
+
 int roma_op_kde(const float* x, long n, int down, float std, int half_inputs, float* density, void* stream) {
   return kde_launch(x, n, down, std, half_inputs, density, S(stream));
 }

@@ -86,6 +86,8 @@ extern int g_dw_ring;
 // out_conv (C->3, f32) fused with the flow / certainty update (matcher.py:177-178, 496-506)
 int refiner_out_launch(const void* d, long ldd, int dt, const float* w /*[3][Cp]*/, const float* b /*[3]*/,
                        float* flow, float* cert, long M, int Cp, float sx, float sy, hipStream_t s);
+// flow[i] += (sx, sy) * delta[i].xy, cert[i] += delta[i].z (delta [M][4] f32: the FINAL refiner blocks, refiner_block.h)
+int refiner_apply_delta_launch(const float* delta, float* flow, float* cert, long M, float sx, float sy, hipStream_t s);
 
 // bilinear resize, align_corners=False, channels-last small-channel maps (nc = 1 or 2), f32
 int resize_bilinear_launch(const float* in, float* out, int B, int Hin, int Win, int Hout, int Wout, int nc,

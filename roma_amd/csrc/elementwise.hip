@@ -1274,6 +1274,27 @@ __global__ __launch_bounds__(256) void refiner_out_row_kernel(const bf16_t* d, l
   }
 }
 
+// flow / certainty += the per-pixel deltas the FINAL refiner blocks wrote (refiner_block.h): flow [M][2], cert [M], delta [M][4]
+__global__ __launch_bounds__(256) void refiner_apply_delta_kernel(const f32x4* __restrict__ delta, float* __restrict__ flow,
+                                                                  float* __restrict__ cert, long M, float sx, float sy) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < M; i += (long)gridDim.x * 256) {
+    const f32x4 d = delta[i];
+    f32x2 f = *reinterpret_cast<const f32x2*>(flow + 2 * i);
+    f[0] += sx * d[0];
+    f[1] += sy * d[1];
+    *reinterpret_cast<f32x2*>(flow + 2 * i) = f;
+    cert[i] += d[2];
+  }
+}
+
+int refiner_apply_delta_launch(const float* delta, float* flow, float* cert, long M, float sx, float sy, hipStream_t s) {
+  ROMA_REQUIRE((reinterpret_cast<uintptr_t>(delta) & 15) == 0 && (reinterpret_cast<uintptr_t>(flow) & 7) == 0, "refiner_apply_delta: alignment");
+  const long nb = std::min<long>((M + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(refiner_apply_delta_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const f32x4*)delta, flow, cert, M, sx, sy);
+  ROMA_LAUNCH_CHECK();
+  return 0;
+}
+
 int refiner_out_launch(const void* d, long ldd, int dt, const float* w, const float* b, float* flow, float* cert,
                        long M, int Cp, float sx, float sy, hipStream_t s) {
   ROMA_REQUIRE(Cp % 4 == 0 && ldd % 4 == 0, "refiner_out: channel padding must be a multiple of 4");

@@ -55,6 +55,10 @@ struct RefinerW {
   // out_conv composed with the LAST block's 1x1 (two linear maps with nothing in between, matcher.py:92-122, 175-178):
   // oc_w = out_w . pw[8] ([3][Cp], f32), oc_b = out_w . pw[8].b + out_b - the last block then needs no C x C GEMM at all
   float *oc_w = nullptr, *oc_b = nullptr;
+  // the same for the FINAL form of the fused narrow blocks (refiner_block.h): 16-bit [8][Cp], rows 0-2 head / 4-6 remainder of
+  // oc_w, and the composed bias zero-padded to [Cp]
+  void* ocf_w = nullptr;
+  float* ocf_b = nullptr;
 };
 
 class Arena {

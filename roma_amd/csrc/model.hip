@@ -501,6 +501,20 @@ int Model::pack_weights() {
       }
       if (int rc = upload_f32(cw, &r.oc_w)) return rc;
       if (int rc = upload_f32(cb, &r.oc_b)) return rc;
+      if (act_dt != DT_F32) {  // head + remainder split for the MFMA of the FINAL fused blocks
+        std::vector<float> hl((size_t)8 * r.Cp, 0.f), fb((size_t)r.Cp, 0.f);
+        for (int o = 0; o < 3; ++o) {
+          for (int k = 0; k < r.Cp; ++k) {
+            const float wv = cw[(size_t)o * r.Cp + k];
+            const float hi = bf16_to_f32(f32_to_bf16(wv));
+            hl[(size_t)o * r.Cp + k] = hi;
+            hl[(size_t)(4 + o) * r.Cp + k] = wv - hi;  // (rounded to 16 bits by upload_act)
+          }
+          fb[o] = cb[o];
+        }
+        if (int rc = upload_act(hl, &r.ocf_w)) return rc;
+        if (int rc = upload_f32(fb, &r.ocf_b)) return rc;
+      }
     }
   }
   return 0;
@@ -1173,9 +1187,20 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         // (Running the nine-block chain over GROUPS of pairs whose ping-pong buffers fit the 256 MiB Infinity Cache was
         // measured in round 3 and is slower: 97.4 ms/step whole batch, 98.6 / 99.3 / 101.3 with 400 / 200 / 100 MiB
         // groups - the smaller launches lose more than the cache hits win, profiles/r03_v1_ab_attn_map_refiner_groups.log.)
-        bool composed = false;
+        bool composed = false, final_done = false;
         for (int b = 0; b < 9; ++b) {
-          if (b == 8 && compose_out_conv && !fused) {  // (narrow scales keep the fused block: a generic dwconv + out pass is slower there)
+          if (b == 8 && compose_out_conv && fused) {
+            // narrow scales: the FINAL form of the fused block - depthwise + the composed C -> 3 map on the MFMA, 16 bytes of
+            // deltas per pixel instead of a block output, then one small pass that adds them to flow / certainty
+            float* delta = (float*)AL((size_t)M * 4, 4);
+            RUN(refiner_block_final_launch(dcur, delta, r.dw_w[b], r.dw_b[b], r.ocf_w, r.Cp, r.ocf_b, ndp, hs, ws, r.Cp, act_dt, st));
+            const float sxf = (float)ins / (4.0f * (float)W), syf = (float)ins / (4.0f * (float)H);
+            RUN(refiner_apply_delta_launch(delta, flow, cert, M, sxf, syf, st));
+            composed = true;
+            final_done = true;
+            break;
+          }
+          if (b == 8 && compose_out_conv && !fused) {  // wide scales: depthwise kernel, then out_conv with the composed weights
             // last block: depthwise + BN + ReLU only; its 1x1 lives inside the composed out_conv (RefinerW::oc_w)
             RUN(dwconv5x5_launch(dcur, dalt, r.dw_w[b], r.dw_b[b], ndp, hs, ws, r.Cp, act_dt, st));
             std::swap(dcur, dalt);
@@ -1210,8 +1235,9 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           if (int rc = CK(tp + "_blk" + std::to_string(b), dcur, (size_t)M * r.Cp * esz)) return rc;
         }
         const float sx = (float)ins / (4.0f * (float)W), sy = (float)ins / (4.0f * (float)H);
-        RUN(refiner_out_launch(dcur, r.Cp, act_dt, composed ? r.oc_w : r.out_w, composed ? r.oc_b : r.out_b, flow, cert, M, r.Cp,
-                               sx, sy, st));
+        if (!final_done)
+          RUN(refiner_out_launch(dcur, r.Cp, act_dt, composed ? r.oc_w : r.out_w, composed ? r.oc_b : r.out_b, flow, cert, M, r.Cp,
+                                 sx, sy, st));
         if (int rc = CK(tp + "_flow", flow, (size_t)M * 2 * 4)) return rc;
         if (int rc = CK(tp + "_cert", cert, (size_t)M * 4)) return rc;
       }

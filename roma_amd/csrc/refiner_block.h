@@ -15,7 +15,12 @@ int refiner_block_launch(const void* in, void* out, const float* dw_w, const flo
                          const float* pw_b, int B, int H, int W, int Cp, int dt, hipStream_t s);
 // C = 24 only: the wave-private form (refiner_block24w.hip); 0 = launched, 1 = not taken (caller uses the workgroup kernel)
 int refiner_block24_wave_try_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
-                                    const float* pw_b, int B, int H, int W, int dt, hipStream_t s);
+                                    const float* pw_b, int B, int H, int W, int dt, hipStream_t s, float* delta = nullptr);
+// The LAST block of a narrow ConvRefiner (Cp = 24 / 144) with its 1x1 composed with out_conv (matcher.py:92-122, 175-178: two
+// linear maps back to back): writes delta[pixel] = {d flow x, d flow y, d certainty, 0} instead of a block output.
+// pw_final: 16-bit [8][ldpw], rows 0-2 = head, rows 4-6 = 16-bit remainder of the composed [3][Cp] weights; bias_final f32 [Cp].
+int refiner_block_final_launch(const void* in, float* delta, const float* dw_w, const float* dw_b, const void* pw_final, long ldpw,
+                               const float* bias_final, int B, int H, int W, int Cp, int dt, hipStream_t s);
 // C = 576 (the stride-4 ConvRefiner, both passes): the whole block in one kernel with all 576 output channels per workgroup
 // (refiner_block_wide.hip).  0 = launched, 1 = not taken (caller runs dwconv5x5 + 1x1 GEMM), < 0 = error.
 bool refiner_block_wide_supported(int Cp, int dt);

@@ -103,11 +103,16 @@ constexpr int RB1_NR = 3;
 constexpr int RB1_XT = RBCfg<144>::PXB * 32 * RBCfg<144>::XROW;
 static_assert(RBCfg<144>::WORK_BYTES + RB1_XT + RB1_NR * RBCfg<144>::RSTRIDE <= 80 * 1024, "two workgroups per CU");
 
+// FINAL (round 5): the last block of a ConvRefiner, its 1x1 composed with out_conv (see refiner_block24w.hip): `pw` holds 8 rows
+// (rows 0-2 head, rows 4-6 remainder of the composed C -> 3 weights), `pwb` the composed bias in [0, 3); the wave whose turn it
+// is (o & 3) runs ONE chain of 9 MFMAs per row and writes delta[pixel] = {d flow x, d flow y, d certainty, 0} - no Ot, no
+// 288-byte row stores, no remainder block.
+template <bool FINAL>
 __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
                                                                      const float* __restrict__ dww, const float* __restrict__ dwb,
                                                                      const bf16_t* __restrict__ pw, long ldpw,
                                                                      const float* __restrict__ pwb, int B, int H, int W, int SY,
-                                                                     int nxg, int nblocks) {
+                                                                     int nxg, int nblocks, f32x4* __restrict__ delta) {
   constexpr int CP = 144;
   typedef RBCfg<CP> Cf;
   constexpr int GC = Cf::GC, XQ = Cf::XQ, PX = Cf::PX, KS = Cf::KS, NR = RB1_NR, KW = Cf::KW;
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
       }
     }
     if (tid < GC) *(lds_f32x4*)(pbs + tid * 4) = *reinterpret_cast<const f32x4*>(pwb + tid * 4);
-    constexpr int wslots = Cf::TAIL * (XROW / 16);
+    constexpr int wslots = FINAL ? 0 : Cf::TAIL * (XROW / 16);  // (FINAL: `pw` has 8 rows only, and no remainder block)
     for (int i = tid; i < wslots; i += 256) {
       const int n = i / (XROW / 16), sl = i - n * (XROW / 16);
       u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
@@ -162,8 +167,14 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
   }
   u32x4_t wown[KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-    wown[ks] = *reinterpret_cast<const u32x4_t*>(pw + (long)(32 * wv + l31) * ldpw + ks * 16 + hh * 8);
+  for (int ks = 0; ks < KS; ++ks) {
+    if constexpr (FINAL) {
+      wown[ks] = u32x4_t{0u, 0u, 0u, 0u};
+      if (l31 < 8) wown[ks] = *reinterpret_cast<const u32x4_t*>(pw + (long)l31 * ldpw + ks * 16 + hh * 8);
+    } else {
+      wown[ks] = *reinterpret_cast<const u32x4_t*>(pw + (long)(32 * wv + l31) * ldpw + ks * 16 + hh * 8);
+    }
+  }
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wown[ks]));
 
@@ -311,6 +322,25 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
       int lanev = lane;  // opaque copy: keeps loop-invariant addresses from being hoisted into long-lived registers
       asm volatile("" : "+v"(lanev));
       const int l31v = lanev & 31, hhv = lanev >> 5;
+      if constexpr (FINAL) {
+        if ((o & 3) == wv) {  // wave-uniform: the rows of a strip take turns
+          f32x16 oa;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+            if (g == 0 && hhv == 0) bq = *(lds_f32x4*)(pbs);  // composed bias in rows 0-2 (row 3 is zero)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oa[4 * g + j] = bq[j];
+          }
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const u32x4_t xf = *(lds_u32x4*)(Xt + l31v * XROW + ks * 32 + hhv * 16);
+            oa = mfma_h16_32x32x16(wown[ks], xf, oa);
+          }
+          const float d0 = oa[0] + __shfl_xor(oa[0], 32), d1 = oa[1] + __shfl_xor(oa[1], 32), d2 = oa[2] + __shfl_xor(oa[2], 32);
+          if (hhv == 0 && l31v < npx) delta[((long)b * H + ys + o) * W + x0 + l31v] = f32x4{d0, d1, d2, 0.f};
+        }
+      } else {
       {
         f32x16 oa;
 #pragma unroll
@@ -384,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
         *reinterpret_cast<u32x4_t*>(orow_g + jp * (CP * 2) + cb + jc * 16) = q;
       }
     }
+      }
     slot = slot + 1 == NR ? 0 : slot + 1;
   }
   ROMA_RB_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
@@ -399,7 +430,7 @@ bool refiner_block_supported(int Cp, int dt) { return dt == DT_BF16 && (Cp == 24
 
 template <int CP>
 static int launch_cp(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
-                     const float* pw_b, int B, int H, int W, hipStream_t s) {
+                     const float* pw_b, int B, int H, int W, hipStream_t s, float* delta = nullptr) {
   typedef RBCfg<CP> Cf;
   const int nxg = (W + Cf::PX - 1) / Cf::PX;
   // strip height: SY + 4 input rows are read per strip (and ~2 more rows' worth of pipeline fill), and the 512 resident
@@ -430,7 +461,7 @@ static int launch_cp(const void* in, void* out, const float* dw_w, const float* 
     fprintf(stderr, "refiner_block<%d>: %d workgroups/CU, grid %d\n", CP, nb_cu, nblocks);
   }
   static const int env1b = getenv("ROMA_RB144_1B") ? atoi(getenv("ROMA_RB144_1B")) : 1;
-  if (CP == 24 || !(g_rb144_1b >= 0 ? g_rb144_1b : env1b) || dbg) {
+  if (!delta && (CP == 24 || !(g_rb144_1b >= 0 ? g_rb144_1b : env1b) || dbg)) {
     hipLaunchKernelGGL(refiner_block_kernel<CP>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, dw_w, dw_b,
                        (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks, dbg);
     ROMA_LAUNCH_CHECK();
@@ -440,8 +471,12 @@ static int launch_cp(const void* in, void* out, const float* dw_w, const float* 
   ROMA_REQUIRE(CP == 144, "refiner_block: C = 24 runs on the wave-private kernel only (it declined these tensors: 16-byte aligned bf16 in / out / weights are required)");
   ROMA_REQUIRE(g_rb144_1b != 0, "refiner_block: the two-barrier A/B kernel is not part of this build (make TOOLS=1)");
 #endif
-  hipLaunchKernelGGL(refiner_block144_1b_kernel, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, dw_w, dw_b,
-                     (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks);
+  if (delta)
+    hipLaunchKernelGGL(refiner_block144_1b_kernel<true>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)nullptr, dw_w, dw_b,
+                       (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks, (f32x4*)delta);
+  else
+    hipLaunchKernelGGL(refiner_block144_1b_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, dw_w, dw_b,
+                       (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, nblocks, (f32x4*)nullptr);
   ROMA_LAUNCH_CHECK();
   return 0;
 }
@@ -459,6 +494,27 @@ int refiner_block_launch(const void* in, void* out, const float* dw_w, const flo
     return launch_cp<24>(in, out, dw_w, dw_b, pw, ldpw, pw_b, B, H, W, s);
   }
   return launch_cp<144>(in, out, dw_w, dw_b, pw, ldpw, pw_b, B, H, W, s);
+}
+
+// The last block of a ConvRefiner with its 1x1 composed with out_conv: pw_final [8][ldpw] 16-bit (rows 0-2 head, 4-6 remainder of
+// the composed [3][Cp] weights), bias_final f32 [Cp] (composed bias in [0, 3), zeros behind); delta [B*H*W][4] f32 receives
+// {d flow x, d flow y, d certainty, 0} per pixel (refiner_apply_delta_launch adds them to the running flow / certainty).
+int refiner_block_final_launch(const void* in, float* delta, const float* dw_w, const float* dw_b, const void* pw_final, long ldpw,
+                               const float* bias_final, int B, int H, int W, int Cp, int dt, hipStream_t s) {
+  ROMA_REQUIRE(refiner_block_supported(Cp, dt), "refiner_block_final: only bf16 with Cp = 24 or 144");
+  ROMA_REQUIRE(ldpw % 8 == 0 && (reinterpret_cast<uintptr_t>(delta) & 15) == 0, "refiner_block_final: 16-byte aligned weight rows and delta");
+  // algorithmic bytes: the block input once + the 16-byte delta per pixel
+  ProfScope ps(Cp == 24 ? "refiner_block_final_kernel<24>" : "refiner_block_final_kernel<144>",
+               (double)B * H * W * (Cp * 2.0 + 16.0), "byte", s);
+  if (Cp == 24) {
+    const int rc = refiner_block24_wave_try_launch(in, nullptr, dw_w, dw_b, pw_final, ldpw, bias_final, B, H, W, dt, s, delta);
+    if (rc == 1) {
+      set_error("refiner_block_final: the C = 24 kernel declined these tensors (16-byte aligned bf16 input / weights)");
+      return -1;
+    }
+    return rc;
+  }
+  return launch_cp<144>(in, nullptr, dw_w, dw_b, pw_final, ldpw, bias_final, B, H, W, s, delta);
 }
 
 }  // namespace roma

@@ -60,11 +60,17 @@ __device__ __forceinline__ void rbw_glds16(const char* src, lds_u8* lds_wave_bas
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (ROMA_LDS void*)lds_wave_base, 16, 0, 0);
 }
 
+// FINAL (round 5): the LAST block of a ConvRefiner.  Its 1x1 convolution and out_conv are one composed C -> 3 map (model.hip,
+// RefinerW::oc_w); `pw` then holds 8 rows - rows 0-2 the 16-bit head of the composed weights, rows 4-6 their 16-bit remainder
+// (hi + lo carries ~16 significant bits through the MFMA, which has 29 idle rows anyway) - `pwb` the composed bias in [0, 3),
+// and instead of a block output the kernel writes delta[pixel] = {d flow x, d flow y, d certainty, 0} (f32x4): no Ot, no
+// C-channel row stores, and refiner_out's pass over the block output disappears (refiner_apply_delta_kernel adds the deltas).
+template <bool FINAL>
 __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
                                                                       const float* __restrict__ dww, const float* __restrict__ dwb,
                                                                       const bf16_t* __restrict__ pw, long ldpw,
                                                                       const float* __restrict__ pwb, int B, int H, int W, int SY,
-                                                                      int nxg, long ntasks) {
+                                                                      int nxg, long ntasks, f32x4* __restrict__ delta) {
   constexpr int NR = RBW_NR, CP = RBW_C;
   // Distinct LDS objects on purpose (refiner_block.hip): `ring` is the DMA target and is read with inline asm only; the
   // others are ordinary code, which the compiler then does not order behind the in-flight DMA.  (Ot as a slice of the Xt
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
   for (int ks = 0; ks < 2; ++ks) {
     const int k0 = ks * 16 + hh * 8;
     wA[ks] = u32x4_t{0u, 0u, 0u, 0u};
-    if (l31 < CP && k0 < CP) wA[ks] = *reinterpret_cast<const u32x4_t*>(pw + (long)l31 * ldpw + k0);
+    if (l31 < (FINAL ? 8 : CP) && k0 < CP) wA[ks] = *reinterpret_cast<const u32x4_t*>(pw + (long)l31 * ldpw + k0);
   }
   f32x4 pbias[3];
 #pragma unroll
@@ -257,7 +263,11 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
           oa = mfma_h16_32x32x16(wA[ks], xf, oa);
         }
         const int pxl = u * 32 + l31;
-        if (pxl < RBW_PXW) {
+        if constexpr (FINAL) {
+          // rows 0-2 (lanes 0-31, registers 0-2) + rows 4-6 (lanes 32-63, registers 0-2): head + remainder of the composed map
+          const float d0 = oa[0] + __shfl_xor(oa[0], 32), d1 = oa[1] + __shfl_xor(oa[1], 32), d2 = oa[2] + __shfl_xor(oa[2], 32);
+          if (hh == 0 && pxl < npw) delta[((long)b * H + ys + o) * W + xw0 + pxl] = f32x4{d0, d1, d2, 0.f};
+        } else if (pxl < RBW_PXW) {
           lds_u8* orow = Ot + pxl * (CP * 2) + 4 * hh * 2;
 #pragma unroll
           for (int g = 0; g < 3; ++g) {
@@ -268,15 +278,17 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
           }
         }
       }
-      // stream the row out: 120 contiguous 16-byte pieces (fewer on the right image edge)
-      char* orow_g = reinterpret_cast<char*>(obase + ((long)(ys + o) * W + xw0) * CP);
-      {
-        const u32x4_t q = *(lds_u32x4*)(Ot + ok0 * 16);
-        *reinterpret_cast<u32x4_t*>(orow_g + ok0 * 16) = q;
-      }
-      if (two_stores) {
-        const u32x4_t q = *(lds_u32x4*)(Ot + ok1 * 16);
-        *reinterpret_cast<u32x4_t*>(orow_g + ok1 * 16) = q;
+      if constexpr (!FINAL) {
+        // stream the row out: 120 contiguous 16-byte pieces (fewer on the right image edge)
+        char* orow_g = reinterpret_cast<char*>(obase + ((long)(ys + o) * W + xw0) * CP);
+        {
+          const u32x4_t q = *(lds_u32x4*)(Ot + ok0 * 16);
+          *reinterpret_cast<u32x4_t*>(orow_g + ok0 * 16) = q;
+        }
+        if (two_stores) {
+          const u32x4_t q = *(lds_u32x4*)(Ot + ok1 * 16);
+          *reinterpret_cast<u32x4_t*>(orow_g + ok1 * 16) = q;
+        }
       }
     }
     fill = slot;
@@ -290,13 +302,13 @@ int g_rb24_wave = -1;  // roma_tuning("rb24w", v): 1 = this kernel for C = 24 (d
 
 // 0 = launched, 1 = not this kernel's problem, < 0 = error
 int refiner_block24_wave_try_launch(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
-                                    const float* pw_b, int B, int H, int W, int dt, hipStream_t s) {
+                                    const float* pw_b, int B, int H, int W, int dt, hipStream_t s, float* delta) {
   static const int env = getenv("ROMA_RB24W") ? atoi(getenv("ROMA_RB24W")) : 1;
 #ifdef ROMA_TOOLS_BUILD
   if (!(g_rb24_wave >= 0 ? g_rb24_wave : env)) return 1;  // A/B: the two-barrier workgroup kernel (refiner_block_2b.inc)
 #endif
   if (dt != DT_BF16 || H < 1 || W < 1 || (long)W * RBW_C * 2 >= (1l << 31)) return 1;
-  if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) return 1;
+  if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (reinterpret_cast<uintptr_t>(delta ? (void*)delta : out) & 15) != 0) return 1;
   if ((reinterpret_cast<uintptr_t>(pw) & 15) != 0 || ldpw % 8 != 0) return 1;
   const int nxg = (W + RBW_PXW - 1) / RBW_PXW;
   // strip height: a strip of SY rows reads SY + 4 input rows and pays ~3 rows of pipeline fill; 2048 waves are resident
@@ -317,8 +329,12 @@ int refiner_block24_wave_try_launch(const void* in, void* out, const float* dw_w
   const long ntasks = (long)B * nxg * ((H + SY - 1) / SY);
   ROMA_REQUIRE(ntasks < (1l << 31), "refiner_block: grid too large");
   const long nwg = (ntasks + 3) / 4, wg_per_xcd = (nwg + 7) / 8;  // (the kernel decodes the same arithmetic)
-  hipLaunchKernelGGL(refiner_block24_wave_kernel, dim3((unsigned)(wg_per_xcd * 8)), dim3(256), 0, s, (const bf16_t*)in,
-                     (bf16_t*)out, dw_w, dw_b, (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, ntasks);
+  if (delta)
+    hipLaunchKernelGGL(refiner_block24_wave_kernel<true>, dim3((unsigned)(wg_per_xcd * 8)), dim3(256), 0, s, (const bf16_t*)in,
+                       (bf16_t*)nullptr, dw_w, dw_b, (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, ntasks, (f32x4*)delta);
+  else
+    hipLaunchKernelGGL(refiner_block24_wave_kernel<false>, dim3((unsigned)(wg_per_xcd * 8)), dim3(256), 0, s, (const bf16_t*)in,
+                       (bf16_t*)out, dw_w, dw_b, (const bf16_t*)pw, ldpw, pw_b, B, H, W, SY, nxg, ntasks, (f32x4*)nullptr);
   ROMA_LAUNCH_CHECK();
   return 0;
 }

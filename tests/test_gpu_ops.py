@@ -1150,3 +1150,53 @@ def test_refiner_block_wide_repeated_launches_under_load(lib):
         bad += int(not torch.equal(out.view(torch.int16), ref.view(torch.int16)))
     torch.cuda.synchronize()
     assert bad == 0, f"{bad} of 150 launches differ"
+
+
+@pytest.mark.parametrize("Cp,B,H,W", [(24, 2, 13, 10), (24, 1, 75, 301), (24, 3, 3, 200), (24, 1, 290, 150), (144, 2, 13, 10),
+                                      (144, 1, 41, 59), (144, 1, 262, 31), (144, 2, 1, 30), (144, 3, 70, 140)])
+def test_refiner_block_final_composed_out_conv(lib, Cp, B, H, W):
+    """The FINAL form of the fused narrow ConvRefiner blocks (round 5): depthwise 5x5 + BN + ReLU, then the block's 1x1 composed
+    with out_conv (linear o linear, matcher.py:92-122, 175-178) as ONE C -> 3 map on the MFMA - weights as a 16-bit head + 16-bit
+    remainder in rows 0-2 / 4-6 of an 8-row matrix, bias in the accumulator - written as per-pixel deltas, and the pass that adds
+    them to flow / certainty.  Against torch f64 on the same 16-bit-rounded depthwise output; three launches agree bit for bit."""
+    x = rnd(B, Cp, H, W, seed=1).to(torch.bfloat16)
+    w, b = rnd(Cp, 1, 5, 5, seed=2, std=0.2), rnd(Cp, seed=3)
+    wc = rnd(3, Cp, seed=4, std=Cp ** -0.5)          # the composed out_w . pw8 (f32 at pack time)
+    bc = rnd(3, seed=5)
+    hi = wc.to(torch.bfloat16)
+    lo = (wc - hi.float()).to(torch.bfloat16)
+    pwf = torch.zeros(8, Cp, dtype=torch.bfloat16)
+    pwf[0:3], pwf[4:7] = hi, lo
+    bf = torch.zeros(Cp)
+    bf[:3] = bc
+    wp = w.reshape(Cp, 25).T.contiguous().cuda()
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    # the depthwise half from the stand-alone kernel (same FMA order: its 16-bit output is what the fused kernel puts into LDS;
+    # a torch f64 stencil rounds 1 in ~200 values to the neighbouring 16-bit number), checked against torch loosely
+    t = torch.empty_like(xin)
+    ok(lib, lib.roma_op_dwconv5x5(P(xin), P(t), P(wp), P(b.cuda()), B, H, W, Cp, BF16, None))
+    torch.cuda.synchronize()
+    mid = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=2, groups=Cp)).permute(0, 2, 3, 1)
+    assert float((t.cpu().double() - mid).abs().max()) <= 2.0 ** -7 * float(mid.abs().max())
+    ref = torch.einsum("bhwc,oc->bhwo", t.cpu().double(), hi.double() + lo.double()) + bc.double()
+    outs = []
+    for _ in range(3):
+        delta = torch.full((B, H, W, 4), float("nan"), device="cuda")
+        ok(lib, lib.roma_op_refiner_block_final(P(xin), P(delta), P(wp), P(b.cuda()), P(pwf.cuda()), P(bf.cuda()), B, H, W, Cp, BF16, None))
+        torch.cuda.synchronize()
+        outs.append(delta)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    got = outs[0].cpu().double()
+    assert torch.isfinite(got).all() and float(got[..., 3].abs().max()) == 0.0
+    err = (got[..., :3] - ref).abs()
+    scale = float(ref.abs().max())
+    print(f"refiner_block_final C={Cp}: max |delta - f64| = {float(err.max()):.2e} (|delta| max {scale:.2f})")
+    assert float(err.max()) < 2e-5 * max(scale, 1.0) + 1e-5, (float(err.max()), scale)
+    # the apply pass
+    flow, cert = rnd(B * H * W, 2, seed=6).cuda(), rnd(B * H * W, seed=7).cuda()
+    f0, c0 = flow.clone(), cert.clone()
+    ok(lib, lib.roma_op_refiner_apply_delta(P(outs[0]), P(flow), P(cert), B * H * W, 0.25, 0.5, None))
+    torch.cuda.synchronize()
+    d = outs[0].reshape(-1, 4)
+    assert torch.equal(flow[:, 0], f0[:, 0] + 0.25 * d[:, 0]) and torch.equal(flow[:, 1], f0[:, 1] + 0.5 * d[:, 1])
+    assert torch.equal(cert, c0 + d[:, 2])
