@@ -602,22 +602,27 @@ def test_dma_ring_kernels_keep_their_queue(built_lib, bdir):
         pytest.skip("object files not present (library shipped pre-built)")
     for f in ("dwconv_ring.o", "refiner_block24w.o"):
         ks = kernel_resources.kernels(objs[f])
-        assert len(ks) == 1 and ks[0]["spill"] == 0 and ks[0]["scratch"] == 0 and ks[0]["vgpr"] <= 256, ks
-        dis = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", extract_code_object(objs[f])], capture_output=True,
-                             text=True, check=True).stdout.splitlines()
-        dma = [i for i, ln in enumerate(dis) if "global_load_lds_dwordx4" in ln]
-        assert len(dma) >= 6, f
-        # the row loop = from the last DMA issue (the loop's own) to the loop's back edge: the next backward branch
-        body = []
-        for ln in dis[dma[-1]:]:
-            body.append(ln)
-            if re.search(r"s_cbranch_\w+ 6[0-9]{4}\b|s_branch 6[0-9]{4}\b", ln):  # negative 16-bit offset = backward
-                break
-        waits = [int(m.group(1)) for ln in body for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", ln)] if m]
-        # exactly the younger DMA may stay in flight - 3 pieces x (NR - 1) rows - and nothing else: no full drain, and no
-        # allowance for the younger output stores either (a store can retire before an older load; the 1-in-1000 stale-row
-        # reads of profiles/r03_v20_determinism_stress.log)
-        assert waits and set(waits) == {15 if f == "dwconv_ring.o" else 9}, (f, waits)
+        nk = 1 if f == "dwconv_ring.o" else 2  # refiner_block24_wave_kernel<false> and its FINAL form <true> (round 5)
+        assert len(ks) == nk and all(k["spill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 256 for k in ks), ks
+        full = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", extract_code_object(objs[f])], capture_output=True,
+                              text=True, check=True).stdout
+        kerns = [k for k in re.split(r"\n(?=[0-9a-f]+ <_Z)", full) if "global_load_lds_dwordx4" in k]
+        assert len(kerns) == nk, (f, len(kerns))
+        for kern in kerns:
+            dis = kern.splitlines()
+            dma = [i for i, ln in enumerate(dis) if "global_load_lds_dwordx4" in ln]
+            assert len(dma) >= 6, f
+            # the row loop = from the last DMA issue (the loop's own) to the loop's back edge: the next backward branch
+            body = []
+            for ln in dis[dma[-1]:]:
+                body.append(ln)
+                if re.search(r"s_cbranch_\w+ 6[0-9]{4}\b|s_branch 6[0-9]{4}\b", ln):  # negative 16-bit offset = backward
+                    break
+            waits = [int(m.group(1)) for ln in body for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", ln)] if m]
+            # exactly the younger DMA may stay in flight - 3 pieces x (NR - 1) rows - and nothing else: no full drain, and no
+            # allowance for the younger output stores either (a store can retire before an older load; the 1-in-1000 stale-row
+            # reads of profiles/r03_v20_determinism_stress.log)
+            assert waits and set(waits) == {15 if f == "dwconv_ring.o" else 9}, (f, waits)
     # ws1x1.hip: weights in 144 registers, chunk ring with counted waits: no spills / scratch, and between the step's barrier
     # and the loop's back edge no vmcnt wait at all (round 4: the wait-count pass carried "global load pending" on the weight
     # registers into the loop and drained the ring in front of the first MFMA of every step)
