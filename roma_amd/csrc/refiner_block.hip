@@ -36,6 +36,7 @@ typedef ROMA_LDS u32x4_t lds_u32x4;
 typedef ROMA_LDS u32x2_t lds_u32x2;
 
 __device__ __attribute__((aligned(256))) unsigned int g_rb_zero_page[64];  // source of every out-of-image DMA chunk
+__device__ __attribute__((aligned(256))) unsigned int g_rb_dump[512];       // where lanes right of the tile store (C = 144): 64 x 16 B + the largest piece offset
 
 template <int CP> struct RBCfg {
   static constexpr int GC = CP / 4;                        // channel groups of 4
@@ -116,17 +117,15 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
   constexpr int CP = 144;
   typedef RBCfg<CP> Cf;
   constexpr int GC = Cf::GC, XQ = Cf::XQ, PX = Cf::PX, KS = Cf::KS, NR = RB1_NR, KW = Cf::KW;
-  constexpr int XROW = Cf::XROW, NDMA = Cf::NDMA, RSTRIDE = Cf::RSTRIDE, OPIX = Cf::OPIX;
+  constexpr int XROW = Cf::XROW, NDMA = Cf::NDMA, RSTRIDE = Cf::RSTRIDE;
   static_assert(Cf::PXB == 1 && Cf::NBF == 4 && Cf::TAIL == 16, "one 32-pixel block, four full channel blocks + 16");
   __shared__ __attribute__((aligned(1024))) unsigned char ring[NR * RSTRIDE];
   __shared__ __attribute__((aligned(16))) unsigned char work[Cf::OFF_XT];          // taps, 1x1 bias, remainder weights
   __shared__ __attribute__((aligned(16))) unsigned char xtb[2 * RB1_XT];           // Xt, double buffered
-  __shared__ __attribute__((aligned(16))) unsigned char otb[PX * OPIX];            // Ot: per-wave channel slices
   lds_u8* const wk = (lds_u8*)work;
   lds_f32* const wsm = (lds_f32*)wk;
   lds_f32* const pbs = (lds_f32*)(wk + Cf::OFF_PWB);
   lds_u8* const Wt = wk + Cf::OFF_WT;
-  lds_u8* const Ot = (lds_u8*)otb;
 
   const int per_xcd = (nblocks + 7) / 8;
   const long lb = (long)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
@@ -144,16 +143,12 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
   const int npx = min(PX, W - x0);
 
   {
-    // taps + bias in SLOT order: slot s of a tap row holds channel group (s + 32) % 36, i.e. the row starts with groups
-    // 32 .. 35 (see the lane map below)
+    // taps + bias, 25 + 1 rows of 36 channel groups (16 B each), in channel order
     constexpr int nvec = 26 * GC;
 #pragma unroll
     for (int it = 0; it < (nvec + 255) / 256; ++it) {
       const int i = tid + 256 * it;
-      if (i < nvec) {
-        const int row = i / GC, sl = i - row * GC, g = (sl + 32) % GC;
-        *(lds_f32x4*)(wsm + i * 4) = *reinterpret_cast<const f32x4*>(row < 25 ? dww + ((long)row * GC + g) * 4 : dwb + (long)g * 4);
-      }
+      if (i < nvec) *(lds_f32x4*)(wsm + i * 4) = *reinterpret_cast<const f32x4*>(i < 25 * GC ? dww + (long)i * 4 : dwb + (long)(i - 25 * GC) * 4);
     }
     if (tid < GC) *(lds_f32x4*)(pbs + tid * 4) = *reinterpret_cast<const f32x4*>(pwb + tid * 4);
     constexpr int wslots = FINAL ? 0 : Cf::TAIL * (XROW / 16);  // (FINAL: `pw` has 8 rows only, and no remainder block)
@@ -206,23 +201,38 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
   if (kw == KW) ROMA_RB_WAIT_VM((NR - 1) * KW); else ROMA_RB_WAIT_VM((NR - 1) * (KW - 1));
   ROMA_RB_BARRIER();  // input row 0 landed
 
-  // Lane -> (column quad xq, channel group cg).  With the plain tid = 36 xq + cg map a 16-lane pass of the tap reads
-  // (ds_read_b128, 64 B per 4 lanes) straddles the 35 -> 0 wrap of the channel groups in 1-2 of every 4 passes, and groups
-  // 32 .. 35 share their banks with groups 0 .. 3 / 16 .. 19 (144 dwords per tap row = 2.25 x 64): 2-way conflicts on the 25
-  // tap reads of every row (LDS bank-conflict share 0.32, profiles/r03_pmc_sq_summary.json).  Here every pass reads 16
-  // CONSECUTIVE slots of the tap row (or repeats an address of the same pass, which broadcasts):
-  //   waves 0-2: lanes 0-35 = quad 2w, slots 4..35, 0..3;  lanes 36-63 = quad 2w + 1, slots 0..27
-  //   wave 3:    lanes 0-35 = quad 6, slots 0..35;         lanes 36-59 = slots 28..35 of quads 1, 3, 5
-  int xq, wslot;
+  // Lane -> (column quad xq, channel group cg).  Three LDS access streams depend on it, each served in its own lane groups
+  // (MI355X_MICROARCH.md, LDS table): the 8 ring reads of a row (ds_read_b64: lanes 0-31 | 32-63, 64 banks), the 25 tap reads
+  // (ds_read_b128: {0-3, 12-15, 20-27} {4-11, 16-19, 28-31} and the same + 32, 64 banks) and the 4 Xt writes (ds_write_b64:
+  // four groups of 16 consecutive lanes, 32 banks).  A group is free of conflicts when its addresses are distinct modulo
+  // the bank row, or equal.  With cg = 16 a + b (a = 0, 1; a = 2 for the four groups 32 .. 35):
+  //   ring  byte (4 xq + j) 288 + 8 cg  -> 8-byte unit (16 [xq odd] + cg) mod 32 = 16 (a + [xq odd] mod 2) + b
+  //   taps  byte 16 cg                  -> 16-byte unit cg mod 16 = b
+  //   Xt    byte (4 xq + px) 304 + 8 cg -> 8-byte unit (8 [xq odd] + cg) mod 16 = b (+ 8)
+  // so a BLOCK = the 16 groups of one quad with one a, laid on 16 consecutive lanes in the order of b, is conflict free in
+  // all three, and two blocks form a conflict-free half-wave when they are (even quad, a) + (odd quad, a) - complementary
+  // ring halves, the same tap addresses - or (quad, a = 0) + (same quad, a = 1):
+  //   waves 0-2: lanes 0-15 (2w, a=0) | 16-31 (2w+1, a=0) | 32-47 (2w, a=1) | 48-63 (2w+1, a=1)
+  //   wave 3:    lanes 0-31 quad 6, cg = lane; lanes 32-59 the groups 32 .. 35 of the quads 0 2 1 3 | 4 6 5 (4 lanes each)
+  // The 28 left-over items (7 quads x groups 32 .. 35) cannot be conflict free: over the workgroup 11 items share each ring
+  // unit 0 .. 3 against 8 half-waves, 18 each Xt unit 0 .. 3 against 16 groups.  Gathered in wave 3's upper half they cost 3
+  // extra cycles on a ring read and 1 + 1 on an Xt write (the minimum), nothing on a tap read (four addresses, broadcast).
+  // History: tid = 36 xq + cg had 2-way conflicts on every tap read (share 0.32, r03_pmc_sq_summary.json); round 3's slot
+  // rotation removed them from two of the four b128 groups only, because it assumed 16 CONSECUTIVE lanes per pass (0.229).
+  // Pure relabelling of which lane computes which (quad, group): same values, bit for bit.
+  int xq, cg;
   if (wv < 3) {
-    xq = lane < 36 ? 2 * wv : 2 * wv + 1;
-    wslot = lane < 36 ? (lane + 4) % 36 : lane - 36;
+    xq = 2 * wv + ((lane >> 4) & 1);
+    cg = (lane & 15) + 16 * (lane >> 5);
+  } else if (lane < 32) {
+    xq = 6;
+    cg = lane;
   } else {
-    const int k24 = lane - 36;
-    xq = lane < 36 ? 6 : 1 + 2 * (k24 >> 3);
-    wslot = lane < 36 ? lane : 28 + (k24 & 7);
+    const int k = lane - 32;
+    xq = (0x55643120u >> (4 * (k >> 2))) & 7;  // 0 2 1 3 | 4 6 5 (5: idle lanes 60-63, the addresses of their group)
+    cg = 32 + (k & 3);
   }
-  const int cg = (wslot + 32) % 36;
+  const int wslot = cg;
   const int xb = x0 + xq * 4;
   const bool active = (wv < 3 || lane < 60) && xb < W;
   const int c = cg * 4;        // channel offset: ring reads, Xt writes
@@ -341,6 +351,10 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
           if (hhv == 0 && l31v < npx) delta[((long)b * H + ys + o) * W + x0 + l31v] = f32x4{d0, d1, d2, 0.f};
         }
       } else {
+      // this lane's store position: pixel l31, byte 64 wv + 16 hh of it (lanes right of the tile: their slot of the dump page)
+      char* const orow_w = reinterpret_cast<char*>(obase + ((long)(ys + o) * W + x0) * CP) + 64 * wv;
+      char* const pl = l31v < npx ? orow_w + l31v * (CP * 2) + 16 * hhv : reinterpret_cast<char*>(g_rb_dump) + lanev * 16;
+      u32x4_t q_first;
       {
         f32x16 oa;
 #pragma unroll
@@ -354,15 +368,20 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
           const u32x4_t xf = *(lds_u32x4*)(Xt + l31v * XROW + ks * 32 + hhv * 16);
           oa = mfma_h16_32x32x16(wown[ks], xf, oa);
         }
-        if (l31v < PX) {
-          lds_u8* orow = Ot + l31v * OPIX + (32 * wv + 4 * hhv) * 2;
+        // A lane holds channels 32 wv + 8 g + 4 hh + [0, 4) of pixel l31; v_permlane32_swap pairs the half-waves so that lane
+        // (l31, hh) ends up with the 8 consecutive channels 32 wv + 16 P + 8 hh + [0, 8): two 16-byte stores, 32 contiguous
+        // bytes per pixel and instruction, straight from the accumulators (until round 5 the row went through an LDS tile
+        // Ot: 4 ds_write_b64 + 3 ds_read_b128 + a wait per row, 2-way bank conflicts on both sides).  Lanes right of the
+        // tile store into a dump page: exactly three store instructions per wave and row, whatever the lanes' validity.
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            u32x2_t q;
-            q.x = pack_bf16x2(oa[4 * g + 0], oa[4 * g + 1]);
-            q.y = pack_bf16x2(oa[4 * g + 2], oa[4 * g + 3]);
-            *(lds_u32x2*)(orow + g * 16) = q;
-          }
+        for (int P = 0; P < 2; ++P) {
+          const unsigned a0 = pack_bf16x2(oa[8 * P + 0], oa[8 * P + 1]), a1 = pack_bf16x2(oa[8 * P + 2], oa[8 * P + 3]);
+          const unsigned b0 = pack_bf16x2(oa[8 * P + 4], oa[8 * P + 5]), b1 = pack_bf16x2(oa[8 * P + 6], oa[8 * P + 7]);
+          const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          const u32x4_t q = {s0[0], s1[0], s0[1], s1[1]};
+          *reinterpret_cast<u32x4_t*>(pl + 32 * P) = q;
+          if (P == 0) q_first = q;
         }
       }
       // ... and, when it is this wave's turn, the 16-channel remainder block (weights from LDS)
@@ -383,35 +402,16 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
           const u32x4_t xf = *(lds_u32x4*)(Xt + l31v * XROW + ks * 32 + hhv * 16);
           ta = mfma_h16_32x32x16(wf, xf, ta);
         }
-        if (l31v < PX) {
-          lds_u8* orow = Ot + l31v * OPIX + (32 * Cf::NBF + 4 * hhv) * 2;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            if (8 * g + 4 * hhv < Cf::TAIL) {
-              u32x2_t q;
-              q.x = pack_bf16x2(ta[4 * g + 0], ta[4 * g + 1]);
-              q.y = pack_bf16x2(ta[4 * g + 2], ta[4 * g + 3]);
-              *(lds_u32x2*)(orow + g * 16) = q;
-            }
-          }
-        }
-      }
-      // stream out what this wave wrote: its slice = npx x 4 pieces of 16 B (two stores per lane), then either the
-      // remainder block's npx x 2 pieces or - to keep the store count per row uniform for the counted waits - piece 0 again
-      char* orow_g = reinterpret_cast<char*>(obase + ((long)(ys + o) * W + x0) * CP);
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int j = min(lanev + 64 * it, npx * 4 - 1);
-        const int jp = j >> 2, jc = j & 3;
-        const u32x4_t q = *(lds_u32x4*)(Ot + jp * OPIX + 64 * wv + jc * 16);
-        *reinterpret_cast<u32x4_t*>(orow_g + jp * (CP * 2) + 64 * wv + jc * 16) = q;
-      }
-      {
-        const int j = mine ? min(lanev, npx * 2 - 1) : 0;
-        const int jp = mine ? (j >> 1) : 0, jc = mine ? (j & 1) : 0;
-        const int cb = mine ? 64 * Cf::NBF : 64 * wv;  // byte column of the piece inside a pixel
-        const u32x4_t q = *(lds_u32x4*)(Ot + jp * OPIX + cb + jc * 16);
-        *reinterpret_cast<u32x4_t*>(orow_g + jp * (CP * 2) + cb + jc * 16) = q;
+        // 16 channels: g = 0, 1 hold them (lane: 8 g + 4 hh + [0, 4)); after the swap lane (l31, hh) has 128 + 8 hh + [0, 8)
+        const unsigned a0 = pack_bf16x2(ta[0], ta[1]), a1 = pack_bf16x2(ta[2], ta[3]);
+        const unsigned b0 = pack_bf16x2(ta[4], ta[5]), b1 = pack_bf16x2(ta[6], ta[7]);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        const u32x4_t q = {s0[0], s1[0], s0[1], s1[1]};
+        *reinterpret_cast<u32x4_t*>(pl + 64 * (Cf::NBF - wv)) = q;
+      } else {
+        // not this wave's turn: its first piece once more, to keep the store count per row uniform for the counted waits
+        *reinterpret_cast<u32x4_t*>(pl) = q_first;
       }
     }
       }
