@@ -7,15 +7,16 @@
 // be shared (the recipe of dwconv5x5_ring_kernel, which issues 55 % of its cycles with no barrier at all):
 //
 //   * a wave = 40 output columns x all 24 channels x a strip of rows; lane = (4 channels, 4 columns): 6 channel groups x
-//     10 column quads = 60 lanes (the workgroup kernel: 216 of 256);
+//     10 column quads = 60 lanes (the workgroup kernel: 216 of 256), through the lane table below (LDS bank conflicts);
 //   * per input row the wave needs 44 pixels x 48 B: three `global_load_lds_dwordx4` into its own NR = 4 row ring.  After
 //     every 4 pixels (12 pieces) one 16-byte piece of the row stays empty, so that the column
 //     quads of a `ds_read_b64` half-wave start 52 dwords apart (0, 52, 40, 28, 16 mod 64 - five disjoint 12-dword runs;
 //     the natural 48-dword pitch puts quad 4 on quad 0's banks);
 //   * the depthwise output row goes to a wave-private Xt[40 pixels][32 k] (bf16, 80-byte rows as in the workgroup kernel),
 //     two 32-pixel MFMA blocks (the second one 8 pixels + zeros) x 2 k-steps against the 1x1 weights held in registers,
-//     bias in the accumulator init; the result is packed into a wave-private Ot[40][24] and leaves as 120 contiguous
-//     16-byte pieces, two stores per lane;
+//     bias in the accumulator init; v_permlane32_swap pairs the half-waves and the row leaves in three 16-byte stores per
+//     lane straight from the accumulators (until round 5: through a wave-private LDS tile Ot[40][24], 6 ds_write_b64 +
+//     2 ds_read_b128 + a wait per row);
 //   * the only thing that orders anything is the wave's own counted `s_waitcnt vmcnt` (allowance = the younger DMA) and the
 //     in-order LDS pipeline: NO barrier after the weights have been staged, the waves drift freely, and a wave whose tile is
 //     off the image simply leaves.
@@ -46,10 +47,33 @@ constexpr int RBW_NR = 4;         // ring rows per wave (the DMA runs three rows
 constexpr int RBW_ROWB = 3072;    // bytes per ring row: 192 pieces of 16 B (44 pixels x 3 + 10 gaps = 142 used)
 constexpr int RBW_PXW = 40;       // output columns per wave
 constexpr int RBW_XROW = 80;      // bytes per Xt pixel row: 32 k x 2 B + 16 (conflict-free 16-byte MFMA fragment reads)
-constexpr int RBW_XT = 64 * RBW_XROW;   // two 32-pixel MFMA blocks; rows 40 .. 63 stay zero
-constexpr int RBW_OT = 2048;      // 40 pixels x 48 B = 1920, rounded
+constexpr int RBW_XT = 64 * RBW_XROW + 32;   // two 32-pixel MFMA blocks; rows 40 .. 63 stay zero; + the second block's shift
 constexpr int RBW_RING = 4 * RBW_NR * RBW_ROWB;           // 48 KiB per workgroup
-constexpr int RBW_WORK = 4 * (RBW_XT + RBW_OT);           // 28 KiB
+constexpr int RBW_WORK = 4 * RBW_XT;                      // 20 KiB
+
+// LDS banks (round 5; MI355X_MICROARCH.md, LDS table).  Three streams depend on which lane computes which (column quad xq,
+// channel group cg) - the 8 ring reads of a row (ds_read_b64: half-waves, 64 banks), the 4 Xt writes (ds_write_b64: groups of
+// 16 consecutive lanes, 32 banks = 16 units of 8 B) and, through the Xt layout, the MFMA operand reads (ds_read_b128: lane
+// groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}, 16 units of 16 B).  lane = 6 xq + cg had a 2-way conflict on every ring
+// read (quad 5's groups 0, 1 sit in the first half-wave, on quad 0's banks), on three of the four groups of every Xt write and
+// on every Ot write: share 0.152 (profiles/r04_pmc_sq_summary.json).  Now:
+//   * ring: the quads whose 12-dword runs are disjoint are {0 .. 4} and {5 .. 9} - one set per half-wave;
+//   * Xt: the write unit of (xq, cg) is 8 [xq odd] + cg mod 16 with the plain 80-byte rows - two windows of six, twelve lanes
+//     of sixteen at best.  A row's 16 pad bytes allow a 16-byte shift: rows of the quads with an odd number of bits in
+//     (xq & 7) - {1, 2, 4, 7}, one of the two lane groups of the operand read, which therefore stays conflict free - start
+//     16 bytes later, and the second MFMA block (quads 8, 9; read by its own instruction) 32 bytes later.  Windows: quads
+//     0 6: 0-5, 2 4: 2-7, 3 5: 8-13, 1 7: 10-15, 8: 4-9, 9: 14-3.  The table fills every 16-lane group with distinct units,
+//     except lanes 16-31 (quads 2 and 4 share a window and, with quad 0, supply three lanes per unit 2-5 to the two groups of
+//     their half-wave): one extra cycle per Xt write, the minimum.
+// Entry = 8 xq + cg; 255 = idle lane.  tests/test_cpu_oracle.py checks cover and conflict count of this table.
+__device__ const unsigned char g_rbw_lane_map[64] = {
+    0,  1,  2,  3,  4,  5,  24, 25, 26, 27, 28, 29, 20, 21, 12, 13,   // quad 0 | quad 3 | quad 2: 4 5 | quad 1: 4 5
+    8,  9,  10, 11, 16, 17, 18, 19, 32, 33, 34, 35, 36, 37, 255, 255, // quad 1: 0-3 | quad 2: 0-3 | quad 4
+    48, 49, 50, 51, 52, 53, 56, 57, 58, 59, 60, 61, 66, 67, 68, 69,   // quad 6 | quad 7 | quad 8: 2-5
+    40, 41, 42, 43, 44, 45, 64, 65, 72, 73, 74, 75, 76, 77, 255, 255  // quad 5 | quad 8: 0 1 | quad 9
+};
+// byte offset of Xt pixel row p (0 .. 63)
+__device__ __forceinline__ int rbw_xt_row(int p) { return p * RBW_XROW + 16 * ((0x96 >> ((p >> 2) & 7)) & 1) + (p >= 32 ? 32 : 0); }
 constexpr int RBW_WSM = 26 * RBW_C * 4;                   // depthwise taps + bias, f32
 static_assert(RBW_RING + RBW_WORK + RBW_WSM <= 80 * 1024, "two workgroups per CU");
 static_assert(3 * (RBW_NR - 1) <= 63, "vmcnt is a 6-bit counter");
@@ -78,14 +102,12 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
   // object of its own it does not.  tests/test_cpu_oracle.py audits the loop for it.)
   __shared__ __attribute__((aligned(1024))) unsigned char ring[RBW_RING];
   __shared__ __attribute__((aligned(16))) unsigned char xtb[4 * RBW_XT];
-  __shared__ __attribute__((aligned(16))) unsigned char otb[4 * RBW_OT];
   __shared__ __attribute__((aligned(16))) float wsmb[26 * RBW_C];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
   lds_f32* const wsm = (lds_f32*)wsmb;  // [26][24]
   lds_u8* const Xt = (lds_u8*)xtb + wv * RBW_XT;
-  lds_u8* const Ot = (lds_u8*)otb + wv * RBW_OT;
 
   // ---- one-time staging: the tap table (shared, read-only afterwards) and this wave's zeroed Xt
   for (int i = tid; i < 26 * (CP / 4); i += 256)
@@ -108,14 +130,17 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
   const int sy = min(SY, H - ys);
   const int T = sy + 4;  // input rows ys - 2 .. ys + sy + 1
 
-  const int cg = lane % 6, xq = lane / 6;
-  const bool active = xq < 10;
+  unsigned lm = g_rbw_lane_map[lane];
+  // retire the load in the compiler's book HERE (its wait-count pass does not see the inline-asm waits below: a load whose
+  // first consumer it places inside the row loop would get an s_waitcnt vmcnt(0) there - the whole DMA queue drained per row;
+  // tests/test_cpu_oracle.py audits the loop for it)
+  asm volatile("" : "+v"(lm));
+  const bool active = lm != 255u;
+  const int cg = active ? (int)(lm & 7u) : 0, xq = active ? (int)(lm >> 3) : 0;
   const int c = cg * 4;
   const int xw0 = xg * RBW_PXW;            // first output column of the wave
   const int x0 = xw0 - 2;                  // image column of ring pixel 0
   const int npw = min(RBW_PXW, W - xw0);   // valid output columns of the wave (>= 1)
-  const int nvp = npw * 3;                 // valid 16-byte pieces of an output row
-  const bool two_stores = nvp > 64;        // wave-uniform
 
   // ---- 1x1 weights of all 24 output channels: A operand (row = channel, 8 consecutive k per lane), rows / k >= 24 zero
   u32x4_t wA[2];
@@ -169,8 +194,12 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
     }
   const unsigned rd0 = (unsigned)(size_t)myring + (unsigned)(xq * 208 + cg * 8);
   bf16_t* const obase = out + ((long)b * H * W) * CP;
-  // output pieces of this lane: k = lane and lane + 64, clamped into the valid range (duplicates store the same bytes)
-  const int ok0 = min(lane, nvp - 1), ok1 = min(lane + 64, nvp - 1);
+  int xtw0 = rbw_xt_row(xq * 4) + cg * 8;                               // this lane's Xt write position (pixel 4 xq)
+  int xtr0 = rbw_xt_row(l31) + hh * 16, xtr1 = rbw_xt_row(32 + l31) + hh * 16;  // its operand rows of the two MFMA blocks
+  // opaque: hipcc otherwise folds the 0 / 16 / 32-byte shifts into SELECTS OF POINTERS, the LDS lowering then no longer knows
+  // which LDS object an access belongs to, and every Xt access of the row loop gets an s_waitcnt vmcnt(0) in front of it
+  // ("may alias the DMA target") - the whole DMA queue drained twice per row (the audit in tests/test_cpu_oracle.py)
+  asm volatile("" : "+v"(xtw0), "+v"(xtr0), "+v"(xtr1));
 
 #pragma unroll
   for (int rr = 0; rr < NR - 1; ++rr) ROMA_RBW_ISSUE(rr, rr);
@@ -226,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
       }
 #undef ROMA_RBW_CVT
       if (o >= 0) {
-        lds_u8* xrow = Xt + (xq * 4) * RBW_XROW + cg * 8;
+        lds_u8* xrow = Xt + xtw0;
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
           u32x2_t u;
@@ -250,44 +279,49 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
     }
     if (o >= 0) {
       // ---------------- 1x1 convolution of output row o on MFMA, out of the wave's own Xt
+      f32x16 oa[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        f32x16 oa;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) oa[4 * g + j] = g < 3 ? pbias[g][j] : 0.f;
+          for (int j = 0; j < 4; ++j) oa[u][4 * g + j] = g < 3 ? pbias[g][j] : 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const u32x4_t xf = *(lds_u32x4*)(Xt + (u * 32 + l31) * RBW_XROW + ks * 32 + hh * 16);
-          oa = mfma_h16_32x32x16(wA[ks], xf, oa);
-        }
-        const int pxl = u * 32 + l31;
-        if constexpr (FINAL) {
-          // rows 0-2 (lanes 0-31, registers 0-2) + rows 4-6 (lanes 32-63, registers 0-2): head + remainder of the composed map
-          const float d0 = oa[0] + __shfl_xor(oa[0], 32), d1 = oa[1] + __shfl_xor(oa[1], 32), d2 = oa[2] + __shfl_xor(oa[2], 32);
-          if (hh == 0 && pxl < npw) delta[((long)b * H + ys + o) * W + xw0 + pxl] = f32x4{d0, d1, d2, 0.f};
-        } else if (pxl < RBW_PXW) {
-          lds_u8* orow = Ot + pxl * (CP * 2) + 4 * hh * 2;
-#pragma unroll
-          for (int g = 0; g < 3; ++g) {
-            u32x2_t q;
-            q.x = pack_bf16x2(oa[4 * g + 0], oa[4 * g + 1]);
-            q.y = pack_bf16x2(oa[4 * g + 2], oa[4 * g + 3]);
-            *(lds_u32x2*)(orow + g * 16) = q;
-          }
+          const u32x4_t xf = *(lds_u32x4*)(Xt + (u ? xtr1 : xtr0) + ks * 32);
+          oa[u] = mfma_h16_32x32x16(wA[ks], xf, oa[u]);
         }
       }
-      if constexpr (!FINAL) {
-        // stream the row out: 120 contiguous 16-byte pieces (fewer on the right image edge)
-        char* orow_g = reinterpret_cast<char*>(obase + ((long)(ys + o) * W + xw0) * CP);
-        {
-          const u32x4_t q = *(lds_u32x4*)(Ot + ok0 * 16);
-          *reinterpret_cast<u32x4_t*>(orow_g + ok0 * 16) = q;
+      if constexpr (FINAL) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int pxl = u * 32 + l31;
+          // rows 0-2 (lanes 0-31, registers 0-2) + rows 4-6 (lanes 32-63, registers 0-2): head + remainder of the composed map
+          const float d0 = oa[u][0] + __shfl_xor(oa[u][0], 32), d1 = oa[u][1] + __shfl_xor(oa[u][1], 32),
+                      d2 = oa[u][2] + __shfl_xor(oa[u][2], 32);
+          if (hh == 0 && pxl < npw) delta[((long)b * H + ys + o) * W + xw0 + pxl] = f32x4{d0, d1, d2, 0.f};
         }
-        if (two_stores) {
-          const u32x4_t q = *(lds_u32x4*)(Ot + ok1 * 16);
-          *reinterpret_cast<u32x4_t*>(orow_g + ok1 * 16) = q;
+      } else {
+        // A lane holds channels 8 g + 4 hh + [0, 4) of pixel 32 u + l31 (g = 0 .. 2).  v_permlane32_swap(a, b) exchanges lanes
+        // 32-63 of a with lanes 0-31 of b: for (g = 0, g = 1) of one block lane (l31, hh) ends up with the 8 consecutive
+        // channels 8 hh + [0, 8) of its pixel; for g = 2 of BOTH blocks the lower half-wave gets channels 16 .. 23 of pixel l31,
+        // the upper one those of pixel 32 + l31 - i.e. of pixel `lane`.  Three 16-byte stores per lane and row.
+        char* const orow_g = reinterpret_cast<char*>(obase + ((long)(ys + o) * W + xw0) * CP);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned a0 = pack_bf16x2(oa[u][0], oa[u][1]), a1 = pack_bf16x2(oa[u][2], oa[u][3]);
+          const unsigned b0 = pack_bf16x2(oa[u][4], oa[u][5]), b1 = pack_bf16x2(oa[u][6], oa[u][7]);
+          const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          const int pxl = u * 32 + l31;
+          if (pxl < npw) *reinterpret_cast<u32x4_t*>(orow_g + pxl * (CP * 2) + 16 * hh) = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+        }
+        {
+          const unsigned a0 = pack_bf16x2(oa[0][8], oa[0][9]), a1 = pack_bf16x2(oa[0][10], oa[0][11]);
+          const unsigned b0 = pack_bf16x2(oa[1][8], oa[1][9]), b1 = pack_bf16x2(oa[1][10], oa[1][11]);
+          const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          if (lane < npw) *reinterpret_cast<u32x4_t*>(orow_g + lane * (CP * 2) + 32) = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
         }
       }
     }
