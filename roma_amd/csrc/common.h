@@ -113,6 +113,16 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 #endif
 }
 #endif
+// ReLU + pack of two f32 into 16-bit storage: round first, then clamp the PACKED pair with one v_pk_max_i16 against zero (the
+// sign bit of bfloat16 / binary16 is the sign bit of the 16-bit integer, so max(x, 0) as int16 is max(x, +0) as a float; -0 and
+// values that round to -0 become +0 exactly as with fmaxf before the rounding - rounding is monotonic and keeps the sign).  One
+// VALU instruction per pair instead of two v_max_f32 per pair in the VALU-bound stencil kernels (round 5).
+__device__ __forceinline__ uint32_t pack_relu_h16x2(float lo, float hi) {
+  typedef short pk_i16x2 __attribute__((ext_vector_type(2)));
+  const pk_i16x2 z = {0, 0};
+  const pk_i16x2 v = __builtin_bit_cast(pk_i16x2, pack_bf16x2(lo, hi));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(v, z));
+}
 
 // D[32x32] += A[32 x 16] . B[16 x 32] on the matrix core, 16-bit operands of this build's format, f32 accumulate:
 // v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x16_f16 (same rate, same register layout: 8 consecutive k per lane).

@@ -81,8 +81,8 @@ __device__ __forceinline__ void dwr_row(f32x2 (&acc)[5][4][2], const f32x4 (&wre
       const f32x2 w0 = f32x2{wx[0], wx[1]}, w1 = f32x2{wx[2], wx[3]};
 #pragma unroll
       for (int px = 0; px < 4; ++px) {
-        acc[k][px][0] = v[px + kx][0] * w0 + acc[k][px][0];
-        acc[k][px][1] = v[px + kx][1] * w1 + acc[k][px][1];
+        acc[k][px][0] = v[px + kx][0] * w0 + (k == 4 && kx == 0 ? bias0 : acc[k][px][0]);  // (the new row starts from the bias:
+        acc[k][px][1] = v[px + kx][1] * w1 + (k == 4 && kx == 0 ? bias1 : acc[k][px][1]);  //  no 16 v_mov per row to re-seed acc[4])
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -93,8 +93,8 @@ __device__ __forceinline__ void dwr_row(f32x2 (&acc)[5][4][2], const f32x4 (&wre
     for (int px = 0; px < 4; ++px) {
       if (px < npx) {  // (exec-masked: the instruction is issued for the wave as long as one lane owns column px)
         uint2 u;
-        u.x = pack_bf16x2(fmaxf(acc[0][px][0][0], 0.f), fmaxf(acc[0][px][0][1], 0.f));
-        u.y = pack_bf16x2(fmaxf(acc[0][px][1][0], 0.f), fmaxf(acc[0][px][1][1], 0.f));
+        u.x = pack_relu_h16x2(acc[0][px][0][0], acc[0][px][0][1]);
+        u.y = pack_relu_h16x2(acc[0][px][1][0], acc[0][px][1][1]);
         *reinterpret_cast<uint2*>(orow + (long)px * Cp) = u;
       }
     }
@@ -106,11 +106,6 @@ __device__ __forceinline__ void dwr_row(f32x2 (&acc)[5][4][2], const f32x4 (&wre
       acc[k][px][0] = acc[k + 1][px][0];
       acc[k][px][1] = acc[k + 1][px][1];
     }
-#pragma unroll
-  for (int px = 0; px < 4; ++px) {
-    acc[4][px][0] = bias0;
-    acc[4][px][1] = bias1;
-  }
 }
 
 __global__ __launch_bounds__(256, 2) void dwconv5x5_ring_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,

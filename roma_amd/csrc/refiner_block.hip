@@ -100,9 +100,12 @@ __device__ __forceinline__ void rb_glds16(const char* src, lds_u8* lds_wave_base
 //     is visible" point as well.
 // The second Xt buffer is paid for with the ring: NR = 3 rows (the DMA still runs a full row ahead of the one being
 // waited for).  Arithmetic and its order are unchanged: bit-identical results (tests).
-constexpr int RB1_NR = 3;
 constexpr int RB1_XT = RBCfg<144>::PXB * 32 * RBCfg<144>::XROW;
-static_assert(RBCfg<144>::WORK_BYTES + RB1_XT + RB1_NR * RBCfg<144>::RSTRIDE <= 80 * 1024, "two workgroups per CU");
+// LDS of this kernel: ring + taps / bias / remainder weights + two Xt buffers (no output tile since round 5)
+// (A ring of 4 rows - the LDS the output tile freed - was measured in round 5: 6.68 / 6.73 against 6.71 / 6.78 ms per step, noise;
+// the kernel waits for its VALU, not for the DMA.  profiles/r05_v11_block144_ring_depth.log)
+constexpr int RB1_NR = 3;
+static_assert(RB1_NR * RBCfg<144>::RSTRIDE + RBCfg<144>::OFF_XT + 2 * RB1_XT <= 80 * 1024, "two workgroups per CU");
 
 // FINAL (round 5): the last block of a ConvRefiner, its 1x1 composed with out_conv (see refiner_block24w.hip): `pw` holds 8 rows
 // (rows 0-2 head, rows 4-6 remainder of the composed C -> 3 weights), `pwb` the composed bias in [0, 3); the wave whose turn it
@@ -291,8 +294,8 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
           const f32x2 w0 = f32x2{wx[0], wx[1]}, w1 = f32x2{wx[2], wx[3]};
 #pragma unroll
           for (int px = 0; px < 4; ++px) {
-            acc[k][px][0] = v[px + kx][0] * w0 + acc[k][px][0];
-            acc[k][px][1] = v[px + kx][1] * w1 + acc[k][px][1];
+            acc[k][px][0] = v[px + kx][0] * w0 + (k == 4 && kx == 0 ? bias0 : acc[k][px][0]);  // (the new row starts from the bias:
+            acc[k][px][1] = v[px + kx][1] * w1 + (k == 4 && kx == 0 ? bias1 : acc[k][px][1]);  //  no 16 v_mov per row to re-seed acc[4])
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -303,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
           u32x2_t u;
-          u.x = pack_bf16x2(fmaxf(acc[0][px][0][0], 0.f), fmaxf(acc[0][px][0][1], 0.f));
-          u.y = pack_bf16x2(fmaxf(acc[0][px][1][0], 0.f), fmaxf(acc[0][px][1][1], 0.f));
+          u.x = pack_relu_h16x2(acc[0][px][0][0], acc[0][px][0][1]);
+          u.y = pack_relu_h16x2(acc[0][px][1][0], acc[0][px][1][1]);
           *(lds_u32x2*)(xrow + px * XROW) = u;
         }
       }
@@ -315,11 +318,6 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
           acc[k][px][0] = acc[k + 1][px][0];
           acc[k][px][1] = acc[k + 1][px][1];
         }
-#pragma unroll
-      for (int px = 0; px < 4; ++px) {
-        acc[4][px][0] = bias0;
-        acc[4][px][1] = bias1;
-      }
     }
     // this wave's pieces of input row t + 1 must have landed: the DMA issued after them may stay in flight - row t + 2 only
     // (row t + NR is issued below).  The stores of the last iterations are NOT part of the allowance (a store can retire

@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
           const f32x2 w0 = f32x2{wx[0], wx[1]}, w1 = f32x2{wx[2], wx[3]};
 #pragma unroll
           for (int px = 0; px < 4; ++px) {
-            acc[k][px][0] = v[px + kx][0] * w0 + acc[k][px][0];
-            acc[k][px][1] = v[px + kx][1] * w1 + acc[k][px][1];
+            acc[k][px][0] = v[px + kx][0] * w0 + (k == 4 && kx == 0 ? bias0 : acc[k][px][0]);  // (the new row starts from the bias:
+            acc[k][px][1] = v[px + kx][1] * w1 + (k == 4 && kx == 0 ? bias1 : acc[k][px][1]);  //  no 16 v_mov per row to re-seed acc[4])
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
           u32x2_t u;
-          u.x = pack_bf16x2(fmaxf(acc[0][px][0][0], 0.f), fmaxf(acc[0][px][0][1], 0.f));
-          u.y = pack_bf16x2(fmaxf(acc[0][px][1][0], 0.f), fmaxf(acc[0][px][1][1], 0.f));
+          u.x = pack_relu_h16x2(acc[0][px][0][0], acc[0][px][0][1]);
+          u.y = pack_relu_h16x2(acc[0][px][1][0], acc[0][px][1][1]);
           *(lds_u32x2*)(xrow + px * RBW_XROW) = u;
         }
       }
@@ -271,11 +271,6 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
           acc[k][px][0] = acc[k + 1][px][0];
           acc[k][px][1] = acc[k + 1][px][1];
         }
-#pragma unroll
-      for (int px = 0; px < 4; ++px) {
-        acc[4][px][0] = bias0;
-        acc[4][px][1] = bias1;
-      }
     }
     if (o >= 0) {
       // ---------------- 1x1 convolution of output row o on MFMA, out of the wave's own Xt
