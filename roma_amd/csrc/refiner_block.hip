@@ -235,11 +235,10 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
     xq = (0x55643120u >> (4 * (k >> 2))) & 7;  // 0 2 1 3 | 4 6 5 (5: idle lanes 60-63, the addresses of their group)
     cg = 32 + (k & 3);
   }
-  const int wslot = cg;
   const int xb = x0 + xq * 4;
   const bool active = (wv < 3 || lane < 60) && xb < W;
   const int c = cg * 4;        // channel offset: ring reads, Xt writes
-  const int cw = wslot * 4;    // position inside a tap row of wsm
+  const int cw = cg * 4;       // position inside a tap row of wsm (channel order)
   const f32x4 bx = *(lds_f32x4*)(wsm + 25 * CP + cw);
   const f32x2 bias0 = f32x2{bx[0], bx[1]}, bias1 = f32x2{bx[2], bx[3]};
   f32x2 acc[5][4][2];
