@@ -38,6 +38,12 @@ struct GemmArgs {
   int lower_only = 0;  // skip tiles strictly above the diagonal (square problems)
   // implicit 3x3 convolution view of A (NHWC, pad 1); M = B*H*W, K = 9*conv_c
   int conv_h = 0, conv_w = 0, conv_c = 0;
+  // K order of the convolution's weight rows: 0 = tap major, k = (ky*3 + kx) * Cin + ci (the operator entry point's layout);
+  // 1 = slab major, k = ((ci / 64) * 9 + ky*3 + kx) * 64 + ci % 64 (Cin % 64 == 0): the nine taps of one 64-channel slab are
+  // consecutive K tiles, so a workgroup re-reads the same (256 + 2 W) pixels x 128 bytes nine times in a row - a working set
+  // the XCD's L2 holds - instead of sweeping all Cin channels of its pixels once per tap (round 5; the model packs the VGG
+  // layers with Cout >= 256 this way in the 16-bit modes)
+  int conv_korder = 0;
   // EPI_QKV
   void *q = nullptr, *k = nullptr, *vt = nullptr;
   int heads = 0, hd = 0, ntok = 0, npad = 0;

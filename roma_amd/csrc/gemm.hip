@@ -64,6 +64,7 @@ int gemm_launch(const GemmArgs& a0, hipStream_t stream) {
   if (conv) {
     ROMA_REQUIRE(a.conv_c % (8 * ce) == 0, "gemm(conv3x3): Cin must be a multiple of the K slab");
     ROMA_REQUIRE(a.K == 9 * a.conv_c, "gemm(conv3x3): K != 9*Cin");
+    ROMA_REQUIRE(a.conv_korder == 0 || (a.conv_korder == 1 && a.conv_c % 64 == 0), "gemm(conv3x3): slab-major weights need Cin % 64 == 0");
   } else {
     ROMA_REQUIRE(a.lda % ce == 0, "gemm: lda must keep 16-byte alignment");
   }

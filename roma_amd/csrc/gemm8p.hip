@@ -148,8 +148,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
   {                                                                                                           \
     char* dst_ = smem + (BSEL) * BUF + (HF) * 128 * ROWB + (2 * wave) * 1024;                                 \
     if constexpr (CONV) {                                                                                     \
-      const int tap_ = ((KP) * conv_inv) >> 16;                                                               \
-      const int c0_ = ((KP) - tap_ * conv_spt) * BK;                                                          \
+      const int slab_ = ((KP) * 7282) >> 16; /* KP / 9 (exact for KP < 1024; KP < 72 here) */                 \
+      const int tap_ = a.conv_korder ? (KP) - 9 * slab_ : ((KP) * conv_inv) >> 16;                            \
+      const int c0_ = (a.conv_korder ? slab_ : (KP) - tap_ * conv_spt) * BK;                                  \
       const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                                          \
       const long soff_ = (((long)dy_ * a.conv_w + dx_) * a.conv_c + c0_) * 2;                                 \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                         \
@@ -174,8 +175,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
   {                                                                                                           \
     char* dst_ = smem + (BSEL) * BUF + (HF) * 128 * ROWB + (2 * wave + (J)) * 1024;                           \
     if constexpr (CONV) {                                                                                     \
-      const int tap_ = ((KP) * conv_inv) >> 16;                                                               \
-      const int c0_ = ((KP) - tap_ * conv_spt) * BK;                                                          \
+      const int slab_ = ((KP) * 7282) >> 16; /* KP / 9 (exact for KP < 1024; KP < 72 here) */                 \
+      const int tap_ = a.conv_korder ? (KP) - 9 * slab_ : ((KP) * conv_inv) >> 16;                            \
+      const int c0_ = (a.conv_korder ? slab_ : (KP) - tap_ * conv_spt) * BK;                                  \
       const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                                          \
       const long soff_ = (((long)dy_ * a.conv_w + dx_) * a.conv_c + c0_) * 2;                                 \
       const bool ok_ = (a_mask[HF][J] >> tap_) & 1u;                                                          \

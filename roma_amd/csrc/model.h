@@ -95,6 +95,11 @@ class Model {
   // "compose_out_conv", default 1): 1/9 of the refiners' 1x1 GEMM work and one pass over the block output disappear; the
   // result differs from the two-step evaluation only by rounding (the 16-bit modes no longer round the dropped intermediate)
   bool compose_out_conv = !(getenv("ROMA_COMPOSE_OUT") && atoi(getenv("ROMA_COMPOSE_OUT")) == 0);  // env: A/B runs
+  // VGG layers with Cout >= 256 in the 16-bit modes: weight rows in slab-major K order (gemm.h, GemmArgs::conv_korder) - the nine
+  // taps of a 64-channel slab back to back, an L2-sized working set per workgroup.  Set before the weights are packed (the
+  // environment switch exists for A/B runs; it changes only the summation order of the K loop).
+  bool vgg_slab_major = !(getenv("ROMA_CONV_KORDER") && atoi(getenv("ROMA_CONV_KORDER")) == 0);
+  int vgg_korder[12] = {0};
   bool fuse_refiner_blocks = true;  // bf16 mode: fused dw5x5+1x1 kernel at the narrow scales (option "fuse_refiner_blocks")
   // bf16 mode: DINOv2's residual stream in bf16, like the reference's bf16 backbone (encoders.py: dinov2 weights and
   // input are cast to amp_dtype); the decoder transformer keeps f32 (autocast leaves its residual f32).  Option

@@ -362,10 +362,13 @@ int Model::pack_weights() {
       if (int rc = make_lin(wg, &bf, 64, 27, &vgg[0])) return rc;
     } else {
       std::vector<float> wp((size_t)cout * 9 * cin);
+      vgg_korder[i] = (vgg_slab_major && act_dt != DT_F32 && cout >= 256 && cin % 64 == 0) ? 1 : 0;
       for (int o = 0; o < cout; ++o)
         for (int ci = 0; ci < cin; ++ci)
-          for (int k = 0; k < 9; ++k)
-            wp[(size_t)o * 9 * cin + (size_t)k * cin + ci] = w[((size_t)o * cin + ci) * 9 + k] * s[o];
+          for (int k = 0; k < 9; ++k) {
+            const size_t kk = vgg_korder[i] ? ((size_t)(ci / 64) * 9 + k) * 64 + ci % 64 : (size_t)k * cin + ci;
+            wp[(size_t)o * 9 * cin + kk] = w[((size_t)o * cin + ci) * 9 + k] * s[o];
+          }
       if (int rc = make_lin(wp, &bf, cout, 9 * cin, &vgg[i])) return rc;
     }
     vgg_cin[i] = cin;
@@ -959,7 +962,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         g.A = in; g.W = vgg[li].w; g.ldw = vgg[li].ldw; g.C = out; g.ldc = vgg_cout[li];
         g.M = nimg * h * w; g.N = vgg_cout[li]; g.K = 9 * vgg_cin[li];
         g.in_dt = act_dt; g.out_dt = act_dt; g.bias = vgg[li].b; g.act = ACT_RELU;
-        g.conv_h = h; g.conv_w = w; g.conv_c = vgg_cin[li];
+        g.conv_h = h; g.conv_w = w; g.conv_c = vgg_cin[li]; g.conv_korder = vgg_korder[li];
         RUN(gemm_launch(g, st));
         return 0;
       };
