@@ -96,9 +96,12 @@ class Model {
   // result differs from the two-step evaluation only by rounding (the 16-bit modes no longer round the dropped intermediate)
   bool compose_out_conv = !(getenv("ROMA_COMPOSE_OUT") && atoi(getenv("ROMA_COMPOSE_OUT")) == 0);  // env: A/B runs
   // VGG layers with Cout >= 256 in the 16-bit modes: weight rows in slab-major K order (gemm.h, GemmArgs::conv_korder) - the nine
-  // taps of a 64-channel slab back to back, an L2-sized working set per workgroup.  Set before the weights are packed (the
-  // environment switch exists for A/B runs; it changes only the summation order of the K loop).
-  bool vgg_slab_major = !(getenv("ROMA_CONV_KORDER") && atoi(getenv("ROMA_CONV_KORDER")) == 0);
+  // taps of a 64-channel slab back to back, an L2-sized working set per workgroup.  Measured in round 5: L2-miss traffic of the
+  // conv GEMM 477 -> 143 MB raw FETCH_SIZE per launch, and the kernel 1.6 % SLOWER (9.31 against 9.15 ms per step, three
+  // alternations on one box: profiles/r05_v15_conv_k_order_ab.log) - the misses were Infinity-Cache hits and the tap-major walk
+  // reads each pixel's channels as one contiguous run.  OFF by default; ROMA_CONV_KORDER=1 selects it (read before the weights
+  // are packed; it changes only the summation order of the K loop).
+  bool vgg_slab_major = getenv("ROMA_CONV_KORDER") && atoi(getenv("ROMA_CONV_KORDER")) == 1;
   int vgg_korder[12] = {0};
   bool fuse_refiner_blocks = true;  // bf16 mode: fused dw5x5+1x1 kernel at the narrow scales (option "fuse_refiner_blocks")
   // bf16 mode: DINOv2's residual stream in bf16, like the reference's bf16 backbone (encoders.py: dinov2 weights and
