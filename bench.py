@@ -2,12 +2,15 @@
 
 Workload (BASELINE.json metric / configs[2]; reference timing script
 tests/test_roma_upsample_inference_time.py:7-47): roma_outdoor, coarse 560 -> upsample 864,
-batch = 8 pairs per GPU, symmetric, bf16 compute, synthetic N(0,1) images and seeded synthetic
-weights (no pretrained weights / datasets offline).  A "step" = one match() over one batch,
+batch = 8 pairs per GPU, symmetric, synthetic N(0,1) images and seeded synthetic weights (no
+pretrained weights / datasets offline).  Precision = the arithmetic that timing script really
+runs (--dtype mixed, the default): its amp_dtype=bfloat16 reaches DINOv2 only
+(roma_models.py:183-188), VGG / decoder / refiners autocast to float16 (encoders.py:7,
+matcher.py:46,341) - ROMA_MIXED.  All-bfloat16 (--dtype bf16) is timed under other_configs.  A "step" = one match() over one batch,
 inputs already resident in HBM.  N > 1: one process per GPU, pairs sharded 8 per GPU (weak
 scaling), the only collective is the RCCL gather of the results.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py                                           # N = 1, 50 timed steps after 10 warm-ups
     python bench.py --gpus 8 --steps 20 --warmup 3            # re-executes itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
@@ -106,13 +109,14 @@ class DryMatcher:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)   # SURVEY 8d protocol: >= 50 timed steps after 10 warm-ups (~6 s)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=None, help="image pairs per GPU per step (default 8; 1 for --config coarse)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "mixed"],
-                    help="bf16 = the metric's dtype, one 16-bit format everywhere; f16 = the reference's default amp_dtype "
-                         "(IEEE binary16 storage, libroma_hip_f16.so); mixed = what the reference's timing script really runs: "
-                         "bf16 DINOv2 + binary16 VGG / decoder / refiners (ROMA_MIXED); f32 = the exact parity mode")
+    ap.add_argument("--dtype", default="mixed", choices=["bf16", "f16", "f32", "mixed"],
+                    help="mixed (default) = what the reference's bf16 timing script really computes: bf16 DINOv2 + binary16 "
+                         "VGG / decoder / refiners (ROMA_MIXED) - the parity-bearing 16-bit mode; bf16 = one 16-bit format "
+                         "everywhere; f16 = the reference's default amp_dtype (IEEE binary16 storage, libroma_hip_f16.so); "
+                         "f32 = the exact parity mode")
     ap.add_argument("--config", default="full", choices=["full", "coarse"],
                     help="full = 560 -> 864 upsample path (the metric); coarse = coarse-only 560 (BASELINE config 2)")
     ap.add_argument("--coarse", type=int, default=560)
@@ -127,6 +131,9 @@ def main():
                          "indoor weights) and the f16 storage mode, each with its own roofline object")
     ap.add_argument("--cpu-baseline-reps", type=int, default=3)
     ap.add_argument("--dry", action="store_true", help="CPU-only launch-logic check: gloo backend, stand-in match()")
+    ap.add_argument("--compact-gather", action="store_true",
+                    help="N > 1: gather only the predicted warp channels + certainty, the root rebuilds the constant grid "
+                         "channels (-40 %% of the root's ingress; byte-identical result, roma_amd/distributed.py)")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 1 if args.config == "coarse" else 8
@@ -193,7 +200,7 @@ def main():
         warp, cert = model.match(inp["im_A"], inp["im_B"], **kw)
         if world > 1:
             drain()  # queued behind this step's kernels: the previous gather has had the whole match() to finish
-            pending[0] = gather_results(warp, cert, n_pairs, async_op=True)
+            pending[0] = gather_results(warp, cert, n_pairs, async_op=True, compact_grid=args.compact_gather)
         return warp, cert
 
     if args.warmup == 0 and not args.dry:
@@ -250,6 +257,10 @@ def main():
     finite = bool(torch.isfinite(out[1]).all()) if out[1] is not None else True
 
     what = (f"{args.coarse}->{args.upsample}, symmetric, upsample_preds" if full else f"{args.coarse} coarse-only, symmetric")
+    policy = {"mixed": "precision policy of the reference's bf16 timing script: bfloat16 DINOv2 + float16 autocast for VGG / decoder / "
+                       "refiners (ROMA_MIXED), f32 accumulate",
+              "bf16": "bfloat16 storage everywhere, f32 accumulate", "f16": "IEEE binary16 storage everywhere, f32 accumulate",
+              "f32": "exact f32 (f32-input MFMA)"}[args.dtype]
     result = {
         "metric": "image-pairs/sec, roma_outdoor 560->864, batch=8 per GPU" if full else
                   "image-pairs/sec, roma_outdoor coarse-only 560, batch=1 (BASELINE config 2; not the headline metric)",
@@ -258,8 +269,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"roma_outdoor match() {what}, {args.batch} pairs/GPU/step, seeded synthetic weights + N(0,1) images",
+        # the reference script's "bf16" run IS this mix (16-bit MFMA rate for both formats); --dtype bf16 = all-bfloat16
+        "dtype": "bf16" if args.dtype == "mixed" else args.dtype, "data": "synthetic",
+        "config": {"workload": f"roma_outdoor match() {what}, {args.batch} pairs/GPU/step, seeded synthetic weights + N(0,1) images; {policy}",
+                   "precision_policy": args.dtype,
                    "global_batch": n_pairs, "streams_per_gpu": int(os.environ.get("ROMA_STREAMS", args.streams)),
                    "parallelism": (f"pairs sharded x{world}, {'gloo (dry run)' if args.dry else 'RCCL'} gather of results "
                                    "(step i's gather overlaps step i+1's match)") if world > 1 else "single GPU",
@@ -272,7 +285,9 @@ def main():
         result["pairs_per_s_per_rank"] = per_rank
         result["ms_per_step_per_rank"] = [1e3 * args.batch / v for v in per_rank]
         # what the root receives per step: (world - 1) shards of warp [b, H, 2W, 4] + certainty [b, H, 2W] f32
-        result["gather_bytes_per_step_into_rank0"] = int((world - 1) * (out[0][:args.batch].numel() + out[1][:args.batch].numel()) * 4) if rank == 0 else None
+        result["gather_bytes_per_step_into_rank0"] = int((world - 1) * (out[0][:args.batch].numel() // (2 if args.compact_gather else 1)
+                                                                       + out[1][:args.batch].numel()) * 4) if rank == 0 else None
+        result["compact_gather"] = bool(args.compact_gather)
         result["single_gpu_no_gather_pairs_per_s_per_rank"] = solo_all  # same binary, same GPUs, gather off (N = 1 yardstick)
         result["gather_overhead_frac"] = 1.0 - (n_pairs * args.steps / dt) / sum(solo_all)
         result["gather_wait_ms_rank0"] = {"median": statistics.median(gather_ms) if gather_ms else None,
@@ -397,7 +412,7 @@ def main():
         else:
             result["parity"] = None
 
-    default_run = full and args.dtype == "bf16" and args.coarse == 560 and args.upsample == 864 and args.batch == 8
+    default_run = full and args.dtype == "mixed" and args.coarse == 560 and args.upsample == 864 and args.batch == 8
     if rank == 0 and world == 1 and default_run and not args.no_other_configs:
         # ---- the other single-GPU configurations of BASELINE.json, as nested objects of the same JSON line (they are NOT
         # the metric): each builds its own handle, is timed like the main loop (synchronise / K steps / synchronise) and
@@ -453,18 +468,10 @@ def main():
             "config2_coarse_only_b1_bf16": side_config("bf16", False, 1, 30, 5, 0, 1, "match_full_coarse.npz"),
             "config5_indoor_f32_b8": side_config("f32", True, 8, 3, 1, 2, 3, "match_full8_indoor.npz"),
             "f16_storage_b8 (the reference's default amp_dtype)": side_config("f16", True, 8, 10, 3, 0, 1, "match_full8.npz"),
-            # the precision mix the reference's timing script really runs (amp_dtype = bfloat16 reaches DINOv2 only,
-            # roma_models.py:183-188; VGG / decoder / refiners autocast to float16): the parity-bearing 16-bit line
-            "mixed_bf16_dinov2_f16_rest_b8 (the reference timing script's policy)": side_config("mixed", True, 8, 10, 3, 0, 1, "match_full8.npz"),
+            # one 16-bit format everywhere (narrower than what the reference computes: its VGG / decoder / refiners autocast
+            # to float16 whatever amp_dtype is) - kept as a timed, parity-gated side line since round 6
+            "all_bf16_storage_b8": side_config("bf16", True, 8, 10, 3, 0, 1, "match_full8.npz"),
         }
-        # The parity-bearing 16-bit line at the TOP level, next to the timed bf16 mode's `parity`: ROMA_MIXED is what the
-        # reference's own timing script computes (tests/test_roma_upsample_inference_time.py:45 + roma_models.py:183-188), runs
-        # at the speed of the bf16 mode and holds the continuous part of the pipeline to ~1.4e-3 of the reference's fp32 output.
-        mx = result["other_configs"]["mixed_bf16_dinov2_f16_rest_b8 (the reference timing script's policy)"]
-        result["parity_mixed_precision"] = {
-            "mode": "ROMA_MIXED: bfloat16 DINOv2 + binary16 VGG / decoder / refiners (amp_dtype=bfloat16, decoder_dtype=float16)",
-            "value": mx["value"], "unit": "image-pairs/s", "ms_per_step": mx["ms_per_step"], "same_workload_as_value": True,
-            **(mx.get("parity") or {})}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle (CPU restatement of the reference; the reference itself is not on the GPU box) on

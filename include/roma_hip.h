@@ -173,7 +173,7 @@ int roma_destroy(roma_handle_t h);
  * "rb24w" 1 / 0 = C = 24 fused block: wave-private kernel (default) / two-barrier workgroup kernel; "rb144_1b" 1 / 0 = C = 144
  * fused block: one barrier per row (default) / two; "gemm8p_sched" 1 / 0 = K-loop schedule of the 8-phase GEMM: k-half
  * phases (default) / quadrant phases (bit-identical results); "rb_wide" 1 / 0 = the C = 576 ConvRefiner block as ONE fused kernel
- * (default) / as dwconv5x5 + 1x1 GEMM; "ws1x1" 1 / 0 = the N = K = 576 refiner 1x1 on the
+ * (measured slower: off) / as dwconv5x5 + 1x1 GEMM (default; ROMA_RB_WIDE=1 enables the fused kernel); "ws1x1" 1 / 0 = the N = K = 576 refiner 1x1 on the
  * weight-stationary kernel (default) / on the 256 x 192 tile kernel (bit-identical results).  Every alternative computes the same values (the stencil / block
  * kernels bit for bit); -1 restores the default (or the environment variable of the same name in upper case, ROMA_...). */
 int roma_tuning(const char* key, int value);

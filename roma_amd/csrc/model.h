@@ -66,9 +66,18 @@ class Arena {
   char* base = nullptr;
   size_t cap = 0, off = 0, peak = 0;
   bool dry = true;
+  // set when a live allocation did not fit the planned capacity (an option changed between roma_finalize's dry run and the
+  // call): the request is then served from the START of the arena - aliased, so the call's results are garbage, but no
+  // kernel writes outside the hipMalloc'd workspace - and the entry point reports the error instead of returning results
+  bool overflow = false;
   void reset() { off = 0; }
   void* alloc(size_t bytes) {
     off = (off + 255) & ~(size_t)255;
+    if (!dry && off + bytes > cap) {
+      overflow = true;
+      if (off > peak) peak = off;
+      return bytes <= cap ? (void*)base : nullptr;
+    }
     void* p = dry ? reinterpret_cast<void*>((uintptr_t)0x1000 + off) : (void*)(base + off);
     off += bytes;
     if (off > peak) peak = off;

@@ -1191,6 +1191,11 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         // measured in round 3 and is slower: 97.4 ms/step whole batch, 98.6 / 99.3 / 101.3 with 400 / 200 / 100 MiB
         // groups - the smaller launches lose more than the cache hits win, profiles/r03_v1_ab_attn_map_refiner_groups.log.)
         bool composed = false, final_done = false;
+        if (dry && fused) {  // plan the FINAL block's delta buffer whatever "compose_out_conv" is now: the option may change later
+          const size_t mk = arena.mark();
+          (void)AL((size_t)M * 4, 4);
+          arena.release(mk);
+        }
         for (int b = 0; b < 9; ++b) {
           if (b == 8 && compose_out_conv && fused) {
             // narrow scales: the FINAL form of the fused block - depthwise + the composed C -> 3 map on the MFMA, 16 bytes of
@@ -1271,6 +1276,12 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
     flow_fin = flow; cert_fin = cert;
     if (!up) { flow_p1 = flow; cert_p1 = cert; }
     arena.release(pass_mark);
+  }
+  if (!dry && (arena.overflow || persist.overflow)) {
+    arena.overflow = persist.overflow = false;
+    set_error("roma_match / roma_forward: the workspace planned by roma_finalize is too small for this call (an option that "
+              "changes the buffer plan was switched after roma_finalize); the results of this call are invalid");
+    return -5;
   }
   if (fw) return 0;
   // =============================== epilogue (matcher.py:839-850, 891-929)

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void refiner_block_wide_kernel(const bf16_t
   }
 }
 
-int g_rb_wide = -1;  // roma_tuning("rb_wide", v): 1 = this kernel for C = 576 (default), 0 = dwconv5x5 + 1x1 GEMM, 2 / 3 = this kernel with the scalar / packed stencil, -1 = env ROMA_RB_WIDE
+int g_rb_wide = -1;  // roma_tuning("rb_wide", v): 1 = this kernel for C = 576, 0 = dwconv5x5 + 1x1 GEMM (default: the fused kernel measured slower), 2 / 3 = this kernel with the scalar / packed stencil, -1 = env ROMA_RB_WIDE
 
 bool refiner_block_wide_supported(int Cp, int dt) { return dt == DT_BF16 && Cp == RW_C; }
 
@@ -395,7 +395,11 @@ int refiner_block_wide_try_launch(const void* in, void* out, const float* dw_w, 
   ROMA_REQUIRE(ntiles < (1l << 30), "refiner_block_wide: grid too large");
   // algorithmic work of the block: the 1x1's FLOPs (the stencil's 50 FLOP per element ride along)
   ProfScope ps("refiner_block_wide_kernel<576>", 2.0 * (double)B * H * W * (double)Cp * Cp, "flop", s);
-  const int dbg = getenv("ROMA_RBW_DBG") ? atoi(getenv("ROMA_RBW_DBG")) : 0;  // ablations (tools/bench_refiner_wide.py): 1 no stencil, 2 no MFMA, 4 no DMA after the prologue, 8 no tap reads, 16 no epilogue
+#ifdef ROMA_TOOLS_BUILD  // ablations (tools/bench_refiner_wide.py): 1 no stencil, 2 no MFMA, 4 no DMA after the prologue, 8 no tap reads, 16 no epilogue
+  static const int dbg = getenv("ROMA_RBW_DBG") ? atoi(getenv("ROMA_RBW_DBG")) : 0;
+#else  // the shipped libraries never take ablation bits from the environment (they produce wrong outputs by design)
+  constexpr int dbg = 0;
+#endif
   static const int pk_env = getenv("ROMA_RB_WIDE_PK") ? atoi(getenv("ROMA_RB_WIDE_PK")) : 1;
   const int mode = g_rb_wide >= 2 ? g_rb_wide : 0;  // roma_tuning("rb_wide", 2 / 3): force the scalar / packed stencil (A/B)
   const bool pk = mode == 3 ? true : (mode == 2 ? false : pk_env != 0);

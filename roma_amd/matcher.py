@@ -323,6 +323,13 @@ class RegressionMatcher:
         b, c, H, W = im_A.shape
         assert tuple(im_B.shape) == tuple(im_A.shape), "For batched images we assume same size"
         dev = im_A.device
+        # same device contract as match(): the handle does hipSetDevice(self.device), so a tensor of another GPU (or a CPU
+        # im_B) would reach the kernels as a foreign pointer - a memory fault instead of a Python exception
+        if dev.index is not None and dev.index != self.device.index:
+            raise ValueError(f"roma_amd.forward: inputs live on {dev} but this matcher was built for {self.device}; "
+                             "use one matcher (one handle) per GPU")
+        dev = self.device
+        im_A, im_B = im_A.to(dev), im_B.to(dev)
         if upsample:
             if (H, W) != tuple(self.upsample_res):
                 raise RuntimeError(f"forward(upsample=True): images are {(H, W)} but upsample_res is {tuple(self.upsample_res)}")
@@ -586,8 +593,9 @@ def roma_model(resolution, upsample_preds, device=None, weights=None, dinov2_wei
     compatibility; the fused HIP local-correlation kernel is always used.
 
     Accepted: `amp_dtype` float32 (exact-f32 MFMA parity mode), bfloat16 (libroma_hip.so), float16 (libroma_hip_f16.so);
-    `resolution` a multiple of 56 per side (14 for the DINOv2 patch grid as in the reference, and 8 because the VGG
-    pyramid is kept un-floored down to stride 8); `upsample_res` a multiple of 8."""
+    `resolution` a multiple of 14 per side (the DINOv2 patch grid, asserted as in the reference); sides that are not
+    multiples of 8 are fine - the VGG pyramid floors at every max-pool like the reference's (126 x 154 -> 182 x 198 is a
+    tested configuration); `upsample_res` any size the reference accepts."""
     resolution = _to_hw(resolution)
     upsample_res = _to_hw(upsample_res)
     assert resolution[0] % 14 == 0, "Needs to be multiple of 14 for backbone"

@@ -531,6 +531,35 @@ def test_gloo_world2_gather(tmp_path):
         "        assert W.shape == (1, 4, 6, 4) and Cc.shape == (1, 4, 6) and float(W.min()) == 7.0 and float(Cc.max()) == 9.0\n"
         "    else:\n"
         "        assert W is None and Cc is None\n"
+        "# round 6: compact_grid - symmetric warps travel without their constant grid channels and the root rebuilds them:\n"
+        "# byte-identical to the plain gather (even, ragged and async; the root takes the grid from its own shard)\n"
+        "from roma_amd.distributed import symmetric_grid\n"
+        "H, Wd = 8, 12\n"
+        "grid = symmetric_grid(H, Wd, 'cpu')\n"
+        "for n in (6, 5, 1):\n"
+        "    s, c = shard_pairs(n, r, w)\n"
+        "    g = torch.Generator().manual_seed(100 + r)\n"
+        "    warp = torch.rand((c, H, 2 * Wd, 4), generator=g) * 2 - 1\n"
+        "    warp[:, :, :Wd, :2] = grid\n"
+        "    warp[:, :, Wd:, 2:] = grid\n"
+        "    cert = torch.rand((c, H, 2 * Wd), generator=g)\n"
+        "    Wf, Cf = gather_results(warp, cert, n)\n"
+        "    Wc, Cc = gather_results(warp, cert, n, compact_grid=True)\n"
+        "    Wa, Ca = gather_results(warp, cert, n, async_op=True, compact_grid=True).wait()\n"
+        "    if r == 0:\n"
+        "        assert Wc.shape == Wf.shape == (n, H, 2 * Wd, 4)\n"
+        "        assert torch.equal(Wc.view(torch.int32), Wf.view(torch.int32)) and torch.equal(Cc, Cf)\n"
+        "        assert torch.equal(Wa.view(torch.int32), Wf.view(torch.int32)) and torch.equal(Ca, Cf)\n"
+        "    else:\n"
+        "        assert Wc is None and Wa is None\n"
+        "# root with an EMPTY shard (dst = 1 of a 1-pair job): the grid comes from the reference's linspace formula\n"
+        "n = 1\n"
+        "s, c = shard_pairs(n, r, w)\n"
+        "warp = torch.zeros((c, H, 2 * Wd, 4)); warp[:, :, :Wd, :2] = grid; warp[:, :, Wd:, 2:] = grid\n"
+        "Wc, Cc = gather_results(warp, torch.ones((c, H, 2 * Wd)), n, dst=1, compact_grid=True)\n"
+        "if r == 1:\n"
+        "    assert Wc.shape == (1, H, 2 * Wd, 4) and torch.equal(Wc[0, :, :Wd, :2], grid) and torch.equal(Wc[0, :, Wd:, 2:], grid)\n"
+        "    assert float(Wc[0, :, :Wd, 2:].abs().max()) == 0.0\n"
         "if r == 0:\n"
         "    print('GATHER_OK')\n"
         "dist.destroy_process_group()\n")

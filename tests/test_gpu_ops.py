@@ -1118,7 +1118,11 @@ def test_refiner_block_wide_fused(lib, B, H, W):
     ok(lib, lib.roma_op_dwconv5x5(P(xin), P(t), P(wp), P(bd), B, H, W, Cp, BF16, None))
     ok(lib, lib.roma_op_gemm(P(t), Cp, P(pwd), Cp, P(y2), Cp, B * H * W, Cp, Cp, 1, 0, 0, 0, P(pbd), None, None, 0, 0, 1.0, BF16, BF16, None))
     torch.cuda.synchronize()
-    assert torch.equal(t.cpu().view(torch.int16), mid.permute(0, 2, 3, 1).contiguous().view(torch.int16)) or True  # (mid is f64-rounded)
+    # the stand-alone stencil accumulates in f32, `mid` is the f64 result rounded once: equal up to one bf16 ulp, and
+    # almost everywhere bit for bit
+    tm, mm = t.cpu().float(), mid.permute(0, 2, 3, 1).contiguous().float()
+    assert float((tm - mm).abs().max()) <= 2.0 ** -7 * float(mm.abs().max()) + 1e-6
+    assert float((tm.view(torch.int32) == mm.view(torch.int32)).float().mean()) > 0.98
     d = (outs[0].float() - y2.float()).abs()
     assert float(d.max()) <= 2.0 ** -7 * float(y2.float().abs().max()) + 1e-6, float(d.max())  # within one bf16 ulp of each other
     assert float((outs[0].view(torch.int16) == y2.view(torch.int16)).float().mean()) > 0.98

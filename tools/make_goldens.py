@@ -249,6 +249,16 @@ def mega():
     print(meta)
 
 
+def block_sums(w, c, blk=8):
+    """{warp_blocksum [B, H/8, 2W/8, 2], cert_blocksum [B, H/8, 2W/8]} in f64 (symmetric output, H and W multiples of 8)."""
+    B, H, W2, _ = w.shape
+    W = W2 // 2
+    pred = np.concatenate([w[:, :, :W, 2:], w[:, :, W:, :2]], axis=2).astype(np.float64)
+    wb = pred.reshape(B, H // blk, blk, W2 // blk, blk, 2).sum(axis=(2, 4))
+    cb = c.astype(np.float64).reshape(B, H // blk, blk, W2 // blk, blk).sum(axis=(2, 4))
+    return dict(warp_blocksum=wb, cert_blocksum=cb)
+
+
 def full8(name="match_full8", seed_w=0, seed_in=1):
     """BASELINE configs 3 / 5 geometry: B=8 symmetric 560 -> 864 fp32 (16 directed pairs: batch-index arithmetic
     (b + B) mod 2B at full size).  Default seeds = bench.py's rank-0 workload, so the bench line can carry a parity
@@ -260,6 +270,10 @@ def full8(name="match_full8", seed_w=0, seed_in=1):
                warp_rowsum=w.sum(axis=(2, 3), dtype=np.float64), cert_rowsum=c.sum(axis=2, dtype=np.float64),
                cls16_argmax=st["cls16_argmax"], cls16_top2gap=st["cls16_top2gap"], gm_cert16=st["gm_cert16"],
                gm_flow16=st["gm_flow16"])
+    # round 6: EVERY output pixel of the benchmark geometry enters a gated quantity - f64 sums over 8 x 8 pixel blocks of
+    # the certainty and of the two predicted warp channels (left half: [..., 2:], right half: [..., :2]; the other two are
+    # the constant grid, compared exactly elsewhere); the 1/8 lattice above holds 1 pixel in 64
+    out.update(block_sums(w, c))
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     meta = dict(coarse=560, up=864, B=8, symmetric=True, seed_w=seed_w, seed_in=seed_in, subsample=8,
                 min_top2_gap=float(st["cls16_top2gap"].min()), ref_seconds=dt,
