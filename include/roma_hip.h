@@ -174,7 +174,11 @@ int roma_destroy(roma_handle_t h);
  * fused block: one barrier per row (default) / two; "gemm8p_sched" 1 / 0 = K-loop schedule of the 8-phase GEMM: k-half
  * phases (default) / quadrant phases (bit-identical results); "rb_wide" 1 / 0 = the C = 576 ConvRefiner block as ONE fused kernel
  * (measured slower: off) / as dwconv5x5 + 1x1 GEMM (default; ROMA_RB_WIDE=1 enables the fused kernel); "ws1x1" 1 / 0 = the N = K = 576 refiner 1x1 on the
- * weight-stationary kernel (default) / on the 256 x 192 tile kernel (bit-identical results).  Every alternative computes the same values (the stencil / block
+ * weight-stationary kernel (default) / on the 256 x 192 tile kernel (bit-identical results); "gp_col" 1 / 0 = the GP's blocked
+ * Cholesky solve left-looking, one launch per block column (default) / the right-looking chain of three launches per column
+ * (results agree to f32 rounding); "gp_col_leader" 1 / 0 = inside a column launch one leader workgroup per image factorises
+ * the diagonal block and hands its inverse to the row-block workgroups (default) / every workgroup factorises its own copy
+ * (bit-identical results; also the time-out path of the hand-off).  Every alternative computes the same values (the stencil / block
  * kernels bit for bit); -1 restores the default (or the environment variable of the same name in upper case, ROMA_...). */
 int roma_tuning(const char* key, int value);
 /* measuring tool (tools/bench_gemm_ablation.py): after a GEMM launched with the "gemm_dbg" trace bit (32768), copies the
@@ -221,7 +225,10 @@ int roma_op_layernorm_dt(const void* x, int dt_in, const float* w, const float* 
 int roma_op_gemm_res_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K,
                           const float* bias, const float* scale, const void* res, long ldr, void* stream);
 /* Batched SPD solve  (A + 0 ) X = F  via blocked Cholesky: A [batch,n,n] f32 (destroyed), Ft [batch, d, n] = F^T,
- * overwritten by X^T.  Workspaces: LT [batch,n,n], Linv/LinvT [batch, n/64, 64, 64].  n multiple of 64. */
+ * overwritten by X^T.  Workspaces: LT [batch,n,n], Linv/LinvT [batch, n/64, 64, 64].  n multiple of 64.
+ * Augmented layout (what the GP uses): Ft == A + n * n, i.e. ONE (n + d) x n matrix per item with the right-hand sides right
+ * behind A (items (n + d) * n floats apart when batch > 1) - the forward substitution then runs inside the factorisation,
+ * one launch per 64-column block (chol_col.hip; roma_tuning("gp_col", 0) selects the right-looking launch chain instead). */
 int roma_op_cholesky_solve_t(float* A, float* Ft, float* LT, float* Linv, float* LinvT, int n, int d, int batch,
                              void* stream);
 /* GP.forward (matcher.py:291-323) with the cosine kernel (matcher.py:191-200, T = 0.2) and sigma_noise = 0.1:

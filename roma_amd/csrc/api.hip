@@ -240,6 +240,7 @@ int roma_tuning(const char* key, int value) {
   else if (k == "gemm8p_sched") g_gemm8p_sched = value;
   else if (k == "ws1x1") g_ws1x1_mode = value;
   else if (k == "lc_mode") g_lc_mode = value;
+  else if (k == "lc_bin") g_lc_bin = value;
   else if (k == "conv64") g_conv64_mode = value;
   else if (k == "attn_xcd") g_attn_xcd_map = value;
   else if (k == "attn_exp2") g_attn_exp2 = value;
@@ -247,6 +248,8 @@ int roma_tuning(const char* key, int value) {
   else if (k == "rb144_1b") g_rb144_1b = value;
   else if (k == "rb_wide") g_rb_wide = value;
   else if (k == "dw_ring") g_dw_ring = value;
+  else if (k == "gp_col") g_gp_col = value;
+  else if (k == "gp_col_leader") g_gp_col_leader = value;
   else {
     set_error("roma_tuning: unknown key " + k);
     return ROMA_ERR_ARG;
@@ -393,6 +396,10 @@ int roma_op_gemm_res_bf16(const void* A, long lda, const void* W, long ldw, void
 
 int roma_op_cholesky_solve_t(float* A, float* Ft, float* LT, float* Linv, float* LinvT, int n, int d, int batch,
                              void* stream) {
+  // Ft == A + n * n with batch > 1 cannot be the dense [batch, n, n] + [batch, d, n] layout (Ft would overlap the second
+  // matrix): it is the augmented layout of the GP - one (n + d) x n matrix per item, items (n + d) * n floats apart
+  if (batch > 1 && Ft == A + (long)n * n)
+    return cholesky_solve_t(A, Ft, LT, Linv, LinvT, n, d, batch, S(stream), (long)(n + d) * n, (long)(n + d) * n);
   return cholesky_solve_t(A, Ft, LT, Linv, LinvT, n, d, batch, S(stream));
 }
 

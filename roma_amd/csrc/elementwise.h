@@ -53,6 +53,15 @@ int transpose_launch(const float* in, float* out, int n, long ld, int batch, hip
 int chol_diag_launch(float* A, long ld, long strideA, float* Linv, float* LinvT, int k, int nblk, int batch,
                      hipStream_t s);
 
+// Round 6 (chol_col.hip): block column k of the left-looking factorisation of the augmented system A [batch][(n + d) x n]
+// (ld floats per row): L[R, S_k] for every row block R below the diagonal block incl. the d right-hand-side rows, the inverse
+// tables of block k, LT[S_k, R] = L[R, S_k]^T.  The factor's diagonal blocks travel in LT's diagonal blocks until
+// chol_col_restore_launch copies them into A (behind the last column).
+int chol_col_launch(float* A, long ld, long strideA, float* LT, long strideLT, int n, int d, float* Linv, float* LinvT, int k,
+                    int nblk, int batch, unsigned epoch, hipStream_t s);
+extern int g_gp_col_leader;  // roma_tuning("gp_col_leader"): leader / follower hand-off inside a column launch on / off
+int chol_col_restore_launch(float* A, long ld, long strideA, const float* LT, long strideLT, int n, int batch, hipStream_t s);
+
 // pad the trailing (npad - n) diagonal of a Gram matrix with identity and zero its off-diagonals
 int pad_identity_launch(float* A, long ld, long strideA, int n, int npad, int batch, hipStream_t s);
 
@@ -82,6 +91,7 @@ int dwconv5x5_launch(const void* in, void* out, const float* w, const float* bia
 int dwconv5x5_ring_try_launch(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp, int dt,
                               hipStream_t s);
 extern int g_dw_ring;
+extern int g_gp_col;  // model.hip: roma_tuning("gp_col") - left-looking block-column Cholesky (chol_col.hip) on / off
 
 // out_conv (C->3, f32) fused with the flow / certainty update (matcher.py:177-178, 496-506)
 int refiner_out_launch(const void* d, long ldd, int dt, const float* w /*[3][Cp]*/, const float* b /*[3]*/,

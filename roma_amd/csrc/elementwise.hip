@@ -3,6 +3,7 @@
 // one wave64 per row for row reductions, f32 math everywhere.
 #include <algorithm>
 #include "elementwise.h"
+#include "chol_diag.h"
 #include <stdio.h>
 
 #include <stdlib.h>
@@ -427,10 +428,8 @@ int transpose_launch(const float* in, float* out, int n, long ld, int batch, hip
 // arithmetic and its order unchanged: bit-identical results.
 __global__ __launch_bounds__(256) void chol_diag_kernel(float* A, long ld, long strideA, float* Linv, float* LinvT,
                                                         int k, int nblk) {
-  // 68-float rows: 16-byte aligned and conflict free for lane-per-row ds_read_b128 (bank = 4 * lane).  The inner loops
-  // move 4 columns per LDS operation (row piece of this lane + a broadcast piece of the transposed copy): the scalar
-  // version issued ~10k dependent single-dword LDS operations per call and took 123 us on the GP's critical path.
-  constexpr int S = 68;
+  // the factorisation / inverse wave pair and the write-back live in chol_diag.h (shared with chol_col.hip)
+  constexpr int S = CHOL_S;
   __shared__ __attribute__((aligned(16))) float L[64 * S];   // L[i][c]   (lane i owns row i)
   __shared__ __attribute__((aligned(16))) float LT[64 * S];  // LT[j][c] = L[c][j]   (broadcast source)
   __shared__ __attribute__((aligned(16))) float XT[64 * S];  // XT[c][t] = X[t][c]   (lane c owns row c)
@@ -445,71 +444,11 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(float* A, long ld, long 
   }
   if (tid == 0) progress = -1;
   __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {  // columns in four bands: a band's steps touch column groups >= 16 jb only
-      for (int j = 16 * jb; j < 16 * jb + 16; ++j) {
-        const float d = sqrtf(L[j * S + j]);
-        const float lij = (i == j) ? d : L[i * S + j] / d;
-        L[i * S + j] = lij;   // rows < j: harmless garbage in the strictly upper part
-        LT[j * S + i] = lij;  // column j of the factor, contiguous
-        // column j is final: let the inverse take row j.  Release / acquire at workgroup scope (round 5): one
-        // s_waitcnt lgkmcnt(0) in front of the flag store instead of relying on the LDS executing different waves' DS
-        // operations in one FIFO, which the memory model does not promise.
-        __hip_atomic_store(&progress, j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // a_ic -= l_ij * l_cj for c > j.  Every column group of the band's range every time (selects, no trip count that
-        // depends on j): the LDS operations of a step are independent and pipeline, instead of ~150 cycles of latency per
-        // group; the compile-time band start drops the 37 % of the groups that lie wholly left of column j.
-#pragma unroll
-        for (int c = 16 * jb; c < 64; c += 4) {
-          f32x4 a = *reinterpret_cast<const f32x4*>(&L[i * S + c]);
-          const f32x4 lc = *reinterpret_cast<const f32x4*>(&LT[j * S + c]);  // same address in every lane: broadcast
-#pragma unroll
-          for (int u = 0; u < 4; ++u) a[u] = (c + u > j) ? a[u] - lij * lc[u] : a[u];
-          *reinterpret_cast<f32x4*>(&L[i * S + c]) = a;
-        }
-      }
-    }
-  } else if (wave == 1) {
-    // inverse: lane c solves L x = e_c by forward substitution; x lives in XT[c][.].  Four interleaved partial sums
-    // (t mod 4) keep the dependent-FMA chain at 16 instead of 64 per row.  Row r reads L[r][t <= r] only: final once the
-    // factorisation has published step r (the entries right of the diagonal it may see half-updated are masked out).
-    const int c = i;
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {  // rows in four bands: row r only needs the unknowns t < r, i.e. groups < 16 (rb + 1)
-      for (int r = 16 * rb; r < 16 * rb + 16; ++r) {
-        while (__hip_atomic_load(&progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < r) __builtin_amdgcn_s_sleep(1);
-        f32x4 part = {(r == c) ? 1.f : 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 16 * (rb + 1); t += 4) {
-          const f32x4 lr = *reinterpret_cast<const f32x4*>(&L[r * S + t]);   // broadcast
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(&XT[c * S + t]);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) part[u] = (t + u < r) ? part[u] - lr[u] * xv[u] : part[u];
-        }
-        XT[c * S + r] = ((part[0] + part[1]) + (part[2] + part[3])) / L[r * S + r];
-      }
-    }
-  }
+  if (wave == 0) chol_diag_factor_wave(L, LT, &progress, i);
+  else if (wave == 1) chol_diag_inverse_wave(L, XT, &progress, i);
   __syncthreads();
-  float* Li = Linv + ((long)blockIdx.x * nblk + k) * 4096;
-  float* LiT = LinvT + ((long)blockIdx.x * nblk + k) * 4096;
-  // write-back, 16 bytes per lane: the factor (upper part zeroed), Linv^T rows (= XT rows) and Linv (transposed read)
-  for (int idx = tid; idx < 64 * 16; idx += 256) {
-    const int row = idx >> 4, c4 = (idx & 15) * 4;
-    f32x4 lv = *reinterpret_cast<const f32x4*>(&L[row * S + c4]);
-    f32x4 xt = *reinterpret_cast<const f32x4*>(&XT[row * S + c4]);  // XT[row][c4..] = X[c4..][row] = LinvT[row][c4..]
-    f32x4 xl;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (c4 + u > row) lv[u] = 0.f;
-      if (c4 + u < row) xt[u] = 0.f;               // X[t][c] is zero for t < c
-      xl[u] = (c4 + u <= row) ? XT[(c4 + u) * S + row] : 0.f;  // Linv[row][c4+u] = X[row][c4+u]
-    }
-    *reinterpret_cast<f32x4*>(Ab + (long)row * ld + c4) = lv;
-    *reinterpret_cast<f32x4*>(LiT + row * 64 + c4) = xt;
-    *reinterpret_cast<f32x4*>(Li + row * 64 + c4) = xl;
-  }
+  chol_diag_writeback(L, XT, Ab, ld, Linv + ((long)blockIdx.x * nblk + k) * 4096, LinvT + ((long)blockIdx.x * nblk + k) * 4096,
+                      tid, 256);
 }
 
 int chol_diag_launch(float* A, long ld, long strideA, float* Linv, float* LinvT, int k, int nblk, int batch,

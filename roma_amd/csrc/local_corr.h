@@ -22,12 +22,20 @@ struct LocalCorrArgs {
   int nearest = 0;             // general form only: mode="nearest" of the plugin (local_correlation.py:19,30): one tap, weight 1
   // window form: device scratch for the tile work list, (2 * tiles + 4) ints with tiles = B * ceil(H/8) * ceil(W/8); nullptr =
   // allocate stream-ordered scratch for the call.  force_gather is set by the launcher (tuning switch).
+  // Round 6: the queries of incoherent tiles are sorted into bins of f1 (local_corr.hip, LIST form of the tile kernel); the scratch
+  // then also holds the bin counters and the sorted query list: local_corr_ws_ints(B, H, W, radius) ints in all.
   int* ws = nullptr;
   long ws_bytes = 0;
   int force_gather = 0;
   int pxmax = 0;               // set by the launcher: largest rectangle (pixels) the tile kernel's LDS stage holds
+  // set by the launcher: bin geometry and the offsets (in ints) of the bin tables / the sorted query list inside ws
+  int bin_ts = 0, bin_nx = 0, bin_ny = 0, ws_bins = 0, ws_qlist = 0;
 };
 extern int g_lc_mode;  // roma_tuning("lc_mode")
+extern int g_lc_bin;   // roma_tuning("lc_bin"): 1 = incoherent tiles through the bin-sorted LIST form (default), 0 = per-query gathers
+
+// ints of device scratch local_corr_window_launch needs for this problem (window form, tiled radii 2 / 3 / 7; 0 otherwise)
+long local_corr_ws_ints(int B, int H, int W, int radius);
 
 // Window form (integer-patch identity: all K taps share one fractional offset).
 int local_corr_window_launch(const LocalCorrArgs& a, hipStream_t stream);

@@ -240,7 +240,12 @@ template <> struct LcDot<bf16_t> {  // 64 channels per 128-byte chunk, packed pa
 // sum_c f1[slot][c] f0[query][c]  on v_mfma_f32_32x32x16 straight from the same 144-byte-pitch stage (every staged row is
 // read once per 32 queries: ~0.3 MB), and every lane - a query - then picks the (2r+2)^2 entries of its own window out of
 // its accumulators.  Wave w owns the 32 queries of tile half w & 1 and the 32-slot blocks (w >> 1), (w >> 1) + 2, ...
-template <int R, typename T, typename TOUT, bool MFMA>
+// LIST = true (round 6): the work items are not 8 x 8 tiles of the query image but groups of up to 64 queries whose windows
+// fall into one TS x TS bin of f1 (local_corr_bin_* kernels below): the queries of the tiles the classifier calls
+// incoherent, sorted by where they look.  Everything behind the query identities is the same kernel - bounding rectangle,
+// one staged copy of it, all-pairs on the matrix core - so an incoherent warp costs ~ (rectangle + 64 f0 rows) per 64 queries
+// instead of 64 x (2r+2)^2 gathered f1 pixels.  The bin edge is chosen so that the rectangle always fits the stage.
+template <int R, typename T, typename TOUT, bool MFMA, bool LIST = false>
 __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(const LocalCorrArgs a) {
   constexpr int P = 2 * R + 2, KW = 2 * R + 1, K = KW * KW;
   constexpr int NR = (P + 3) / 4;  // patch rows per wave
@@ -255,6 +260,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
   float* qfx = reinterpret_cast<float*>(qy0 + 64);          // [64]
   float* qfy = qfx + 64;                                    // [64]
   int* tinfo = reinterpret_cast<int*>(qfy + 64);            // bx0, by0, bw, bh
+  int* qpx = tinfo + 8;                                     // [64] pixel of each query inside its image, -1 = none
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (a.W + LC_TQ - 1) / LC_TQ, tiles_y = (a.H + LC_TQ - 1) / LC_TQ;
@@ -264,17 +270,26 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
   // One workgroup per listed tile; the launch covers every tile of the call and the surplus workgroups exit at once.
   // (Persistent workgroups pulling tiles from the list were measured 30 % slower on coherent warps: the two workgroups
   // of a CU then run their load and compute phases in lock-step instead of drifting apart like short-lived ones do.)
-  for (int tidx = blockIdx.x; tidx < a.ws[1]; tidx += gridDim.x) {
+  for (int tidx = blockIdx.x; tidx < (LIST ? a.ws[2] : a.ws[1]); tidx += gridDim.x) {
   __syncthreads();  // previous tile's readers of tinfo / the stage are done (grid-stride repeat only)
-  const int tile = tlist[tidx];
-  const int b = tile / tpi;
-  const int trem = tile - b * tpi;
-  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  int b, qin;        // image of the work item; this lane's query as a pixel index inside the image (-1: none)
+  if constexpr (LIST) {
+    const int* ql = a.ws + a.ws_qlist + (long)tidx * 64;
+    const int g = ql[lane];                 // global pixel index b * HW + y * W + x, or -1 (padding of the item)
+    b = __shfl(g, 0) / (int)HW;             // slot 0 of an item is always a query (local_corr_bin_scatter_kernel)
+    qin = g >= 0 ? g - b * (int)HW : -1;
+  } else {
+    const int tile = tlist[tidx];
+    b = tile / tpi;
+    const int trem = tile - b * tpi;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int qy = ty * LC_TQ + (lane >> 3), qx = tx * LC_TQ + (lane & 7);
+    qin = (qy < a.H && qx < a.W) ? qy * a.W + qx : -1;
+  }
 
-  // ---- per-query window origin (lane = query), bounding rectangle of the tile's integer patches
-  const int qy = ty * LC_TQ + (lane >> 3), qx = tx * LC_TQ + (lane & 7);
-  const bool qvalid = qy < a.H && qx < a.W;
-  const long qpix = (long)b * HW + (long)qy * a.W + qx;
+  // ---- per-query window origin (lane = query), bounding rectangle of the item's integer patches
+  const bool qvalid = qin >= 0;
+  const long qpix = (long)b * HW + (qvalid ? qin : 0);
   int x0 = 0, y0 = 0;
   float fx = 0.f, fy = 0.f;
   if (qvalid) {
@@ -291,7 +306,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
       ylo = min(ylo, __shfl_xor(ylo, off));
       yhi = max(yhi, __shfl_xor(yhi, off));
     }
-    qx0[lane] = x0; qy0[lane] = y0; qfx[lane] = fx; qfy[lane] = fy;
+    qx0[lane] = x0; qy0[lane] = y0; qfx[lane] = fx; qfy[lane] = fy; qpx[lane] = qin;
     if (lane == 0) {
       // rectangle of f1 pixels any query of the tile touches, clipped to the image (outside taps contribute zero)
       const int bx0 = max(xlo - R, 0), bx1 = min(xhi + R + 1, a.W - 1);
@@ -350,10 +365,9 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
       const int py = slotp / bwp, px = slotp - py * bwp;
       if (px < bw) off = (unsigned)((((long)(by0 + py) * a.W + (bx0 + px)) * a.ld1) * (long)sizeof(T) + piece * 16);
     } else if (slotp < nslots) {
-      const int q = slotp - (int)npx;
-      const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
-      if (gy < a.H && gx < a.W) {
-        off = (unsigned)((((long)gy * a.W + gx) * a.ld0) * (long)sizeof(T) + piece * 16);
+      const int qp = qpx[slotp - (int)npx];
+      if (qp >= 0) {
+        off = (unsigned)(((long)qp * a.ld0) * (long)sizeof(T) + piece * 16);
         from_f0 |= 1u << k;
       }
     }
@@ -376,9 +390,8 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
           const int py = slotp / bwp, px = slotp - py * bwp;
           if (px < bw) src = reinterpret_cast<const char*>(f1p + ((long)(by0 + py) * a.W + (bx0 + px)) * a.ld1 + c0) + piece * 16;
         } else {
-          const int q = slotp - (int)npx;
-          const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
-          if (gy < a.H && gx < a.W) src = reinterpret_cast<const char*>(f0p + ((long)gy * a.W + gx) * a.ld0 + c0) + piece * 16;
+          const int qp = qpx[slotp - (int)npx];
+          if (qp >= 0) src = reinterpret_cast<const char*>(f0p + (long)qp * a.ld0 + c0) + piece * 16;
         }
         uint4 v = make_uint4(0, 0, 0, 0);
         if (src) v = *reinterpret_cast<const uint4*>(src);
@@ -499,13 +512,13 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
   __syncthreads();
   for (int o = tid; o < LC_TQ * LC_TQ * K; o += 256) {
     const int q = o / K, k = o - q * K;
-    const int gy = ty * LC_TQ + (q >> 3), gx = tx * LC_TQ + (q & 7);
-    if (gy >= a.H || gx >= a.W) continue;
+    const int qp = qpx[q];
+    if (qp < 0) continue;
     const int j = k / KW, i = k - j * KW;
     const float wfx = qfx[q], wfy = qfy[q];
     const float* d = Dl + q * (P * P) + j * P + i;
     const float c = (1.f - wfy) * (1.f - wfx) * d[0] + (1.f - wfy) * wfx * d[1] + wfy * (1.f - wfx) * d[P] + wfy * wfx * d[P + 1];
-    ElemIO<TOUT>::st(outp + ((long)b * HW + (long)gy * a.W + gx) * a.ldo + k, c * a.scale);
+    ElemIO<TOUT>::st(outp + ((long)b * HW + qp) * a.ldo + k, c * a.scale);
   }
   }  // tile loop
 }
@@ -566,6 +579,78 @@ __global__ __launch_bounds__(64) void local_corr_classify_kernel(const LocalCorr
     if (coherent) a.ws[4 + tiles + basec + __popcll(mc & below)] = tile;
     else a.ws[4 + baseg + __popcll(mg & below)] = tile;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: counting sort of the incoherent tiles' queries by the TS x TS bin of f1 their window starts in.
+//   window origin ox = x0 - R, clamped to [-P, W]; bin = ((ox + P) / TS, (oy + P) / TS) of the query's image: the windows of a
+//   bin lie in a rectangle of at most (TS + P - 1)^2 pixels (windows wholly outside the image contribute zeros wherever
+//   they are put), which the launcher sizes to fit the tile kernel's stage.
+// ws + ws_bins: count [nbins] | first item [nbins] | cursor [nbins];  ws[2] = number of items (groups of <= 64 queries of
+// one bin);  ws + ws_qlist: items x 64 global pixel indices, -1 = padding (memset by the launcher).
+// The order of the queries inside a bin depends on the atomics' arrival order; the RESULT of a query does not (its dot
+// products are evaluated per (slot, query) with a fixed channel order whatever the item looks like).
+template <int R> __device__ __forceinline__ int lc_bin_of(const LocalCorrArgs& a, long pix, int b) {
+  constexpr int P = 2 * R + 2;
+  int x0, y0;
+  float fx, fy;
+  unnormalize_floor(a.warp[pix * 2 + 0], a.W, x0, fx);
+  unnormalize_floor(a.warp[pix * 2 + 1], a.H, y0, fy);
+  const int ox = min(max(x0 - R, -P), a.W), oy = min(max(y0 - R, -P), a.H);
+  return (b * a.bin_ny + (oy + P) / a.bin_ts) * a.bin_nx + (ox + P) / a.bin_ts;
+}
+
+// grid: one 64-thread workgroup per gather-list tile (the launch covers every tile of the call; surplus workgroups exit)
+template <int R, bool SCATTER>
+__global__ __launch_bounds__(64) void local_corr_bin_kernel(const LocalCorrArgs a) {
+  const int li = blockIdx.x;
+  const int nlist = a.ws[0];
+  const int tile = a.ws[4 + li];
+  if (li >= nlist) return;
+  const int lane = threadIdx.x;
+  const int tiles_x = (a.W + LC_TQ - 1) / LC_TQ, tiles_y = (a.H + LC_TQ - 1) / LC_TQ;
+  const int tpi = tiles_x * tiles_y;
+  const int b = tile / tpi;
+  const int trem = tile - b * tpi;
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int gy = ty * LC_TQ + (lane >> 3), gx = tx * LC_TQ + (lane & 7);
+  if (gy >= a.H || gx >= a.W) return;
+  const long pix = (long)b * a.H * a.W + (long)gy * a.W + gx;
+  const int bin = lc_bin_of<R>(a, pix, b);
+  const int nbins = a.B * a.bin_nx * a.bin_ny;
+  int* cnt = a.ws + a.ws_bins;
+  if constexpr (!SCATTER) {
+    atomicAdd(cnt + bin, 1);
+  } else {
+    const int slot = atomicAdd(cnt + 2 * nbins + bin, 1);
+    a.ws[a.ws_qlist + (long)cnt[nbins + bin] * 64 + slot] = (int)pix;
+  }
+}
+
+// one workgroup: items per bin = ceil(count / 64), exclusive scan -> first item of every bin, total -> ws[2]
+__global__ __launch_bounds__(1024) void local_corr_bin_scan_kernel(const LocalCorrArgs a) {
+  __shared__ int part[1024];
+  const int nbins = a.B * a.bin_nx * a.bin_ny;
+  int* cnt = a.ws + a.ws_bins;
+  const int tid = threadIdx.x;
+  const int per = (nbins + 1023) / 1024;
+  const int i0 = tid * per, i1 = min(i0 + per, nbins);
+  int sum = 0;
+  for (int i = i0; i < i1; ++i) sum += (cnt[i] + 63) >> 6;
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - sum;
+  for (int i = i0; i < i1; ++i) {
+    cnt[nbins + i] = run;
+    run += (cnt[i] + 63) >> 6;
+  }
+  if (tid == 1023) a.ws[2] = part[1023];
 }
 
 // Per-query gathers for the pixels of the tiles on the gather list: block = (list entry, round of 4 queries), one query per
@@ -658,11 +743,39 @@ static int check_common(const LocalCorrArgs& a, int ce) {
 
 int g_lc_mode = -1;  // roma_tuning("lc_mode"): -1 / 0 = tiled (MFMA all-pairs for 16-bit features) + work list (default), 1 = every tile to the gather list, 2 = per-pixel launch (the form every other radius uses)
 
+int g_lc_bin = -1;
+
+// bin edge: the largest TS with (TS + P - 1)^2 <= the smallest stage any build of the tile kernel has for this radius (the
+// 16-bit MFMA form's 320 slots for r <= 3) - one geometry for every precision keeps local_corr_ws_ints independent of it
+static int lc_bin_ts(int radius) {
+  const int P = 2 * radius + 2, pxmax = radius <= 3 ? 320 : 704;
+  int ts = 1;
+  while ((ts + P) * (ts + P) <= pxmax) ++ts;  // (ts + 1 + P - 1)^2
+  return ts;
+}
+long local_corr_ws_ints(int B, int H, int W, int radius) {
+  if (radius != 2 && radius != 3 && radius != 7) return 0;
+  const long tiles = (long)B * ((H + LC_TQ - 1) / LC_TQ) * ((W + LC_TQ - 1) / LC_TQ);
+  const int ts = lc_bin_ts(radius), P = 2 * radius + 2;
+  const long nbins = (long)B * ((W + P) / ts + 1) * ((H + P) / ts + 1);
+  return 4 + 2 * tiles + 3 * nbins + 64 * (tiles + nbins);
+}
+
 template <int R, typename T, typename TOUT, bool MFMA>
 static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   LocalCorrArgs a = a0;
   const int tiles = a.B * ((a.H + LC_TQ - 1) / LC_TQ) * ((a.W + LC_TQ - 1) / LC_TQ);
-  const size_t need = (size_t)(2 * tiles + 4) * sizeof(int);
+  constexpr int P = 2 * R + 2;
+  a.bin_ts = lc_bin_ts(R);
+  a.bin_nx = (a.W + P) / a.bin_ts + 1;
+  a.bin_ny = (a.H + P) / a.bin_ts + 1;
+  const long nbins = (long)a.B * a.bin_nx * a.bin_ny;
+  a.ws_bins = 4 + 2 * tiles;
+  a.ws_qlist = a.ws_bins + 3 * (int)nbins;
+  static const int bin_env = getenv("ROMA_LC_BIN") ? atoi(getenv("ROMA_LC_BIN")) : 1;
+  const bool binned = (g_lc_bin >= 0 ? g_lc_bin : bin_env) != 0 && (long)a.B * a.H * a.W < (1l << 31) &&
+                      (a.bin_ts + P - 1) * (a.bin_ts + P - 1) <= LcGeom<R, MFMA>::PXMAX;
+  const size_t need = (size_t)local_corr_ws_ints(a.B, a.H, a.W, R) * sizeof(int);
   bool own_ws = false;
   if (!a.ws) {  // operator entry points: stream-ordered scratch (the model passes a slice of its arena)
     ROMA_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&a.ws), need, stream));
@@ -672,7 +785,7 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   }
   a.force_gather = g_lc_mode == 1 ? 1 : 0;
   ROMA_CHECK_HIP(hipMemsetAsync(a.ws, 0, 4 * sizeof(int), stream));
-  const size_t lds_tile = (size_t)LcGeom<R, MFMA>::STAGE + 4 * 64 * 4 + 32;
+  const size_t lds_tile = (size_t)LcGeom<R, MFMA>::STAGE + 5 * 64 * 4 + 32;
   a.pxmax = LcGeom<R, MFMA>::PXMAX;  // what the classifier calls a coherent tile: its rectangle fits this kernel's stage
   static bool attr_set[64] = {false};
   int dev = 0;
@@ -690,9 +803,33 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   // gather list: one query per wave, four per workgroup.  (Eight waves per workgroup - to share the two dependent scalar
   // loads at the head of every workgroup - were measured SLOWER on the benchmark model's incoherent warps: 1.86 vs 1.60 ms
   // at r = 2, 0.96 vs 0.91 at r = 3, profiles/r03_final_visit.log; the variant was removed in round 4.)
-  hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT, 4>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
-                     stream, a);
-  ROMA_LAUNCH_CHECK();
+  if (binned) {
+    // incoherent tiles: sort their queries by target bin, then the LIST form of the tile kernel (one item = <= 64 queries of a bin)
+    ROMA_CHECK_HIP(hipMemsetAsync(a.ws + a.ws_bins, 0, (size_t)3 * nbins * sizeof(int), stream));
+    ROMA_CHECK_HIP(hipMemsetAsync(a.ws + a.ws_qlist, 0xff, (size_t)64 * (tiles + nbins) * sizeof(int), stream));
+    hipLaunchKernelGGL((local_corr_bin_kernel<R, false>), dim3((unsigned)tiles), dim3(64), 0, stream, a);
+    ROMA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(local_corr_bin_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
+    ROMA_LAUNCH_CHECK();
+    hipLaunchKernelGGL((local_corr_bin_kernel<R, true>), dim3((unsigned)tiles), dim3(64), 0, stream, a);
+    ROMA_LAUNCH_CHECK();
+    static bool attr_set_l[64] = {false};
+    if (dev < 0 || dev >= 64 || !attr_set_l[dev]) {
+      ROMA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&local_corr_tile_kernel<R, T, TOUT, MFMA, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tile));
+      if (dev >= 0 && dev < 64) attr_set_l[dev] = true;
+    }
+    // the number of items is only known on the device: at most one per tile's worth of queries plus one partial item per bin.
+    // The kernel strides over the item list, so a capped grid is enough; surplus workgroups exit at once.
+    const long max_items = (long)tiles + nbins;
+    hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT, MFMA, true>), dim3((unsigned)std::min<long>(max_items, 8192)), dim3(256),
+                       lds_tile, stream, a);
+    ROMA_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL((local_corr_list_kernel<R, T, TOUT, 4>), dim3((unsigned)tiles * 16u), dim3(256), (size_t)4 * a.C * sizeof(float),
+                       stream, a);
+    ROMA_LAUNCH_CHECK();
+  }
   if (own_ws) ROMA_CHECK_HIP(hipFreeAsync(a.ws, stream));
   return 0;
 }

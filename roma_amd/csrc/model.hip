@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <set>
 
 #include "attention.h"
@@ -681,6 +682,7 @@ int Model::match_streams(int B, const float* ima, const float* imb, const float*
 // GEMM of step k simply run over mrem + d rows and the 2 * nblk - 1 launches of the forward loop disappear from the GP's
 // launch-latency-bound chain (~0.75 ms of 10 .. 25 us launches at n = 1600); same operations on every element in the same
 // order, so the result is bit-identical to the separate loop.
+int g_gp_col = -1;  // roma_tuning("gp_col", v): 1 = left-looking block-column kernel (default), 0 = right-looking chain, -1 = env ROMA_GP_COL
 int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, int n, int d, int batch, hipStream_t st,
                      long strideA, long strideR) {
   ROMA_REQUIRE(n % 64 == 0 && n > 0 && d % 4 == 0, "cholesky_solve: n must be a multiple of 64, d of 4");
@@ -690,7 +692,17 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
   static const bool aug_env = !(getenv("ROMA_GP_AUG") && atoi(getenv("ROMA_GP_AUG")) == 0);  // A/B: 0 = always the separate forward loop
   const bool aug = aug_env && Rt == A + (long)n * n && (batch == 1 || (sA == sR && sA >= (long)(n + d) * n));
   const int extra = aug ? d : 0;
-  for (int k = 0; k < nblk; ++k) {
+  // Round 6: the augmented system left-looking, ONE launch per block column (chol_col.hip) instead of chol_diag + panel +
+  // trailing update; L^T is written by the same launches.  roma_tuning("gp_col", 0) / ROMA_GP_COL=0: the right-looking chain.
+  static const bool col_env = !(getenv("ROMA_GP_COL") && atoi(getenv("ROMA_GP_COL")) == 0);
+  const bool col = aug && (g_gp_col >= 0 ? g_gp_col != 0 : col_env) && d >= 64 && d % 64 == 0;
+  static std::atomic<unsigned> solve_epoch{0};  // tags the in-launch hand-off flags of this solve (chol_col.hip)
+  const unsigned epoch = col ? ++solve_epoch : 0u;
+  for (int k = 0; k < nblk && col; ++k)
+    if (int rc = chol_col_launch(A, n, sA, LT, sLT, n, d, Linv, LinvT, k, nblk, batch, epoch, st)) return rc;
+  if (col)
+    if (int rc = chol_col_restore_launch(A, n, sA, LT, sLT, n, batch, st)) return rc;
+  for (int k = 0; k < nblk && !col; ++k) {
     if (int rc = chol_diag_launch(A, n, sA, Linv, LinvT, k, nblk, batch, st)) return rc;
     const int mrem = n - (k + 1) * 64;
     if (mrem + extra <= 0) break;
@@ -711,7 +723,8 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
     t.M = mrem + extra; t.N = mrem; t.K = 64; t.batch = batch;
     if (int rc = gemm_launch(t, st)) return rc;
   }
-  if (int rc = transpose_launch(A, LT, n, n, batch, st, sA, sLT)) return rc;
+  if (!col)
+    if (int rc = transpose_launch(A, LT, n, n, batch, st, sA, sLT)) return rc;
   for (int k = 0; k < nblk && !aug; ++k) {  // forward (separate right-hand sides only)
     GemmArgs g;
     g.A = Rt + k * 64; g.lda = n; g.sA = sR;
@@ -1153,8 +1166,8 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
           lc.f0 = pf; lc.f1 = pf; lc.warp = flow; lc.out = off(d0, 2 * r.Cf + r.E);
           lc.B = ndp; lc.H = hs; lc.W = ws; lc.C = r.Cf; lc.radius = r.radius; lc.ld0 = ldf; lc.ld1 = ldf; lc.ldo = r.Cp;
           lc.nimg = nimg; lc.f1_shift = shift; lc.scale = 1.0f / sqrtf((float)r.Cf); lc.in_dt = act_dt; lc.out_dt = act_dt;
-          const long lc_tiles = (long)ndp * ((hs + 7) / 8) * ((ws + 7) / 8);  // tile work list (local_corr.h)
-          lc.ws = (int*)AL((size_t)2 * lc_tiles + 4, 4); lc.ws_bytes = (2 * lc_tiles + 4) * 4;
+          const long lc_ints = local_corr_ws_ints(ndp, hs, ws, r.radius);  // tile work lists + bin tables + sorted query list (local_corr.h)
+          lc.ws = (int*)AL((size_t)lc_ints, 4); lc.ws_bytes = lc_ints * 4;
           RUN(local_corr_window_launch(lc, st));
         }
         if (debug && !dry) {

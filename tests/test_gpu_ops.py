@@ -446,31 +446,82 @@ def test_cholesky_solve(lib, n, d, batch):
 
 
 @pytest.mark.parametrize("n,d", [(64, 512), (320, 512), (1600, 512)])
-def test_cholesky_solve_augmented_storage_is_bit_identical(lib, n, d):
-    """Round 4: with F^T stored right behind A (one (n + d) x n matrix, what gp_posterior allocates) the forward substitution runs
-    inside the factorisation loop - the same operations on every element in the same order, so X, the factor and the block
-    inverses must equal the separate-buffer form bit for bit."""
+def test_cholesky_solve_augmented_storage_forms_agree(lib, n, d):
+    """F^T stored right behind A (one (n + d) x n matrix, what gp_posterior allocates): the forward substitution is part of the
+    factorisation.  Three forms of the same solve:
+      * separate buffers: right-looking chain, separate forward loop (rounds 1-3);
+      * augmented, roma_tuning("gp_col", 0): the same right-looking operations on every element in the same order (round 4) -
+        bit-identical to the separate form;
+      * augmented, default (round 6): the LEFT-looking block-column kernel (chol_col.hip), one launch per 64 columns - another
+        summation order (one fmaf chain over the earlier blocks instead of in-memory subtractions), so it agrees to f32
+        rounding and is held to the f64 solution like the others."""
     y = rnd(1, n, 48, seed=11)
     yn = y / y.norm(dim=-1, keepdim=True)
     A = (torch.exp((yn @ yn.transpose(1, 2) - 1.0) / 0.2) + 0.1 * torch.eye(n))[0]
     Ft = rnd(d, n, seed=12)
     outs = []
-    for aug in (False, True):
+    for aug, col, leader in ((False, 0, 1), (True, 0, 1), (True, 1, 1), (True, 1, 1), (True, 1, 0)):
+        ok(lib, lib.roma_tuning(b"gp_col", col))
+        ok(lib, lib.roma_tuning(b"gp_col_leader", leader))  # 0: every workgroup factorises its own copy of the block (fallback form)
         buf = torch.empty(((n + d) * n + 4096,), device="cuda")
         Ad = buf[:n * n].view(n, n)
         Ad.copy_(A)
         Fd = buf[n * n:(n + d) * n].view(d, n) if aug else torch.empty((d, n), device="cuda")
         Fd.copy_(Ft)
-        LT = torch.empty((n, n), device="cuda")
+        LT = torch.full((n, n), float("nan"), device="cuda")
         Linv = torch.empty((n // 64, 64, 64), device="cuda")
         LinvT = torch.empty_like(Linv)
         ok(lib, lib.roma_op_cholesky_solve_t(P(Ad), P(Fd), P(LT), P(Linv), P(LinvT), n, d, 1, None))
         torch.cuda.synchronize()
-        outs.append((Fd.clone(), torch.tril(Ad).clone(), Linv.clone(), LT.clone()))
-    for a, b in zip(*outs):
+        outs.append((Fd.clone(), torch.tril(Ad).clone(), Linv.clone(), LinvT.clone()))
+    ok(lib, lib.roma_tuning(b"gp_col", -1))
+    ok(lib, lib.roma_tuning(b"gp_col_leader", -1))
+    for a, b in zip(outs[0], outs[1]):   # right-looking: separate == augmented, bit for bit
+        assert torch.equal(a, b)
+    for a, b in zip(outs[2], outs[3]):   # the block-column kernel is deterministic
+        assert torch.equal(a, b)
+    for a, b in zip(outs[2], outs[4]):   # ... and the in-launch hand-off changes who computes, not what
         assert torch.equal(a, b)
     ref = torch.cholesky_solve(Ft.t().double(), torch.linalg.cholesky(A.double()))
-    assert torch.allclose(outs[1][0].cpu().t().double(), ref, atol=2e-4, rtol=1e-4)
+    Lref = torch.linalg.cholesky(A.double())
+    for o in (outs[1], outs[2]):
+        assert torch.allclose(o[0].cpu().t().double(), ref, atol=2e-4, rtol=1e-4), float((o[0].cpu().t().double() - ref).abs().max())
+        assert torch.allclose(o[1].cpu().double(), Lref, atol=1e-4), float((o[1].cpu().double() - Lref).abs().max())
+        assert torch.equal(o[2].transpose(1, 2), o[3])  # Linv^T table = transpose of the Linv table
+    # left- vs right-looking: the same numbers up to f32 rounding of a well-conditioned system (cond ~ 1e3)
+    for a, b, tol in zip(outs[1][:3], outs[2][:3], (5e-5, 2e-5, 2e-4)):
+        assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), float((a - b).abs().max())
+    # the block inverses really invert the factor's diagonal blocks
+    Lc = outs[2][1].cpu().double()
+    for k in range(n // 64):
+        blk = Lc[64 * k:64 * k + 64, 64 * k:64 * k + 64]
+        assert torch.allclose(outs[2][2][k].cpu().double() @ blk, torch.eye(64, dtype=torch.float64), atol=1e-4)
+
+
+@pytest.mark.parametrize("batch", [3])
+def test_cholesky_block_column_batched_matches_f64(lib, batch):
+    """chol_col.hip on a batch with the GP's strides (n = 320, d = 512): every image against the f64 solve; workgroup 0 of a
+    launch must not publish the factor block where its neighbours still read the original one (the diagonal blocks of A are
+    restored behind the last column)."""
+    n, d = 320, 512
+    y = rnd(batch, n, 40, seed=21)
+    yn = y / y.norm(dim=-1, keepdim=True)
+    A = torch.exp((yn @ yn.transpose(1, 2) - 1.0) / 0.2) + 0.1 * torch.eye(n)
+    Ft = rnd(batch, d, n, seed=22)
+    buf = torch.empty((batch, (n + d) * n), device="cuda")
+    LT = torch.empty((batch, n, n), device="cuda")
+    Linv = torch.empty((batch, n // 64, 64, 64), device="cuda")
+    LinvT = torch.empty_like(Linv)
+    for _ in range(2):  # twice from the same inputs: no state is carried between calls
+        buf[:, :n * n] = A.reshape(batch, -1).cuda()
+        buf[:, n * n:] = Ft.reshape(batch, -1).cuda()
+        ok(lib, lib.roma_op_cholesky_solve_t(P(buf), C.c_void_p(buf.data_ptr() + n * n * 4), P(LT), P(Linv), P(LinvT), n, d, batch, None))
+        torch.cuda.synchronize()
+        X = buf[:, n * n:].reshape(batch, d, n).cpu().transpose(1, 2).double()
+        ref = torch.cholesky_solve(Ft.transpose(1, 2).double(), torch.linalg.cholesky(A.double()))
+        assert torch.allclose(X, ref, atol=2e-4, rtol=1e-4), float((X - ref).abs().max())
+        Lgot = torch.tril(buf[:, :n * n].reshape(batch, n, n).cpu().double())
+        assert torch.allclose(Lgot, torch.linalg.cholesky(A.double()), atol=1e-4)
 
 
 def test_cls_to_flow_reference_golden(lib):
