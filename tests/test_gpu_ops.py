@@ -620,19 +620,34 @@ def test_local_corr_tiled_gather_and_legacy_paths_agree(lib, r, c, h, w):
     refb = roma_oracle.local_correlation(f0.bfloat16().float(), f1.bfloat16().float(), r, warp)
     outs = {}
     try:
-        for mode in (0, 1, 2):  # 0: tiles (16-bit: all-pairs on the matrix core; f32: VALU dots) + work list, 1: work list only, 2: per pixel
+        # lc_mode 0: tiles (16-bit: all-pairs on the matrix core; f32: VALU dots) + the incoherent tiles' queries, 1: every tile
+        # treated as incoherent, 2: per pixel;  lc_bin 1 (round 6): incoherent queries sorted by target bin and served by the
+        # LIST form of the tile kernel, 0: per-query gathers (rounds 2-5)
+        for mode, binned in ((0, 1), (1, 1), (0, 0), (1, 0), (2, 0)):
             lib.roma_tuning(b"lc_mode", mode)
+            lib.roma_tuning(b"lc_bin", binned)
             out = local_correlation(f0.cuda(), f1.cuda(), r, warp.cuda())
-            assert torch.allclose(out.cpu(), ref, atol=1e-4, rtol=1e-5), (mode, float((out.cpu() - ref).abs().max()))
+            assert torch.allclose(out.cpu(), ref, atol=1e-4, rtol=1e-5), (mode, binned, float((out.cpu() - ref).abs().max()))
             outb = local_correlation(f0.cuda().bfloat16(), f1.cuda().bfloat16(), r, warp.cuda())
-            assert torch.allclose(outb.cpu(), refb, atol=1e-3, rtol=1e-4), (mode, float((outb.cpu() - refb).abs().max()))
-            outs[mode] = (out.cpu(), outb.cpu())
+            assert torch.allclose(outb.cpu(), refb, atol=1e-3, rtol=1e-4), (mode, binned, float((outb.cpu() - refb).abs().max()))
+            outs[(mode, binned)] = (out.cpu(), outb.cpu())
+        # the binned form is deterministic although the order of the queries inside a bin is not (atomics): run it again
+        lib.roma_tuning(b"lc_mode", 1)
+        lib.roma_tuning(b"lc_bin", 1)
+        for _ in range(3):
+            assert torch.equal(local_correlation(f0.cuda().bfloat16(), f1.cuda().bfloat16(), r, warp.cuda()).cpu(), outs[(1, 1)][1])
+            assert torch.equal(local_correlation(f0.cuda(), f1.cuda(), r, warp.cuda()).cpu(), outs[(1, 1)][0])
     finally:
         lib.roma_tuning(b"lc_mode", -1)
-    # the work-list and legacy forms run the same per-pixel code: bit-identical; the tiled form sums in another order
-    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
-    assert torch.allclose(outs[0][0], outs[1][0], atol=2e-5, rtol=1e-5)
-    assert torch.allclose(outs[0][1], outs[1][1], atol=2e-5, rtol=1e-5)   # 16-bit: MFMA all-pairs tiles vs per-query dots (exact products, f32 sums)
+        lib.roma_tuning(b"lc_bin", -1)
+    # the gather-list and legacy forms run the same per-pixel code: bit-identical; the tiled forms sum in another order
+    assert torch.equal(outs[(1, 0)][0], outs[(2, 0)][0]) and torch.equal(outs[(1, 0)][1], outs[(2, 0)][1])
+    assert torch.allclose(outs[(0, 0)][0], outs[(1, 0)][0], atol=2e-5, rtol=1e-5)
+    # tile form and LIST form evaluate every (window pixel, query) dot product with the same instruction sequence: a query's
+    # result does not depend on which of the two served it
+    assert torch.equal(outs[(0, 1)][1], outs[(1, 1)][1])
+    assert torch.allclose(outs[(0, 1)][0], outs[(1, 1)][0], atol=2e-5, rtol=1e-5)
+    assert torch.allclose(outs[(0, 0)][1], outs[(1, 0)][1], atol=2e-5, rtol=1e-5)   # 16-bit: MFMA all-pairs tiles vs per-query dots (exact products, f32 sums)
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])

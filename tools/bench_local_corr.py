@@ -52,15 +52,22 @@ def run(r, c, h, w, B, regime, dt):
     es = 2.0 if dt == BF16 else 4.0
     alg_bytes = B * h * w * (2.0 * c * es + 8.0 + K * es)
     res = {}
-    names = {0: "tiled", 1: "all_to_gather_list", 2: "per_pixel"}
-    for mode in (0, 1, 2):
+    outs = {}
+    # (lc_mode, lc_bin): lc_bin = 1 sends the queries of incoherent tiles through the bin-sorted LIST form of the tile kernel
+    # (round 6), 0 through per-query gathers (rounds 2-5)
+    forms = {"tiled+binned (default)": (0, 1), "tiled+gather_list (r05 default)": (0, 0), "all_binned": (1, 1),
+             "all_to_gather_list": (1, 0), "per_pixel": (2, 0)}
+    for name, (mode, binned) in forms.items():
         lib.roma_tuning(b"lc_mode", mode)
+        lib.roma_tuning(b"lc_bin", binned)
 
         def call():
             rc = lib.roma_op_local_corr_window(P(f), P(f), P(warp), P(out), B, h, w, c, r, c ** -0.5, K, dt, dt, None)
             assert rc == 0, lib.roma_last_error()
+        out.fill_(float("nan"))
         call()
         torch.cuda.synchronize()
+        outs[name] = out.float().clone()
         ts = []
         for _ in range(7):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -71,14 +78,13 @@ def run(r, c, h, w, B, regime, dt):
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / 3)
         ms = statistics.median(ts)
-        res[names[mode]] = {"ms": round(ms, 4), "algorithmic_GBs": round(alg_bytes / (ms * 1e-3) / 1e9)}
-        res["out_" + str(mode)] = out.float().clone()
-    res.pop("out_1")
-    res.pop("out_3")
-    d = float((res.pop("out_0") - res.pop("out_2")).abs().max())
+        res[name] = {"ms": round(ms, 4), "algorithmic_GBs": round(alg_bytes / (ms * 1e-3) / 1e9)}
+    ref = outs["per_pixel"]
+    d = {k: float((v - ref).abs().max()) for k, v in outs.items() if k != "per_pixel"}
     lib.roma_tuning(b"lc_mode", -1)
+    lib.roma_tuning(b"lc_bin", -1)
     print(json.dumps({"r": r, "C": c, "hw": [h, w], "B": B, "dtype": "bf16" if dt == BF16 else "f32", "warp": regime,
-                      "algorithmic_MB": alg_bytes / 1e6, **res, "max_abs_diff_between_forms": d}), flush=True)
+                      "algorithmic_MB": alg_bytes / 1e6, **res, "max_abs_diff_vs_per_pixel": d}), flush=True)
 
 
 if __name__ == "__main__":
