@@ -336,6 +336,12 @@ int roma_op_visualize_warp(const float* warp, const float* certainty, const floa
 int roma_op_fb_consistency(const float* flow_fwd, const float* flow_bwd, int B, int H, int W, float th_n, float* out,
                            void* stream);
 int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream);
+/* MaxPool2d(2) + the proj head of a VGG pyramid level in one pass over the un-pooled map (encoders.py:17-27,
+ * roma_models.py:156-160): in [B,H,W,C] 16-bit, C = 64 (N <= 32) or 128 (N <= 64) -> pooled [B,H/2,W/2,C] and
+ * pf [B,H*W,ldf] = in . pw^T + pb (pw [N][ldw] 16-bit, pb f32 [N], columns N .. ldf zero).  Bit-identical to
+ * roma_op_maxpool2x2 + roma_op_gemm; roma_tuning("pool_proj", 0) makes the model use those two instead. */
+int roma_op_pool_proj(const void* in, void* pooled, void* pf, const void* pw, long ldw, const float* pb, int N, int ldf, int B, int H,
+                      int W, int C, int dt, void* stream);
 /* ConvRefiner out_conv fused with the flow / certainty update (matcher.py:177-178, 496-506):
  *   o = d[m, 0:Cp] . w[0:3, 0:Cp]^T + b;  flow[m] += (sx * o0, sy * o1);  cert[m] += o2        (f32 accumulate)
  * d DEVICE [M, ldd] in dt (f32 / bf16; channels Cp..ldd ignored), w DEVICE f32 [3][Cp], b f32 [3], flow f32 [M,2], cert f32 [M]. */

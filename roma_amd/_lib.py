@@ -96,6 +96,7 @@ SIGNATURES = {
     "roma_op_tiny_update": (_i, [_vp, _i, _vp, _l, _f, _f, _vp, _l, _vp]),
     "roma_op_tiny_final": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "roma_op_maxpool2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "roma_op_pool_proj": (_i, [_vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "roma_op_conv3x3_c3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "roma_op_conv3x3_c3_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "roma_op_refiner_out": (_i, [_vp, _l, _i, _vp, _vp, _vp, _vp, _l, _i, _f, _f, _vp]),

@@ -12,6 +12,7 @@
 #include "elementwise.h"
 #include "gemm.h"
 #include "local_corr.h"
+#include "pool_proj.h"
 #include "model.h"
 #include "refiner_block.h"
 #include "kde.h"
@@ -249,6 +250,7 @@ int roma_tuning(const char* key, int value) {
   else if (k == "rb_wide") g_rb_wide = value;
   else if (k == "dw_ring") g_dw_ring = value;
   else if (k == "gp_col") g_gp_col = value;
+  else if (k == "pool_proj") g_pool_proj = value;
   else if (k == "gp_col_leader") g_gp_col_leader = value;
   else {
     set_error("roma_tuning: unknown key " + k);
@@ -551,6 +553,11 @@ int roma_op_fb_consistency(const float* flow_fwd, const float* flow_bwd, int B, 
 
 int roma_op_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int dt, void* stream) {
   return maxpool2x2_launch(in, out, B, H, W, C, DT(dt), S(stream));
+}
+
+int roma_op_pool_proj(const void* in, void* pooled, void* pf, const void* pw, long ldw, const float* pb, int N, int ldf, int B, int H,
+                      int W, int C, int dt, void* stream) {
+  return pool_proj_launch(in, pooled, pf, pw, ldw, pb, N, ldf, B, H, W, C, DT(dt), S(stream));
 }
 
 int roma_op_refiner_out(const void* d, long ldd, int dt, const float* w, const float* b, float* flow, float* cert, long M,

@@ -91,6 +91,7 @@ int dwconv5x5_launch(const void* in, void* out, const float* w, const float* bia
 int dwconv5x5_ring_try_launch(const void* in, void* out, const float* w, const float* bias, int B, int H, int W, int Cp, int dt,
                               hipStream_t s);
 extern int g_dw_ring;
+extern int g_pool_proj;  // model.hip: roma_tuning("pool_proj")
 extern int g_gp_col;  // model.hip: roma_tuning("gp_col") - left-looking block-column Cholesky (chol_col.hip) on / off
 
 // out_conv (C->3, f32) fused with the flow / certainty update (matcher.py:177-178, 496-506)

@@ -12,6 +12,7 @@
 
 #include "attention.h"
 #include "conv64.h"
+#include "pool_proj.h"
 #include "elementwise.h"
 #include "gemm.h"
 #include "local_corr.h"
@@ -682,6 +683,7 @@ int Model::match_streams(int B, const float* ima, const float* imb, const float*
 // GEMM of step k simply run over mrem + d rows and the 2 * nblk - 1 launches of the forward loop disappear from the GP's
 // launch-latency-bound chain (~0.75 ms of 10 .. 25 us launches at n = 1600); same operations on every element in the same
 // order, so the result is bit-identical to the separate loop.
+int g_pool_proj = -1;  // roma_tuning("pool_proj", v): 1 = max-pool + proj head of strides 1 / 2 in one pass (default), 0 = separate kernels, -1 = env ROMA_POOL_PROJ
 int g_gp_col = -1;  // roma_tuning("gp_col", v): 1 = left-looking block-column kernel (default), 0 = right-looking chain, -1 = env ROMA_GP_COL
 int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, int n, int d, int batch, hipStream_t st,
                      long strideA, long strideR) {
@@ -952,6 +954,20 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
     const int fh[4] = {H, H / 2, H / 4, H / 8}, fw_[4] = {W, W / 2, W / 4, W / 8};
     const int fc[4] = {64, 128, 256, 512};
     for (int l = 0; l < 4; ++l) feat[l] = AL((size_t)nimg * fh[l] * fw_[l] * fc[l], esz);
+    // Round 6 (pool_proj.hip): at strides 1 and 2 the max-pool and the proj head of the level read the un-pooled map in ONE
+    // pass (16-bit modes); the projected maps are then ready when the decoder reaches those scales.  pf_pre[l]: stride 2^l.
+    static const bool pp_env = !(getenv("ROMA_POOL_PROJ") && atoi(getenv("ROMA_POOL_PROJ")) == 0);
+    void* pf_pre[2] = {nullptr, nullptr};
+    const int pp_si[2] = {4, 3};  // index of stride 1 / 2 in SCALES
+    bool pp_on[2];
+    for (int l = 0; l < 2; ++l) {
+      const RefinerW& rr = ref[pp_si[l]];
+      const int ldf_l = (int)round_up(rr.Cf, 8);
+      pp_on[l] = (g_pool_proj >= 0 ? g_pool_proj != 0 : pp_env) && fh[l] >= 2 && fw_[l] >= 2 &&
+                 pool_proj_supported(fc[l], rr.Cf, ldf_l, act_dt) && proj[pp_si[l]].b != nullptr;
+      if (pp_on[l] || dry) pf_pre[l] = AL((size_t)nimg * fh[l] * fw_[l] * ldf_l, esz);  // (planned whatever the switch says now)
+      if (!pp_on[l] && !dry) pf_pre[l] = nullptr;
+    }
     {
       const size_t enc_mark = arena.mark();
       void* t0 = AL((size_t)nimg * H * W * 64, esz);
@@ -979,11 +995,21 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         RUN(gemm_launch(g, st));
         return 0;
       };
+      auto pool = [&](int l, const void* in, void* out) -> int {
+        if (pp_on[l]) {
+          const int si_ = pp_si[l];
+          RUN(pool_proj_launch(in, out, pf_pre[l], proj[si_].w, proj[si_].ldw, proj[si_].b, ref[si_].Cf, (int)round_up(ref[si_].Cf, 8),
+                               nimg, fh[l], fw_[l], fc[l], act_dt, st));
+        } else {
+          RUN(maxpool2x2_launch(in, out, nimg, fh[l], fw_[l], fc[l], act_dt, st));
+        }
+        return 0;
+      };
       if (int rc = conv(1, t0, feat[0], H, W)) return rc;
-      RUN(maxpool2x2_launch(feat[0], t1, nimg, H, W, 64, act_dt, st));
+      if (int rc = pool(0, feat[0], t1)) return rc;
       if (int rc = conv(2, t1, t0, H / 2, W / 2)) return rc;
       if (int rc = conv(3, t0, feat[1], H / 2, W / 2)) return rc;
-      RUN(maxpool2x2_launch(feat[1], t1, nimg, H / 2, W / 2, 128, act_dt, st));
+      if (int rc = pool(1, feat[1], t1)) return rc;
       if (int rc = conv(4, t1, t0, H / 4, W / 4)) return rc;
       if (int rc = conv(5, t0, t1, H / 4, W / 4)) return rc;
       if (int rc = conv(6, t1, t0, H / 4, W / 4)) return rc;
@@ -1085,9 +1111,10 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
       const size_t smark = arena.mark();
       // ---- proj head, once per image (proj(f_s) == swap(proj(f_q)) since it is per-image)
       const int ldf = (int)round_up(r.Cf, 8);
-      void* pf = AL((size_t)nimg * hw * ldf, esz);
-      {
-        const int lvl = ins == 16 ? 4 : (ins == 8 ? 3 : (ins == 4 ? 2 : (ins == 2 ? 1 : 0)));
+      const int lvl = ins == 16 ? 4 : (ins == 8 ? 3 : (ins == 4 ? 2 : (ins == 2 ? 1 : 0)));
+      const bool pf_ready = lvl < 2 && pp_on[lvl];  // projected with the max-pool of the level (pool_proj.hip)
+      void* pf = pf_ready ? pf_pre[lvl] : AL((size_t)nimg * hw * ldf, esz);
+      if (!pf_ready) {
         GemmArgs g;
         g.A = feat[lvl]; g.lda = PROJ_CIN[si]; g.W = proj[si].w; g.ldw = proj[si].ldw; g.C = pf; g.ldc = ldf;
         g.M = (int)(nimg * hw); g.N = r.Cf; g.K = PROJ_CIN[si]; g.in_dt = act_dt; g.out_dt = act_dt; g.bias = proj[si].b;
@@ -1271,8 +1298,16 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         if (fw->flow[si]) ROMA_CHECK_HIP(hipMemcpyAsync(fw->flow[si], flow, (size_t)ndp * hw * 2 * 4, hipMemcpyDeviceToDevice, st));
         if (fw->cert[si]) ROMA_CHECK_HIP(hipMemcpyAsync(fw->cert[si], cert, (size_t)ndp * hw * 4, hipMemcpyDeviceToDevice, st));
       }
-      if (ins == 16 && !dry)
-        ROMA_CHECK_HIP(hipMemcpyAsync(cert16_keep, cert, (size_t)ndp * hw * 4, hipMemcpyDeviceToDevice, st));
+      // (a kernel, not hipMemcpyAsync: the runtime served this 50-100 KB device-to-device copy as ~100 consecutive
+      //  __amd_rocclr_copyBuffer launches of 3.7 us each - 0.38 ms of the stream, profiles/r05_final_bench_bf16_kernel_stats.csv)
+      if (ins == 16) {
+        const long nkeep = (long)ndp * hw;
+        if (nkeep % 4 == 0) {
+          RUN(copy2d_launch(cert, nkeep, DT_F32, cert16_keep, nkeep, DT_F32, 1, (int)nkeep, st));
+        } else if (!dry) {
+          ROMA_CHECK_HIP(hipMemcpyAsync(cert16_keep, cert, (size_t)nkeep * 4, hipMemcpyDeviceToDevice, st));
+        }
+      }
       arena.release(smark);
       if (ins != 1) {
         const int nh = H / (ins / 2), nw = W / (ins / 2);

@@ -906,6 +906,33 @@ def test_maxpool_and_first_conv(lib):
 
 
 
+@pytest.mark.parametrize("C,N,ldf", [(64, 9, 16), (128, 64, 64)])
+@pytest.mark.parametrize("B,H,W", [(2, 16, 24), (1, 9, 33), (3, 37, 70), (2, 140, 216)])
+def test_pool_proj_fused_is_maxpool_plus_proj_gemm(lib, C, N, ldf, B, H, W):
+    """pool_proj.hip (round 6): MaxPool2d(2) and the proj head of a VGG level (Conv2d 1x1 + folded BN, roma_models.py:156-160) in
+    one pass over the un-pooled map - bit-identical to the two kernels it replaces (roma_op_maxpool2x2, roma_op_gemm) and equal
+    to torch on the same bf16 operands; odd H / W (floor pooling, ragged 32-pixel column tiles, a last row without a partner)."""
+    x = F.relu(rnd(B, H, W, C, seed=1)).to(torch.bfloat16)                     # a post-ReLU map: never negative
+    pw = rnd(N, C, seed=2, std=C ** -0.5).to(torch.bfloat16)
+    pb = rnd(N, seed=3)
+    xd, pwd, pbd = x.cuda(), pw.cuda(), pb.cuda()
+    pooled = torch.full((B, H // 2, W // 2, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    pf = torch.full((B, H * W, ldf), float("nan"), device="cuda", dtype=torch.bfloat16)
+    ok(lib, lib.roma_op_pool_proj(P(xd), P(pooled), P(pf), P(pwd), C, P(pbd), N, ldf, B, H, W, C, BF16, None))
+    pooled2 = torch.empty_like(pooled)
+    pf2 = torch.zeros_like(pf)
+    ok(lib, lib.roma_op_maxpool2x2(P(xd), P(pooled2), B, H, W, C, BF16, None))
+    ok(lib, lib.roma_op_gemm(P(xd), C, P(pwd), C, P(pf2), ldf, B * H * W, N, C, 1, 0, 0, 0, P(pbd), None, None, 0, 0, 1.0, BF16, BF16, None))
+    torch.cuda.synchronize()
+    assert torch.equal(pooled.view(torch.int16), pooled2.view(torch.int16))
+    assert torch.equal(pf[:, :, :N].contiguous().view(torch.int16), pf2[:, :, :N].contiguous().view(torch.int16))
+    assert float(pf[:, :, N:].float().abs().max()) == 0.0 if ldf > N else True   # the pad columns are written as zeros
+    refp = F.max_pool2d(x.float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+    assert torch.equal(pooled.cpu().float(), refp)
+    ref = x.double().reshape(B, H * W, C) @ pw.double().T + pb.double()
+    assert torch.allclose(pf[:, :, :N].cpu().double(), ref, atol=2e-2, rtol=1e-2)
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 16, 24), (1, 9, 33), (3, 37, 70), (1, 560, 560), (2, 100, 864)])
 def test_first_conv_bf16_fused(lib, B, H, W):
     """conv64.hip conv3x3_c3_bf16: the first VGG layer of the bf16 path straight from the f32 image (27 taps split over the two
