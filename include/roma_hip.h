@@ -208,6 +208,12 @@ int roma_op_gemm(const void* A, long lda, const void* W, long ldw, void* C, long
 /* 3x3 conv (pad 1) as implicit GEMM on NHWC input: out[B,H,W,Cout] = relu?(conv(in[B,H,W,Cin], w[Cout][9*Cin]) + bias) */
 int roma_op_conv3x3(const void* in, const void* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
                     int relu, int dt, void* stream);
+/* The same convolution with the weight rows in SLAB-MAJOR K order, w[Cout][k], k = ((ci / 64) * 9 + ky * 3 + kx) * 64 + ci % 64
+ * (Cin % 64 == 0) - how the model packs the VGG layers with Cout >= 256 in the 16-bit modes.  Those run on the patch-resident
+ * kernel (conv_patch.hip: the activation patch + halo of a 64-channel slab stays in LDS for all nine taps, only the weights
+ * stream; roma_tuning("conv_patch", 0) selects the plain implicit GEMM instead - bit-identical results). */
+int roma_op_conv3x3_slab(const void* in, const void* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                         int relu, int dt, void* stream);
 /* Multi-head attention from a packed qkv activation [B*N, 3*heads*hd] (f32): out[B*N, heads*hd].
  * Workspace q,k,vt must hold B*heads*Npad*hd elements each, Npad = roundup(N,128), zero-initialised. */
 int roma_op_attention(const void* q, const void* k, const void* vt, void* out, int B, int heads, int N, int npad, int hd,

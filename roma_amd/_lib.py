@@ -63,6 +63,7 @@ SIGNATURES = {
     "roma_op_local_corr_window": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _l, _i, _i, _vp]),
     "roma_op_gemm": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _i, _l, _l, _l, _vp, _vp, _vp, _l, _i, _f, _i, _i, _vp]),
     "roma_op_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "roma_op_conv3x3_slab": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "roma_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "roma_op_qkv_scatter_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "roma_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),

@@ -9,6 +9,7 @@
 #include "../../include/roma_hip.h"
 #include "attention.h"
 #include "conv64.h"
+#include "conv_patch.h"
 #include "elementwise.h"
 #include "gemm.h"
 #include "local_corr.h"
@@ -243,6 +244,7 @@ int roma_tuning(const char* key, int value) {
   else if (k == "lc_mode") g_lc_mode = value;
   else if (k == "lc_bin") g_lc_bin = value;
   else if (k == "conv64") g_conv64_mode = value;
+  else if (k == "conv_patch") g_conv_patch = value;
   else if (k == "attn_xcd") g_attn_xcd_map = value;
   else if (k == "attn_exp2") g_attn_exp2 = value;
   else if (k == "rb24w") g_rb24_wave = value;
@@ -358,6 +360,15 @@ int roma_op_conv3x3(const void* in, const void* w, const float* bias, void* out,
   g.A = in; g.W = w; g.ldw = 9 * Cin; g.C = out; g.ldc = Cout; g.M = B * H * W; g.N = Cout; g.K = 9 * Cin;
   g.in_dt = DT(dt); g.out_dt = DT(dt); g.bias = bias; g.act = relu ? ACT_RELU : ACT_NONE;
   g.conv_h = H; g.conv_w = W; g.conv_c = Cin;
+  return gemm_launch(g, S(stream));
+}
+
+int roma_op_conv3x3_slab(const void* in, const void* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                         int relu, int dt, void* stream) {
+  GemmArgs g;
+  g.A = in; g.W = w; g.ldw = 9 * Cin; g.C = out; g.ldc = Cout; g.M = B * H * W; g.N = Cout; g.K = 9 * Cin;
+  g.in_dt = DT(dt); g.out_dt = DT(dt); g.bias = bias; g.act = relu ? ACT_RELU : ACT_NONE;
+  g.conv_h = H; g.conv_w = W; g.conv_c = Cin; g.conv_korder = 1;
   return gemm_launch(g, S(stream));
 }
 

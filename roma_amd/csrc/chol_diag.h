@@ -18,30 +18,53 @@ namespace roma {
 
 constexpr int CHOL_S = 68;
 
-// wave A (lane i owns row i): the factorisation, publishing every finished column in `progress`
+// wave A (lane i owns row i): the factorisation, publishing every finished column in `progress`.
+// Round 6: blocked by bands of 16 columns.  Inside a band the lane's 16 entries of its row live in REGISTERS and the column
+// being eliminated is broadcast with v_readlane (the pivot and the 15 - jj entries l_cj of the band's later rows are lane
+// constants: the 64 steps are fully unrolled), so a column step is ~sqrt + divide + (15 - jj) readlane / fma pairs with no LDS
+// round trip on its dependency chain; the columns right of the band receive the band's 16 rank-1 updates at once, from
+// LDS broadcasts, when the band is done.  Until round 5 every step updated ALL later columns through LDS (2 reads + 1 write
+// of 16 bytes per 4 columns, and the next pivot waited for them): 36 us per block, 0.9 ms of the GP chain.  Same operations
+// on every element; the updates of one element are applied in the same order j = 0, 1, 2 ... (bit-identical factor).
 __device__ __forceinline__ void chol_diag_factor_wave(float* L, float* LT, int* progress, int i) {
   constexpr int S = CHOL_S;
 #pragma unroll
-  for (int jb = 0; jb < 4; ++jb) {  // columns in four bands: a band's steps touch column groups >= 16 jb only
-    for (int j = 16 * jb; j < 16 * jb + 16; ++j) {
-      const float d = sqrtf(L[j * S + j]);
-      const float lij = (i == j) ? d : L[i * S + j] / d;
-      L[i * S + j] = lij;   // rows < j: harmless garbage in the strictly upper part
-      LT[j * S + i] = lij;  // column j of the factor, contiguous
-      // column j is final: let the inverse take row j.  Release / acquire at workgroup scope (round 5): one
-      // s_waitcnt lgkmcnt(0) in front of the flag store instead of relying on the LDS executing different waves' DS
-      // operations in one FIFO, which the memory model does not promise.
+  for (int jb = 0; jb < 4; ++jb) {
+    float a[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&L[i * S + 16 * jb + 4 * q]);
+      a[4 * q] = v[0]; a[4 * q + 1] = v[1]; a[4 * q + 2] = v[2]; a[4 * q + 3] = v[3];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = 16 * jb + jj;
+      const float ajj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[jj]), j));
+      const float d = sqrtf(ajj);
+      const float lij = (i == j) ? d : a[jj] / d;
+      a[jj] = lij;
+      L[i * S + j] = lij;   // rows < j: harmless values in the strictly upper part (every consumer masks it)
+      LT[j * S + i] = lij;  // column j of the factor, contiguous: the broadcast source of the band update below
+      // column j is final: let the inverse take row j.  Release / acquire at workgroup scope (round 5).
       __hip_atomic_store(progress, j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      // a_ic -= l_ij * l_cj for c > j.  Every column group of the band's range every time (selects, no trip count that
-      // depends on j): the LDS operations of a step are independent and pipeline, instead of ~150 cycles of latency per
-      // group; the compile-time band start drops the 37 % of the groups that lie wholly left of column j.
 #pragma unroll
-      for (int c = 16 * jb; c < 64; c += 4) {
-        f32x4 a = *reinterpret_cast<const f32x4*>(&L[i * S + c]);
-        const f32x4 lc = *reinterpret_cast<const f32x4*>(&LT[j * S + c]);  // same address in every lane: broadcast
+      for (int cc = jj + 1; cc < 16; ++cc) {
+        const float lcj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lij), 16 * jb + cc));
+        a[cc] = a[cc] - lij * lcj;
+      }
+    }
+    // the columns right of the band: a_ic -= l_ij l_cj for the band's 16 columns j, in the order of j
+    if (jb < 3) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = (c + u > j) ? a[u] - lij * lc[u] : a[u];
-        *reinterpret_cast<f32x4*>(&L[i * S + c]) = a;
+      for (int c = 16 * (jb + 1); c < 64; c += 4) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(&L[i * S + c]);
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          const f32x4 lc = *reinterpret_cast<const f32x4*>(&LT[(16 * jb + jj) * S + c]);  // same address in every lane: broadcast
+#pragma unroll
+          for (int u = 0; u < 4; ++u) t[u] = t[u] - a[jj] * lc[u];
+        }
+        *reinterpret_cast<f32x4*>(&L[i * S + c]) = t;
       }
     }
   }

@@ -40,6 +40,7 @@
 
 #include <algorithm>
 
+#include "conv_patch.h"
 #include "gemm_device.h"
 
 namespace roma {
@@ -595,6 +596,10 @@ int gemm8p_trace_read(unsigned* host, long n) {
 int conv64_try_launch(const GemmArgs& a, hipStream_t stream);  // conv64.hip (weight-stationary 3x3, Cin = 64)
 
 int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
+  if (a.conv_c > 0 && a.conv_korder == 1) {  // slab-major VGG layers: the patch-resident kernel (conv_patch.hip, round 6)
+    const int rc = conv_patch_try_launch(a, stream);
+    if (rc <= 0) return rc;
+  }
   if (a.conv_c == 64 || a.conv_c == 128) {  // the three widest VGG layers have their own kernels (conv64.hip)
     const int rc = conv64_try_launch(a, stream);
     if (rc <= 0) return rc;

@@ -110,7 +110,10 @@ class Model {
   // alternations on one box: profiles/r05_v15_conv_k_order_ab.log) - the misses were Infinity-Cache hits and the tap-major walk
   // reads each pixel's channels as one contiguous run.  OFF by default; ROMA_CONV_KORDER=1 selects it (read before the weights
   // are packed; it changes only the summation order of the K loop).
-  bool vgg_slab_major = getenv("ROMA_CONV_KORDER") && atoi(getenv("ROMA_CONV_KORDER")) == 1;
+  // Round 6: ON by default - it is the K order of the patch-resident kernel (conv_patch.hip), which keeps the activation patch of a
+  // slab in LDS across the nine taps.  ROMA_CONV_KORDER=0 (or ROMA_CONV_PATCH=0) restores tap-major rows on the implicit GEMM.
+  bool vgg_slab_major = !(getenv("ROMA_CONV_KORDER") && atoi(getenv("ROMA_CONV_KORDER")) == 0) &&
+                        !(getenv("ROMA_CONV_PATCH") && atoi(getenv("ROMA_CONV_PATCH")) == 0);
   int vgg_korder[12] = {0};
   bool fuse_refiner_blocks = true;  // bf16 mode: fused dw5x5+1x1 kernel at the narrow scales (option "fuse_refiner_blocks")
   // bf16 mode: DINOv2's residual stream in bf16, like the reference's bf16 backbone (encoders.py: dinov2 weights and

@@ -278,6 +278,44 @@ def test_conv3x3_gemm8p_matches_classic_and_reference(lib, B, H, W, Cin, Cout, s
     assert torch.allclose(outs[1].cpu().double(), ref, atol=3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 37, 45, 128, 256), (3, 70, 70, 256, 512), (1, 108, 108, 512, 512), (2, 9, 11, 256, 256),
+                                            (16, 70, 70, 256, 256), (1, 216, 216, 256, 256), (2, 17, 300, 128, 512)])
+def test_conv3x3_patch_resident_matches_implicit_gemm_and_reference(lib, B, H, W, Cin, Cout):
+    """conv_patch.hip (round 6): the VGG layers with Cout >= 256 with the activation patch + halo of a 64-channel slab resident
+    in LDS across the nine taps.  Slab-major weight rows (roma_op_conv3x3_slab).  Bit-identical to the implicit GEMM on the same
+    packing (gemm8p's conv form / the classic kernel: same products, same k order per accumulator), equal to the tap-major
+    operator up to the summation order, and to torch conv2d on the same bf16 operands.  Image borders on all four sides,
+    patches hanging over the right / bottom edge, images smaller than one patch, several tiles per persistent workgroup
+    (16 x 70 x 70), both cout tiles (Cout = 512); every launch twice (timing-dependent hazards of the LDS-DMA pipeline)."""
+    x, w, b = rnd(B, Cin, H, W, seed=1).bfloat16(), rnd(Cout, Cin, 3, 3, seed=2, std=(9 * Cin) ** -0.5).bfloat16(), rnd(Cout, seed=3)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).permute(0, 2, 3, 1)
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)                                  # [cout][tap][ci]
+    wslab = wt.reshape(Cout, 9, Cin // 64, 64).permute(0, 2, 1, 3).reshape(Cout, 9 * Cin).contiguous().cuda()  # [cout][slab][tap][64]
+    wtap = wt.reshape(Cout, 9 * Cin).contiguous().cuda()
+    bd = b.cuda()
+    outs = {}
+    try:
+        for patch in (1, 0, 1):
+            lib.roma_tuning(b"conv_patch", patch)
+            out = torch.full((B, H, W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+            ok(lib, lib.roma_op_conv3x3_slab(P(xin), P(wslab), P(bd), P(out), B, H, W, Cin, Cout, 1, BF16, None))
+            torch.cuda.synchronize()
+            if patch in outs:
+                assert torch.equal(out.view(torch.int16), outs[patch].view(torch.int16))
+            outs[patch] = out
+    finally:
+        lib.roma_tuning(b"conv_patch", -1)
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[1].view(torch.int16), outs[0].view(torch.int16)), float((outs[1].float() - outs[0].float()).abs().max())
+    assert torch.allclose(outs[1].cpu().double(), ref, atol=3e-2, rtol=3e-2)
+    out_t = torch.empty_like(outs[1])
+    ok(lib, lib.roma_op_conv3x3(P(xin), P(wtap), P(bd), P(out_t), B, H, W, Cin, Cout, 1, BF16, None))
+    torch.cuda.synchronize()
+    d = (out_t.float() - outs[1].float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(out_t.float().abs().max()) + 1e-6  # tap-major vs slab-major order: one bf16 ulp
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 11, 64, 64), (1, 16, 16, 64, 128), (3, 56, 60, 64, 64), (3, 56, 60, 64, 128),
                                             (2, 131, 200, 64, 64), (2, 70, 129, 64, 128), (1, 280, 280, 64, 128), (1, 560, 560, 64, 64),
                                             (2, 9, 11, 128, 128), (3, 56, 60, 128, 128), (2, 70, 129, 128, 128), (9, 140, 131, 128, 128),
