@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARIES = ("profiles/r05_pmc_summary.json", "profiles/r04_pmc_summary.json", "profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json")
+PMC_SUMMARIES = ("profiles/r06_pmc_summary.json", "profiles/r05_pmc_summary.json", "profiles/r04_pmc_summary.json", "profiles/r03_pmc_summary.json", "profiles/r02_pmc_summary.json", "profiles/r01_pmc_summary.json")
 
 
 def pmc_traffic(kernel):
@@ -60,6 +60,8 @@ def pmc_traffic(kernel):
         want = f"void roma::gemm6p_kernel<{conv[targs[1]]}, {act}>"
     elif base == "ws1x1_kernel" and len(targs) == 2:   # -> <ACT>
         want = "void roma::ws1x1_kernel<%d>" % {"none": 0, "relu": 1}[targs[1]]
+    elif base == "conv3x3_patch_kernel":               # not a template: the profile scope only names the storage format
+        want = "roma::conv3x3_patch_kernel"
     for rel in PMC_SUMMARIES:
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):

@@ -45,8 +45,10 @@ __device__ __forceinline__ void chol_diag_factor_wave(float* L, float* LT, int* 
       a[jj] = lij;
       L[i * S + j] = lij;   // rows < j: harmless values in the strictly upper part (every consumer masks it)
       LT[j * S + i] = lij;  // column j of the factor, contiguous: the broadcast source of the band update below
-      // column j is final: let the inverse take row j.  Release / acquire at workgroup scope (round 5).
-      __hip_atomic_store(progress, j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // columns up to j are final: let the inverse take the rows up to j.  Release / acquire at workgroup scope (round 5,
+      // ADVICE r04).  Published every fourth column: the release waits for this wave's LDS writes to land (~100 cycles on the
+      // factorisation's critical path), and the inverse consumes rows four at a time anyway.
+      if ((jj & 3) == 3) __hip_atomic_store(progress, j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
       for (int cc = jj + 1; cc < 16; ++cc) {
         const float lcj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lij), 16 * jb + cc));
@@ -70,25 +72,30 @@ __device__ __forceinline__ void chol_diag_factor_wave(float* L, float* LT, int* 
   }
 }
 
-// wave B (lane c owns unknown vector c): L x = e_c by forward substitution, one row behind the factorisation.  Four
+// wave B (lane c owns unknown vector c): L x = e_c by forward substitution, a few rows behind the factorisation.  Four
 // interleaved partial sums (t mod 4) keep the dependent-FMA chain at 16 instead of 64 per row.  Row r reads L[r][t <= r] only:
-// final once the factorisation has published step r (the entries right of the diagonal it may see half-updated are masked).
+// final once the factorisation has published column r.
+// Round 6: the unknowns live in REGISTERS (64 per lane, rows fully unrolled) - until round 5 every x_r went to LDS and came
+// back for the next row (a write -> read round trip of ~200 cycles on the chain of all 64 rows), which made this wave, not the
+// factorisation, the long pole of the block (31 of 36 us).  The L rows are broadcast reads that depend on nothing but the
+// progress flag, so they are in flight rows ahead.  Same terms, same four partial sums, same order: bit-identical inverse.
 __device__ __forceinline__ void chol_diag_inverse_wave(const float* L, float* XT, int* progress, int c) {
   constexpr int S = CHOL_S;
+  float x[64];
 #pragma unroll
-  for (int rb = 0; rb < 4; ++rb) {  // rows in four bands: row r only needs the unknowns t < r, i.e. groups < 16 (rb + 1)
-    for (int r = 16 * rb; r < 16 * rb + 16; ++r) {
-      while (__hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < r) __builtin_amdgcn_s_sleep(1);
-      f32x4 part = {(r == c) ? 1.f : 0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < 64; ++r) {
+    if ((r & 3) == 0)  // rows r .. r + 3 are published together (chol_diag_factor_wave)
+      while (__hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < r + 3) __builtin_amdgcn_s_sleep(1);
+    float part[4] = {(r == c) ? 1.f : 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 16 * (rb + 1); t += 4) {
-        const f32x4 lr = *reinterpret_cast<const f32x4*>(&L[r * S + t]);   // broadcast
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(&XT[c * S + t]);
+    for (int t = 0; t < r; t += 4) {
+      const f32x4 lr = *reinterpret_cast<const f32x4*>(&L[r * S + t]);  // broadcast
 #pragma unroll
-        for (int u = 0; u < 4; ++u) part[u] = (t + u < r) ? part[u] - lr[u] * xv[u] : part[u];
-      }
-      XT[c * S + r] = ((part[0] + part[1]) + (part[2] + part[3])) / L[r * S + r];
+      for (int u = 0; u < 4; ++u)
+        if (t + u < r) part[u] = part[u] - lr[u] * x[t + u];
     }
+    x[r] = ((part[0] + part[1]) + (part[2] + part[3])) / L[r * S + r];
+    if ((r & 3) == 3) *reinterpret_cast<f32x4*>(&XT[c * S + r - 3]) = f32x4{x[r - 3], x[r - 2], x[r - 1], x[r]};
   }
 }
 

@@ -22,7 +22,7 @@ import sys
 
 def klass(name):
     n = name
-    if re.search(r"gemm8p|gemm6p|ws1x1|conv3x3_c64|conv3x3_c128", n) or re.search(r"gemm_kernel<unsigned short", n):
+    if re.search(r"gemm8p|gemm6p|ws1x1|conv3x3_c64|conv3x3_c128|conv3x3_patch", n) or re.search(r"gemm_kernel<unsigned short", n):
         return "mfma_gemm"
     if "attn" in n:
         return "attention"
@@ -30,7 +30,7 @@ def klass(name):
         return "stencil"
     if re.search(r"local_corr|refiner_input|refiner_out", n):
         return "gather"
-    if re.search(r"gemm_kernel<float|chol_diag|transpose_kernel|pad_identity|gp_basis|rownorm|copyBuffer|fillBuffer", n):
+    if re.search(r"gemm_kernel<float|chol_diag|chol_col|transpose_kernel|pad_identity|gp_basis|rownorm|copyBuffer|fillBuffer", n):
         return "gp_chain"
     return "rest"
 
