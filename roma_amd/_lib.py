@@ -13,6 +13,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# ROMA_LIB_DIR: A/B runs of tools/ against another BUILD of the same two libraries (e.g. the previous commit's); the product
+# default is the in-tree build next to this file.  There is still no fallback: a missing library raises.
+_HERE = os.environ.get("ROMA_LIB_DIR", _HERE)
 LIB_PATH = os.path.join(_HERE, "libroma_hip.so")
 LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(_HERE, "libroma_hip_f16.so")}
 
