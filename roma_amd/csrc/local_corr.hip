@@ -185,12 +185,16 @@ constexpr int LC_PITCH = 144;            // bytes per staged pixel: 128 B of cha
 // workgroups per CU (r <= 3) the stage is capped at 320 slots = 10 blocks of 32 (80 accumulator registers next to the 60
 // staging-prefetch registers); its rectangle rows keep their natural pitch (the matrix-core reads go down the slots, the
 // 144-byte slot pitch alone makes them conflict free), so 320 slots hold zooms up to ~1.35 (r = 2) / ~1.2 (r = 3).
+// Round 6: the large windows (r = 7: one 110 KB workgroup per CU) run with 512 threads - twice the waves to hide the stage /
+// barrier / matrix-core chain of a chunk (two per SIMD instead of one), the all-pairs accumulators split 11 -> 6 blocks per
+// wave.  (Until round 5: 256 threads - 283 GB/s on coherent warps.)
 template <int R, bool MFMA = false> struct LcGeom {
+  static constexpr int NTHR = R <= 3 ? 256 : 512;
   static constexpr int PXMAX = R <= 3 ? (MFMA ? 320 : 448) : 704;
   static constexpr int NSLOT = PXMAX + LC_TQ * LC_TQ;
   static constexpr int STAGE = NSLOT * LC_PITCH;
-  static constexpr int NPRE = (NSLOT * 8 + 255) / 256;  // 16-byte pieces per thread per chunk
-  static constexpr bool PREFETCH = R <= 3;              // larger windows: the accumulators need the registers
+  static constexpr int NPRE = (NSLOT * 8 + NTHR - 1) / NTHR;  // 16-byte pieces per thread per chunk
+  static constexpr bool PREFETCH = R <= 3;  // r = 7: with the 48 prefetch registers next to 96 accumulators hipcc spills 10-18 (measured: ISA)
 };
 
 // Row pitch (in staged pixel slots) of the f1 rectangle.  Lanes are queries: a 16-lane LDS group covers 4 runs of 4
@@ -246,10 +250,11 @@ template <> struct LcDot<bf16_t> {  // 64 channels per 128-byte chunk, packed pa
 // one staged copy of it, all-pairs on the matrix core - so an incoherent warp costs ~ (rectangle + 64 f0 rows) per 64 queries
 // instead of 64 x (2r+2)^2 gathered f1 pixels.  The bin edge is chosen so that the rectangle always fits the stage.
 template <int R, typename T, typename TOUT, bool MFMA, bool LIST = false>
-__global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(const LocalCorrArgs a) {
+__global__ __launch_bounds__((LcGeom<R, MFMA>::NTHR), 2) void local_corr_tile_kernel(const LocalCorrArgs a) {
   constexpr int P = 2 * R + 2, KW = 2 * R + 1, K = KW * KW;
-  constexpr int NR = (P + 3) / 4;  // patch rows per wave
-  constexpr int NBW = MFMA ? ((LcGeom<R, MFMA>::PXMAX + 31) / 32 + 1) / 2 : 1;  // 32-slot blocks per wave (5 ; 11)
+  constexpr int NTHR = LcGeom<R, MFMA>::NTHR, NWV = NTHR / 64, NBG = NWV / 2;  // waves; block groups (wave >> 1) of the MFMA form
+  constexpr int NR = (P + NWV - 1) / NWV;  // patch rows per wave
+  constexpr int NBW = MFMA ? ((LcGeom<R, MFMA>::PXMAX + 31) / 32 + NBG - 1) / NBG : 1;  // 32-slot blocks per wave (5 ; 6)
   static_assert(!MFMA || sizeof(T) == 2, "the MFMA form takes 16-bit features");
   constexpr int CC = LcDot<T>::CC;
   constexpr int LC_STAGE = LcGeom<R, MFMA>::STAGE, LC_PXMAX = LcGeom<R, MFMA>::PXMAX, NPRE = LcGeom<R, MFMA>::NPRE;
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
   const char* f0b = reinterpret_cast<const char*>(f0p);
 #pragma unroll
   for (int k = 0; k < (PREFETCH ? NPRE : 0); ++k) {
-    const int i = tid + 256 * k;
+    const int i = tid + NTHR * k;
     const int slotp = i >> 3, piece = i & 7;
     unsigned off = 0xffffffffu;
     if (slotp < (int)npx) {
@@ -379,11 +384,11 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
     if constexpr (PREFETCH) {
 #pragma unroll
       for (int k = 0; k < NPRE; ++k) {
-        const int i = tid + 256 * k;
+        const int i = tid + NTHR * k;
         if (i < nslots * 8) *reinterpret_cast<uint4*>(lds + (i >> 3) * LC_PITCH + (i & 7) * 16) = pre[k];
       }
     } else {  // plain staging loop: load and store the pieces of this chunk
-      for (int i = tid; i < nslots * 8; i += 256) {
+      for (int i = tid; i < nslots * 8; i += NTHR) {
         const int slotp = i >> 3, piece = i & 7;
         const char* src = nullptr;
         if (slotp < (int)npx) {
@@ -419,8 +424,8 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
         const uint4 af = *reinterpret_cast<const uint4*>(arow + ks * 32);
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
-          if ((2 * i + (wave >> 1)) * 32 < (int)npx) {
-            const uint4 bf = *reinterpret_cast<const uint4*>(brow + i * (64 * LC_PITCH) + ks * 32);
+          if ((NBG * i + (wave >> 1)) * 32 < (int)npx) {
+            const uint4 bf = *reinterpret_cast<const uint4*>(brow + i * (NBG * 32 * LC_PITCH) + ks * 32);
             macc[i] = mfma_h16_32x32x16(bf, af, macc[i]);
           }
         }
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
       for (int i = 0; i < 8; ++i) q[i] = *reinterpret_cast<const uint4*>(f0slot + 16 * i);
 #pragma unroll
       for (int ri = 0; ri < NR; ++ri) {
-        const int r = wave + 4 * ri;  // wave-uniform
+        const int r = wave + NWV * ri;  // wave-uniform
         if (r < P) {
           const int yy = my_y + r;
           const bool rowok = yy >= 0 && yy < bh;
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
       for (int i = 0; i < 8; ++i) q[i] = *reinterpret_cast<const uint4*>(f0slot + 16 * i);
 #pragma unroll
       for (int ri = 0; ri < NR; ++ri) {
-        const int r = wave + 4 * ri;
+        const int r = wave + NWV * ri;
         const int yy = my_y + r;
         if (r < P && yy >= 0 && yy < bh) {
 #pragma unroll
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
     // window entries outside the (clipped) rectangle are zero: clear, then every lane scatters the entries of its query's
     // window out of its accumulators.  Register e of block nb holds slot 32 nb + 8 (e >> 2) + 4 hh + (e & 3) for query
     // 32 (wave & 1) + l31 (the C / D layout of the 32 x 32 MFMA); slot -> rectangle (row, column) incrementally.
-    for (int i = tid; i < LC_TQ * LC_TQ * P * P / 4; i += 256) reinterpret_cast<f32x4*>(Dl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < LC_TQ * LC_TQ * P * P / 4; i += NTHR) reinterpret_cast<f32x4*>(Dl)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     const int l31 = lane & 31, hh = lane >> 5;
     const int q = 32 * (wave & 1) + l31;
@@ -484,8 +489,8 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
     float* dq = Dl + q * (P * P);
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
-      const int s0 = (2 * i + (wave >> 1)) * 32 + 4 * hh;
-      if ((2 * i + (wave >> 1)) * 32 < (int)npx) {
+      const int s0 = (NBG * i + (wave >> 1)) * 32 + 4 * hh;
+      if ((NBG * i + (wave >> 1)) * 32 < (int)npx) {
         int py = s0 / bwp, px = s0 - py * bwp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
   } else {
 #pragma unroll
     for (int ri = 0; ri < NR; ++ri) {
-      const int r = wave + 4 * ri;
+      const int r = wave + NWV * ri;
       if (r < P) {
 #pragma unroll
         for (int j = 0; j < P; ++j) Dl[lane * (P * P) + r * P + j] = acc[ri][j];
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(256, (R <= 3 ? 2 : 1)) void local_corr_tile_kernel(
     }
   }
   __syncthreads();
-  for (int o = tid; o < LC_TQ * LC_TQ * K; o += 256) {
+  for (int o = tid; o < LC_TQ * LC_TQ * K; o += NTHR) {
     const int q = o / K, k = o - q * K;
     const int qp = qpx[q];
     if (qp < 0) continue;
@@ -798,7 +803,7 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
   hipLaunchKernelGGL((local_corr_classify_kernel<R>), dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, stream, a);
   ROMA_LAUNCH_CHECK();
   // (capping this launch at 1024 workgroups - the kernel strides over the list - changes nothing either way: measured)
-  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT, MFMA>), dim3((unsigned)tiles), dim3(256), lds_tile, stream, a);
+  hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT, MFMA>), dim3((unsigned)tiles), dim3(LcGeom<R, MFMA>::NTHR), lds_tile, stream, a);
   ROMA_LAUNCH_CHECK();
   // gather list: one query per wave, four per workgroup.  (Eight waves per workgroup - to share the two dependent scalar
   // loads at the head of every workgroup - were measured SLOWER on the benchmark model's incoherent warps: 1.86 vs 1.60 ms
@@ -822,7 +827,7 @@ static int launch_tiled(const LocalCorrArgs& a0, hipStream_t stream) {
     // the number of items is only known on the device: at most one per tile's worth of queries plus one partial item per bin.
     // The kernel strides over the item list, so a capped grid is enough; surplus workgroups exit at once.
     const long max_items = (long)tiles + nbins;
-    hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT, MFMA, true>), dim3((unsigned)std::min<long>(max_items, 8192)), dim3(256),
+    hipLaunchKernelGGL((local_corr_tile_kernel<R, T, TOUT, MFMA, true>), dim3((unsigned)std::min<long>(max_items, 8192)), dim3(LcGeom<R, MFMA>::NTHR),
                        lds_tile, stream, a);
     ROMA_LAUNCH_CHECK();
   } else {
