@@ -745,6 +745,11 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
     u.M = d; u.N = mrem; u.K = 64; u.batch = batch;
     if (int rc = gemm_launch(u, st)) return rc;
   }
+  // Round 6: the whole backward substitution as one launch (chol_col.hip::chol_bwd_kernel) when L^T and the inverse tables come
+  // from the block-column kernels; roma_tuning("gp_bwd", 0) / ROMA_GP_BWD=0: the launch chain below
+  static const bool bwdf_env = !(getenv("ROMA_GP_BWD") && atoi(getenv("ROMA_GP_BWD")) == 0);
+  if (col && (g_gp_bwd_fused >= 0 ? g_gp_bwd_fused != 0 : bwdf_env))
+    return chol_bwd_launch(Rt, n, sR, LT, sLT, n, d, LinvT, nblk, batch, st);
   static const bool bwd_env = !(getenv("ROMA_GP_BWD2") && atoi(getenv("ROMA_GP_BWD2")) == 0);  // A/B: 0 = two launches per backward step
   if (bwd_env && nblk > 1) {
     // Backward substitution with ONE launch per step.  X_k = R_k Linv_kk and R_j -= X_k L[k,j] (j < k) re-associate to
@@ -1298,8 +1303,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         if (fw->flow[si]) ROMA_CHECK_HIP(hipMemcpyAsync(fw->flow[si], flow, (size_t)ndp * hw * 2 * 4, hipMemcpyDeviceToDevice, st));
         if (fw->cert[si]) ROMA_CHECK_HIP(hipMemcpyAsync(fw->cert[si], cert, (size_t)ndp * hw * 4, hipMemcpyDeviceToDevice, st));
       }
-      // (a kernel, not hipMemcpyAsync: the runtime served this 50-100 KB device-to-device copy as ~100 consecutive
-      //  __amd_rocclr_copyBuffer launches of 3.7 us each - 0.38 ms of the stream, profiles/r05_final_bench_bf16_kernel_stats.csv)
+      // (one of our own kernels rather than a runtime copy node on the stream)
       if (ins == 16) {
         const long nkeep = (long)ndp * hw;
         if (nkeep % 4 == 0) {
