@@ -254,7 +254,6 @@ int roma_tuning(const char* key, int value) {
   else if (k == "gp_col") g_gp_col = value;
   else if (k == "pool_proj") g_pool_proj = value;
   else if (k == "gp_col_leader") g_gp_col_leader = value;
-  else if (k == "gp_bwd") g_gp_bwd_fused = value;
   else {
     set_error("roma_tuning: unknown key " + k);
     return ROMA_ERR_ARG;

@@ -232,67 +232,6 @@ __global__ __launch_bounds__(256) void chol_col_restore_kernel(float* __restrict
   for (int idx = tid; idx < 64 * 64; idx += 256) dst[(long)(idx >> 6) * ld + (idx & 63)] = tile[(idx & 63) * 65 + (idx >> 6)];
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Backward substitution  X L^T = Y  (X, Y: the d right-hand-side rows of the augmented system, in place), fused: ONE launch.
-// The rows of X are independent, so a workgroup owns 64 of them and walks the block columns k = nblk - 1 .. 0 itself:
-//     X_k = (Y_k - sum_{j > k} X_j L[j, k]) Linv_kk        L[j, k] read as rows of L^T (K-contiguous), Linv_kk from the tables
-// - the 26 dependent launches of the right-looking form (one tiny GEMM per column, 0.6 ms of the chain with both streams in
-// it) become a loop with two workgroup barriers per column.  Same tile machinery as the column kernel (f32 MFMA, operands
-// straight from L2); X_k goes back to global memory and is re-read by the later columns of the SAME workgroup (one CU: its
-// stores are visible to its own loads behind __syncthreads).
-__global__ __launch_bounds__(256, 2) void chol_bwd_kernel(float* __restrict__ R, long ldr, long strideR, const float* __restrict__ LTm,
-                                                         long strideLT, int n, const float* __restrict__ LinvT, int nblk) {
-  constexpr int S = CHOL_S;
-  __shared__ __attribute__((aligned(16))) float Pb[64 * S];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63, l31 = lane & 31, kk = lane >> 5;
-  const int rb = blockIdx.x, img = blockIdx.y;
-  const int ti = wave >> 1, tj = wave & 1;
-  float* Rw = R + (long)img * strideR + (64l * rb) * ldr;            // this workgroup's 64 rows
-  const float* LTi = LTm + (long)img * strideLT;
-  for (int k = nblk - 1; k >= 0; --k) {
-    const long S0 = 64l * k;
-    // sum over the columns already solved: slabs j = k + 1 .. nblk - 1 of X (A operand) and of L^T rows S0 .. (B operand)
-    const float* pa = Rw + (32 * ti + l31) * ldr + S0 + 64 + 32 * kk;
-    const float* pb = LTi + (S0 + 32 * tj + l31) * (long)n + S0 + 64 + 32 * kk;
-    const f32x16 acc = cc_tile_product(pa, pb, nblk - 1 - k);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kk, col = 32 * tj + l31;
-      Pb[row * S + col] = Rw[row * ldr + S0 + col] - acc[r];
-    }
-    __syncthreads();
-    // X_k = P Linv_kk : second operand lane (nn, kk) holds Linv[c][nn] = LinvT[nn][c], c = 32 kk + (0 .. 31)
-    const float* lt = LinvT + ((long)img * nblk + k) * 4096 + (32 * tj + l31) * 64 + 32 * kk;
-    f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const f32x4 pv = *reinterpret_cast<const f32x4*>(&Pb[(32 * ti + l31) * S + 32 * kk + 4 * q]);
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(lt + 4 * q);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) o = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[u], xv[u], o, 0, 0, 0);
-    }
-    float* dst = Rw + (32 * ti + 4 * kk) * ldr + S0 + 32 * tj + l31;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * ldr] = o[r];
-    __syncthreads();  // X_k is visible to every wave of this workgroup (and Pb free) before the next column reads it
-  }
-}
-
-int g_gp_bwd_fused = -1;  // roma_tuning("gp_bwd", v): 1 = fused backward kernel (default), 0 = launch chain, -1 = env ROMA_GP_BWD
-
-int chol_bwd_launch(float* Rt, long ldr, long strideR, const float* LT, long strideLT, int n, int d, const float* LinvT, int nblk,
-                    int batch, hipStream_t s) {
-  ROMA_REQUIRE(n % 64 == 0 && d % 64 == 0 && d >= 64 && ldr % 4 == 0 && n % 4 == 0, "chol_bwd: n, d multiples of 64");
-  hipLaunchKernelGGL(chol_bwd_kernel, dim3((unsigned)(d / 64), (unsigned)batch), dim3(256), 0, s, Rt, ldr, strideR, LT, strideLT, n,
-                     LinvT, nblk);
-  ROMA_LAUNCH_CHECK();
-  return 0;
-}
-
 int g_gp_col_leader = -1;  // roma_tuning("gp_col_leader", v): 1 = leader + followers (default), 0 = every workgroup factorises its own copy
 
 // Block column k of the augmented system: A [batch][(n + d) x n] (ld = n), LT [batch][n x n].  `epoch`: any value that differs

@@ -60,10 +60,6 @@ int chol_diag_launch(float* A, long ld, long strideA, float* Linv, float* LinvT,
 int chol_col_launch(float* A, long ld, long strideA, float* LT, long strideLT, int n, int d, float* Linv, float* LinvT, int k,
                     int nblk, int batch, unsigned epoch, hipStream_t s);
 extern int g_gp_col_leader;  // roma_tuning("gp_col_leader"): leader / follower hand-off inside a column launch on / off
-// the backward substitution of the same solve as ONE launch (chol_col.hip): Rt [batch][d x n] (row stride ldr) in place
-int chol_bwd_launch(float* Rt, long ldr, long strideR, const float* LT, long strideLT, int n, int d, const float* LinvT, int nblk,
-                    int batch, hipStream_t s);
-extern int g_gp_bwd_fused;  // roma_tuning("gp_bwd")
 int chol_col_restore_launch(float* A, long ld, long strideA, const float* LT, long strideLT, int n, int batch, hipStream_t s);
 
 // pad the trailing (npad - n) diagonal of a Gram matrix with identity and zero its off-diagonals

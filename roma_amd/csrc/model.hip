@@ -745,11 +745,6 @@ int cholesky_solve_t(float* A, float* Rt, float* LT, float* Linv, float* LinvT, 
     u.M = d; u.N = mrem; u.K = 64; u.batch = batch;
     if (int rc = gemm_launch(u, st)) return rc;
   }
-  // Round 6: the whole backward substitution as one launch (chol_col.hip::chol_bwd_kernel) when L^T and the inverse tables come
-  // from the block-column kernels; roma_tuning("gp_bwd", 0) / ROMA_GP_BWD=0: the launch chain below
-  static const bool bwdf_env = !(getenv("ROMA_GP_BWD") && atoi(getenv("ROMA_GP_BWD")) == 0);
-  if (col && (g_gp_bwd_fused >= 0 ? g_gp_bwd_fused != 0 : bwdf_env))
-    return chol_bwd_launch(Rt, n, sR, LT, sLT, n, d, LinvT, nblk, batch, st);
   static const bool bwd_env = !(getenv("ROMA_GP_BWD2") && atoi(getenv("ROMA_GP_BWD2")) == 0);  // A/B: 0 = two launches per backward step
   if (bwd_env && nblk > 1) {
     // Backward substitution with ONE launch per step.  X_k = R_k Linv_kk and R_j -= X_k L[k,j] (j < k) re-associate to
