@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const ConvPatchAr
             f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][4 * rg + j];
-            v = epi_apply<ACT_RELU, true, false>(v, cols.b[tn][rg], cols.s[0][rg], cols.has_b);
+            v = epi_apply<ACT_RELU, true, false>(v, cols.b[tn][rg], cols.s[0][rg]);
             uint2 pk;
             pk.x = pack_bf16x2(v[0], v[1]);
             pk.y = pack_bf16x2(v[2], v[3]);

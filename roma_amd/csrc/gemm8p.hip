@@ -33,6 +33,9 @@
 //     covers them names every destination register as a read-write operand, so no consumer can be scheduled above it;
 //     tools/audit_gemm8p_isa.py checks in the emitted ISA that nothing touches those registers between a read and its
 //     wait.
+// packed-f32 GELU epilogue (gemm_device.h): this translation unit is compiled with packed-f32 instructions enabled
+// (Makefile PK_SRCS) and is covered by tools/audit_pk_sgpr.py
+#define ROMA_EPI_PK 1
 #include "gemm.h"
 
 #include <stdio.h>

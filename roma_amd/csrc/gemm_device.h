@@ -34,6 +34,27 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   return fmaf(-0.5f * z, e, fmaxf(x, 0.f));
 }
 
+// The same function on four values with packed-f32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32: two values per issue slot) -
+// only in translation units compiled WITH packed-f32 instructions (ROMA_EPI_PK: gemm8p.hip, the DINOv2 fc1 GEMM).  Per
+// element the same IEEE operations in the same order as gelu_erf_fast: bit-identical.  Round 6: the activation was 9 + 4
+// (quarter-rate v_exp) issue slots per value = 1 660 of the ~1 900 VALU slots of the fc1 epilogue per wave and tile.
+#if defined(ROMA_EPI_PK)
+typedef float epi_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ epi_f32x2 gelu_erf_fast2(epi_f32x2 x) {
+  const epi_f32x2 z = {fabsf(x[0]), fabsf(x[1])};
+  epi_f32x2 q = __builtin_elementwise_fma(epi_f32x2{4.881172499153763e-4f, 4.881172499153763e-4f}, z,
+                                          epi_f32x2{-7.198805455118418e-3f, -7.198805455118418e-3f});
+  q = __builtin_elementwise_fma(q, z, epi_f32x2{5.2146803587675095e-2f, 5.2146803587675095e-2f});
+  q = __builtin_elementwise_fma(q, z, epi_f32x2{4.595957100391388e-1f, 4.595957100391388e-1f});
+  q = __builtin_elementwise_fma(q, z, epi_f32x2{1.1510006189346313f, 1.1510006189346313f});
+  const epi_f32x2 t = q * z;
+  const epi_f32x2 e = {__builtin_amdgcn_exp2f(-t[0]), __builtin_amdgcn_exp2f(-t[1])};
+  const epi_f32x2 mz = z * epi_f32x2{-0.5f, -0.5f};
+  const epi_f32x2 mx = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+  return __builtin_elementwise_fma(mz, e, mx);
+}
+#endif
+
 template <typename TOUT> __device__ inline void store4(TOUT* p, f32x4 v, bool vec, int nvalid) {
   if (vec && nvalid >= 4) {
     ElemIO<TOUT>::st4(p, v);
@@ -84,7 +105,10 @@ struct EpiCols {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int n = nw0 + tn * 32 + 8 * rg + 4 * h;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sv = {1.f, 1.f, 1.f, 1.f};
+        // no bias: -0.0, the exact additive identity (x + -0.0 == x for every x including -0.0), so that the epilogues add
+        // unconditionally - with `if (has_b)` hipcc computed BOTH alpha * acc and fma(alpha, acc, bias) for every value and
+        // selected (12 VALU instructions per 4 values instead of 4: round 6 ISA count)
+        f32x4 bv = {-0.f, -0.f, -0.f, -0.f}, sv = {1.f, 1.f, 1.f, 1.f};
         if (FULL || n + 3 < a.N) {
           if (has_b) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
           if (HAS_S && a.scale) sv = *reinterpret_cast<const f32x4*>(a.scale + n);
@@ -113,18 +137,48 @@ struct EpiCols {
   }
 };
 
+// alpha * acc + bias as ONE fma per value (what hipcc's contraction made of `alpha * acc` followed by `+= bias` all along;
+// written out so that it stays one instruction - and one rounding - in the packed-f32 translation units too).  bias is -0.0
+// where the caller passed none (EpiCols::load): fma(alpha, acc, -0.0) == alpha * acc exactly.
+__device__ __forceinline__ f32x4 epi_axpb(float alpha, f32x4 accv, f32x4 bv) {
+#if defined(ROMA_EPI_PK)
+  const epi_f32x2 al = {alpha, alpha};
+  const epi_f32x2 r0 = __builtin_elementwise_fma(al, epi_f32x2{accv[0], accv[1]}, epi_f32x2{bv[0], bv[1]});
+  const epi_f32x2 r1 = __builtin_elementwise_fma(al, epi_f32x2{accv[2], accv[3]}, epi_f32x2{bv[2], bv[3]});
+  return f32x4{r0[0], r0[1], r1[0], r1[1]};
+#else
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = fmaf(alpha, accv[j], bv[j]);
+  return v;
+#endif
+}
+
+// activation and per-column scale of values that already carry their bias
 template <int ACT, bool BF16_OUT, bool HAS_S>
-__device__ __forceinline__ f32x4 epi_apply(f32x4 v, f32x4 bv, f32x4 sv, bool has_b) {
-  if (has_b) v += bv;
+__device__ __forceinline__ f32x4 epi_act(f32x4 v, f32x4 sv) {
   if (ACT == ACT_RELU) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
   } else if (ACT == ACT_GELU) {
+#if defined(ROMA_EPI_PK)
+    if constexpr (BF16_OUT) {
+      const epi_f32x2 g0 = gelu_erf_fast2(epi_f32x2{v[0], v[1]}), g1 = gelu_erf_fast2(epi_f32x2{v[2], v[3]});
+      v = f32x4{g0[0], g0[1], g1[0], g1[1]};
+    } else
+#endif
+    {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = BF16_OUT ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
+      for (int j = 0; j < 4; ++j) v[j] = BF16_OUT ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
+    }
   }
   if constexpr (HAS_S) v *= sv;  // (1.0 where the caller passed no scale)
   return v;
+}
+template <int ACT, bool BF16_OUT, bool HAS_S>
+__device__ __forceinline__ f32x4 epi_apply(f32x4 v, f32x4 bv, f32x4 sv) {
+  v += bv;  // (-0.0 where the caller passed no bias: EpiCols::load)
+  return epi_act<ACT, BF16_OUT, HAS_S>(v, sv);
 }
 
 // bf16 output: the MFMA layout gives each lane 4 consecutive n of ONE row, i.e. a wave store would scatter 8-byte
@@ -144,51 +198,65 @@ __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], con
   // the operator entry point, only together with the bf16 residual; gemm_launch routes other uses to the generic epilogue.
   EpiCols<TN, FULL, HAS_S> cols;
   cols.load(a, nw0, h);
+  // Geometry of the 16-byte pieces this lane moves from the staged rows to C: the same for every 32-row block, so the LDS
+  // offset and the per-lane byte offset into C / the residual are formed ONCE; the row block only moves the wave-uniform
+  // base.  (Round 6: per piece and block hipcc re-derived row / chunk / swizzle and a 64-bit m * ldc product - ~22 VALU
+  // instructions, three of them quarter-rate multiplies - and waited for each ds_read right behind it; now the NPC reads
+  // are issued back to back.)
+  int rdo[NPC], prow[NPC], pn[NPC];
+  unsigned doff[NPC], roff[RES ? NPC : 1];
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int c = lane + 64 * i;
+    const int row = c / CPR, ch = c - row * CPR;
+    rdo[i] = row * RB + ((ch ^ epi_swz<CPR>(row)) << 4);
+    prow[i] = row;
+    pn[i] = nw0 + ch * 8;
+    doff[i] = (unsigned)(row * (int)a.ldc + ch * 8) * 2u;  // (row < 32: fits 32 bits for every ldc < 2^25)
+    if constexpr (RES) roff[i] = (unsigned)(row * (int)a.ldr + ch * 8) * 2u;
+  }
+  char* cbase = reinterpret_cast<char*>(Cb + mw0 * a.ldc + nw0);
+  const char* rbase = RES ? reinterpret_cast<const char*>(Rb + mw0 * a.ldr + nw0) : nullptr;
+  const long dstep = 64 * a.ldc, rstep = 64 * a.ldr;  // 32 rows, in bytes
   // bf16 residual rows in a rolling buffer: piece i of block tm + 1 is requested the moment piece i of block tm has been
   // consumed, so a request has the rest of the row pass plus the next staging pass to come back from L2 / HBM (a second
   // buffer would cost 16-24 registers next to the accumulators: it spilled).  The lane that reads a 16-byte piece is the
   // lane that later writes it, and blocks are disjoint rows: in-place is race free.
   uint4 rres[RES ? NPC : 1];
+  auto piece_ok = [&](int tm, int i) { return FULL || (mw0 + tm * 32 + prow[i] < a.M && pn[i] + 8 <= a.N); };
   auto load_res = [&](int tm, int i) {
-    const int c = lane + 64 * i;
-    const int row = c / CPR, ch = c - row * CPR;
-    const long m = mw0 + tm * 32 + row;
-    const int n = nw0 + ch * 8;
     rres[i] = make_uint4(0, 0, 0, 0);
-    if (FULL || (m < a.M && n + 8 <= a.N)) rres[i] = *reinterpret_cast<const uint4*>(Rb + m * a.ldr + n);
+    if (piece_ok(tm, i)) rres[i] = *reinterpret_cast<const uint4*>(rbase + (long)tm * rstep + roff[i]);
   };
   if constexpr (RES) {
 #pragma unroll
     for (int i = 0; i < NPC; ++i) load_res(0, i);
   }
+  const bool nt = (a.dbg & 1024) != 0;  // streaming (non-temporal) stores, the default (gemm_launch): acknowledged sooner in the vmcnt queue
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
-    const long mw = mw0 + tm * 32;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = a.alpha * acc[tn][tm][4 * rg + j];
-        v = epi_apply<ACT, true, HAS_S>(v, cols.b[tn][rg], cols.s[HAS_S ? tn : 0][rg], cols.has_b);
+        const f32x16& ab = acc[tn][tm];
+        f32x4 v = epi_axpb(a.alpha, f32x4{ab[4 * rg], ab[4 * rg + 1], ab[4 * rg + 2], ab[4 * rg + 3]}, cols.b[tn][rg]);
+        v = epi_act<ACT, true, HAS_S>(v, cols.s[HAS_S ? tn : 0][rg]);
         uint2 pk;
         pk.x = pack_bf16x2(v[0], v[1]);
         pk.y = pack_bf16x2(v[2], v[3]);
         const int ch = tn * 4 + rg;
         *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ epi_swz<CPR>(l31)) << 4) + 8 * h) = pk;
       }
+    uint4 pv[NPC];
 #pragma unroll
-    for (int i = 0; i < NPC; ++i) {
-      const int c = lane + 64 * i;
-      const int row = c / CPR, ch = c - row * CPR;
-      const long m = mw + row;
-      const int n = nw0 + ch * 8;
-      uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ epi_swz<CPR>(row)) << 4));
-      bf16_t* dst = Cb + m * a.ldc + n;
-      if constexpr (RES) {
+    for (int i = 0; i < NPC; ++i) pv[i] = *reinterpret_cast<const uint4*>(ws + rdo[i]);
+    if constexpr (RES) {
+#pragma unroll
+      for (int i = 0; i < NPC; ++i) {
+        uint4 v = pv[i];
         epi_consume(rres[i]);  // consumed on every path (see EpiCols::load)
-        if (FULL || (m < a.M && n + 8 <= a.N)) {
+        if (piece_ok(tm, i)) {
           const uint4 r = rres[i];
           const unsigned* vp = reinterpret_cast<const unsigned*>(&v);
           const unsigned* rp = reinterpret_cast<const unsigned*>(&r);
@@ -200,23 +268,34 @@ __device__ __forceinline__ void epi_staged_bf16(const f32x16 (&acc)[TN][TM], con
           v = make_uint4(o[0], o[1], o[2], o[3]);
         }
         if (tm + 1 < TM) load_res(tm + 1, i);  // the register is free again: request the same piece of the next block
+        pv[i] = v;
       }
-      if (a.dbg & 1) continue;
-      if (FULL) {
-        if (a.dbg & 1024) {  // streaming (non-temporal) stores, the default (gemm_launch): acknowledged sooner in the vmcnt queue
-          typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
-          __builtin_nontemporal_store(u32x4n{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4n*>(dst));
-        } else {
-          *reinterpret_cast<uint4*>(dst) = v;
-        }
+    }
+    if (a.dbg & 1) continue;  // ablation (tools/bench_gemm_overhead.py): no stores
+    char* cb = cbase + (long)tm * dstep;
+    if (FULL) {
+      if (nt) {
+        typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < NPC; ++i)
+          __builtin_nontemporal_store(u32x4n{pv[i].x, pv[i].y, pv[i].z, pv[i].w}, reinterpret_cast<u32x4n*>(cb + doff[i]));
       } else {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) *reinterpret_cast<uint4*>(cb + doff[i]) = pv[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPC; ++i) {
+        const long m = mw0 + tm * 32 + prow[i];
+        const int n = pn[i];
         if (m >= a.M || n >= a.N) continue;
+        bf16_t* d = reinterpret_cast<bf16_t*>(cb + doff[i]);
         if (n + 8 <= a.N) {
-          *reinterpret_cast<uint4*>(dst) = v;
+          *reinterpret_cast<uint4*>(d) = pv[i];
         } else {
-          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+          const bf16_t* e = reinterpret_cast<const bf16_t*>(&pv[i]);
           for (int j = 0; j < 8; ++j)
-            if (n + j < a.N) dst[j] = e[j];
+            if (n + j < a.N) d[j] = e[j];
         }
       }
     }
@@ -239,6 +318,28 @@ __device__ __forceinline__ void epi_staged_qkv(const f32x16 (&acc)[TN][TM], cons
   const float sc = which == 0 ? a.qscale : 1.0f;
   EpiCols<TN, true, false> cols;  // N = 3 * heads * hd is a multiple of the wave's 64 columns: always a full vector
   cols.load(a, nw0, h);
+  // the 16-byte pieces this lane moves out of the staged block: LDS offset and element offset inside the image's q / k
+  // ([head][token][d]) or V^T ([head][d][token]) are the same for every 32-row block (round 6: were re-derived, with a
+  // division by hd, per piece and block)
+  constexpr int NPC = (32 * CPR) / 64;
+  int rdo[NPC], poff[NPC], prow[NPC];
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int c = lane + 64 * i;
+    if (which < 2) {
+      const int row = c / CPR, ch = c - row * CPR;
+      const int nr = nrel + ch * 8;
+      const int head = nr / a.hd, d = nr - head * a.hd;
+      rdo[i] = row * RB + ((ch ^ epi_swz<CPR>(row)) << 4);
+      poff[i] = (head * a.npad + row) * a.hd + d;
+      prow[i] = row;
+    } else {
+      const int dl = c >> 2, tg = c & 3;
+      rdo[i] = dl * 64 + tg * 16;
+      poff[i] = (nrel + dl) * a.npad + tg * 8;  // (head * hd + d == the column inside V)
+      prow[i] = 0;
+    }
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const long mw = mw0 + tm * 32;
@@ -255,7 +356,7 @@ __device__ __forceinline__ void epi_staged_qkv(const f32x16 (&acc)[TN][TM], cons
           f32x4 v;
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][4 * rg + j];
-          if (cols.has_b) v += cols.b[tn][rg];
+          v += cols.b[tn][rg];
           v *= sc;
           uint2 pk;
           pk.x = pack_bf16x2(v[0], v[1]);
@@ -263,16 +364,14 @@ __device__ __forceinline__ void epi_staged_qkv(const f32x16 (&acc)[TN][TM], cons
           const int ch = tn * 4 + rg;
           *reinterpret_cast<uint2*>(ws + l31 * RB + ((ch ^ epi_swz<CPR>(l31)) << 4) + 8 * h) = pk;
         }
-      bf16_t* dstb = reinterpret_cast<bf16_t*>(which == 0 ? a.q : a.k);
+      bf16_t* dstb = reinterpret_cast<bf16_t*>(which == 0 ? a.q : a.k) + ((long)qb * a.heads * a.npad + qt0) * a.hd;
+      uint4 pv[NPC];
 #pragma unroll
-      for (int c = lane; c < 32 * CPR; c += 64) {
-        const int row = c / CPR, ch = c - row * CPR;
-        const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RB + ((ch ^ epi_swz<CPR>(row)) << 4));
-        const int nr = nrel + ch * 8;
-        const int head = nr / a.hd, d = nr - head * a.hd;
-        if (qt0 + row >= a.ntok || (a.dbg & 1)) continue;  // padding rows stay zero
-        *reinterpret_cast<uint4*>(dstb + (((long)qb * a.heads + head) * a.npad + qt0 + row) * a.hd + d) = v;
-      }
+      for (int i = 0; i < NPC; ++i) pv[i] = *reinterpret_cast<const uint4*>(ws + rdo[i]);
+      if (a.dbg & 1) continue;
+#pragma unroll
+      for (int i = 0; i < NPC; ++i)
+        if (qt0 + prow[i] < a.ntok) *reinterpret_cast<uint4*>(dstb + poff[i]) = pv[i];  // padding rows stay zero
     } else {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
@@ -282,7 +381,7 @@ __device__ __forceinline__ void epi_staged_qkv(const f32x16 (&acc)[TN][TM], cons
           f32x4 v;
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][4 * rg + j];
-          if (cols.has_b) v += cols.b[tn][rg];
+          v += cols.b[tn][rg];
           const uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
           unsigned short* col = reinterpret_cast<unsigned short*>(ws + nl * 64 + l31 * 2);  // [d][token]
           col[0] = (unsigned short)(p0 & 0xffffu);
@@ -290,17 +389,14 @@ __device__ __forceinline__ void epi_staged_qkv(const f32x16 (&acc)[TN][TM], cons
           col[64] = (unsigned short)(p1 & 0xffffu);
           col[96] = (unsigned short)(p1 >> 16);
         }
-      bf16_t* vt = reinterpret_cast<bf16_t*>(a.vt);
+      static_assert(NPC == TN * 2, "V^T pieces");
+      bf16_t* vt = reinterpret_cast<bf16_t*>(a.vt) + (long)qb * a.heads * a.hd * a.npad + qt0;
+      uint4 pv[NPC];
 #pragma unroll
-      for (int i = 0; i < TN * 2; ++i) {
-        const int u = lane + 64 * i;
-        const int dl = u >> 2, tg = u & 3;
-        const uint4 v = *reinterpret_cast<const uint4*>(ws + dl * 64 + tg * 16);
-        const int nr = nrel + dl;
-        const int head = nr / a.hd, d = nr - head * a.hd;
-        if (a.dbg & 1) continue;
-        *reinterpret_cast<uint4*>(vt + (((long)qb * a.heads + head) * a.hd + d) * a.npad + qt0 + tg * 8) = v;
-      }
+      for (int i = 0; i < NPC; ++i) pv[i] = *reinterpret_cast<const uint4*>(ws + rdo[i]);
+      if (a.dbg & 1) continue;
+#pragma unroll
+      for (int i = 0; i < NPC; ++i) *reinterpret_cast<uint4*>(vt + poff[i]) = pv[i];
     }
   }
 }
@@ -337,10 +433,9 @@ __device__ __forceinline__ void epi_staged_f32(const f32x16 (&acc)[TN][TM], cons
       }
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = a.alpha * acc[tn][tm][4 * rg + j];
-        v = epi_apply<ACT, false, true>(v, cols.b[0][rg], cols.s[0][rg], cols.has_b);
+        const f32x16& ab = acc[tn][tm];
+        f32x4 v = epi_axpb(a.alpha, f32x4{ab[4 * rg], ab[4 * rg + 1], ab[4 * rg + 2], ab[4 * rg + 3]}, cols.b[0][rg]);
+        v = epi_act<ACT, false, true>(v, cols.s[0][rg]);
         *reinterpret_cast<f32x4*>(ws + l31 * 128 + (((2 * rg + h) ^ (l31 & 7)) << 4)) = v;
       }
 #pragma unroll
