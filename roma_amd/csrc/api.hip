@@ -240,6 +240,7 @@ int roma_tuning(const char* key, int value) {
   if (k == "gemm8p") g_gemm_tuning[0] = value;
   else if (k == "gemm_dbg") g_gemm_tuning[1] = value;
   else if (k == "gemm8p_sched") g_gemm8p_sched = value;
+  else if (k == "gemm8p_maxwg") g_gemm8p_maxwg = value;
   else if (k == "ws1x1") g_ws1x1_mode = value;
   else if (k == "lc_mode") g_lc_mode = value;
   else if (k == "lc_bin") g_lc_bin = value;

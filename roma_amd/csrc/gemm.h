@@ -71,6 +71,7 @@ int gemm6p_try_launch(const GemmArgs& a, hipStream_t stream);
 int ws1x1_try_launch(const GemmArgs& a, hipStream_t stream);
 extern int g_ws1x1_mode;  // roma_tuning("ws1x1", v): 1 on (default), 0 off, -1 = environment ROMA_WS1X1
 extern int g_gemm8p_sched;    // gemm8p K-loop schedule: 1 = k-half phases, 0 = quadrant phases, -1 = environment ROMA_GEMM8P_SCHED (default 1)
+extern int g_gemm8p_maxwg;    // gemm8p persistent-grid cap (tools: tools/bench_gemm_burst.py), -1 = 256
 int gemm8p_trace_read(unsigned* host, long nbytes);  // phase trace of the last ablation-build launch (tools/bench_gemm_ablation.py)
 extern int g_gemm_tuning[2];  // process-wide A/B switches (roma_tuning): [0] use gemm8p (-1 = env ROMA_GEMM8P, default on), [1] dbg bits
 

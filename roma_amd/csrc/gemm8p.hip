@@ -52,6 +52,7 @@ namespace roma {
 // pointer, so the zero "row" must be as long as the longest K row (K <= 32704 bf16)
 static __device__ __attribute__((aligned(256))) unsigned int g_zero_rows[16384];
 
+int g_gemm8p_maxwg = -1;  // roma_tuning("gemm8p_maxwg"): see launch8p_s
 int g_gemm_tuning[2] = {-1, -1};  // [0] gemm8p on / off, [1] dbg bits; -1 = environment (roma_tuning, tests / A-B runs)
 
 enum { E8_NONE = 0, E8_RELU = 1, E8_GELU = 2, E8_RESBF16 = 3, E8_QKV = 4 };
@@ -302,8 +303,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
   __builtin_amdgcn_s_barrier();                  \
   __builtin_amdgcn_sched_barrier(0);
 
+#ifdef ROMA_TOOLS_BUILD  // A/B switches of tools builds: no s_setprio around the MFMA blocks / no wave-group stagger
   const bool prio = !(a.dbg & 64);
   const bool stagger = !(a.dbg & 128);
+#else  // shipped libraries: constants, so that the K loop carries no branch around its s_setprio pairs
+  constexpr bool prio = true, stagger = true;
+#endif
 
   // tile coordinates advance incrementally (one scalar division pair here, none per tile)
   int c_tm = (int)(((long)xcd * per_xcd + li) / NT), c_tn = (int)(((long)xcd * per_xcd + li) % NT);
@@ -348,121 +353,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
     // dead across the epilogue, which needs every register it can get (128 accumulators + the per-column vectors).
     if (gk != 0) R8_TILE_SETUP(c_tm, c_tn)
 
-    for (int kt = 0; kt < nk; ++kt, ++gk) {
-      const unsigned cb = gk & 1u;
-      const unsigned sb = lds0 + cb * BUF;
-      // stream positions s+1 (P1, P2) and s+2 (P3, P4): inside this tile, or the head of the next one
-      const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
-      const bool n1 = in1 || has_next, n2 = in2 || has_next;
-      const int k1 = in1 ? kt + 1 : 0, k2 = in2 ? kt + 2 : kt + 2 - nk;
-      // Nothing of this wave is outstanding on LGKM here (P4 reads nothing).  Saying so in a form the compiler sees keeps
-      // its loop-carried bookkeeping (the epilogue's own LDS reads) from dropping an s_waitcnt lgkmcnt(0) between the
-      // asm fragment reads below (it did: one ~100-cycle stall per K tile).
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-      if constexpr (DMAMF) {
-        // same stream positions per phase as below; the pieces are issued inside the MFMA blocks, so the P4 wait (still in
-        // P4's load block) sees one half-tile less in flight: vmcnt(2) leaves only A0(s+2)
-        R8_READ_W(bf0, 0, sb)
-        __builtin_amdgcn_sched_barrier(0);
-        R8_READ_A(0, sb)
-        R8_PHASE_DM(R8_WAIT_LGKM_AW(bf0), 0, 0, bf0, if (n1) R8_ISSUE_W1(1, 0, k1, cb ^ 1u), if (n1) R8_ISSUE_W1(1, 1, k1, cb ^ 1u))
-        R8_READ_W(bf1, 1, sb)
-        R8_PHASE_DM(R8_WAIT_LGKM_W(bf1), 0, 1, bf1, if (n1) R8_ISSUE_A1(1, 0, k1, cb ^ 1u), if (n1) R8_ISSUE_A1(1, 1, k1, cb ^ 1u))
-        R8_READ_A(1, sb)
-        if (in1 && !in2 && has_next) R8_TILE_SETUP(n_tm, n_tn)
-        R8_PHASE_DM(R8_WAIT_LGKM_A(), 1, 1, bf1, if (n2) R8_ISSUE_A1(0, 0, k2, cb), if (n2) R8_ISSUE_A1(0, 1, k2, cb))
-        if (n2) {
-          R8_WAIT_VM(2);
-        } else {
-          R8_WAIT_VM(0);
-        }
-        R8_PHASE_DM(, 1, 0, bf0, if (n2) R8_ISSUE_W1(0, 0, k2, cb), if (n2) R8_ISSUE_W1(0, 1, k2, cb))
-        continue;
-      }
-      if constexpr (SCHED == 1) {
-        // "KH": a phase is one 64-row half x BOTH column halves x one k-pair (two of the four 16-deep k-groups), so the 24
-        // fragment reads of a K tile fall 8 / 6 / 6 / 4 on the four load blocks instead of 12 / 4 / 8 / 0 (P1's 48 KB
-        // per wave group is 192 LDS cycles + the read latency against the partner group's 256-cycle MFMA block), only
-        // 12 fragments are live instead of 16 (-16 VGPRs), and the 8 MFMAs of a phase rotate over 4 accumulators instead
-        // of 2.  Every accumulator still receives its k-groups in the order 0, 1, 2, 3: results are bit-identical.
-        //   P1: A0 W0 W1 of k-pair 0 -> rows 0;  P2: A1 k-pair 0 (+ W0 k-pair 1) -> rows 1;
-        //   P3: A1 k-pair 1 (+ W1 k-pair 1) -> rows 1;  P4: A0 k-pair 1 -> rows 0
-        // Region life times: W0 until P2, A1 and W1 until P3, A0 until P4, so the DMA stream is
-        //   P1(s): W1(s+1), P2(s): A0(s+1), P3(s): A1(s+1), P4(s): W0(s+2)        (each >= 2 phases after the last read)
-        // with TWO counted waits per K tile, each one phase ahead of the reads it covers: P4 vmcnt(4) (leaves A1(s+1),
-        // W0(s+2); covers P1(s+1)'s reads) and P1 vmcnt(4) (leaves W0(s+1), W1(s+1); covers A1(s), read in P2).
-        // P1
-        if (x_rd) {
-          R8K_READ_W(fw0, 0, 0, sb)
-          R8K_READ_W(fw1, 1, 0, sb)
-          __builtin_amdgcn_sched_barrier(0);
-          R8K_READ_A(0, 0, sb)
-        }
-        if (n1) {
-          if (x_dma) R8_ISSUE_W(1, k1, cb ^ 1u)
-          R8_WAIT_VM(4);
-        } else {
-          R8_WAIT_VM(0);
-        }
-        R8_PHASE_T(R8K_WAIT_AWW(fw0, fw1), R8K_MFMA(0, fw0, fw1), 0)
-        // P2
-        if (x_rd) {
-          R8K_READ_A(1, 0, sb)
-          R8K_READ_W(fw0n, 0, 1, sb)
-        }
-        if (n1 && x_dma) R8_ISSUE_A(0, k1, cb ^ 1u)
-        R8_PHASE_T(R8K_WAIT_AW(fw0n), R8K_MFMA(1, fw0, fw1), 1)
-        // P3
-        if (x_rd) {
-          R8K_READ_A(1, 1, sb)
-          R8K_READ_W(fw1n, 1, 1, sb)
-        }
-        if (n1 && x_dma) R8_ISSUE_A(1, k1, cb ^ 1u)
-        R8_PHASE_T(R8K_WAIT_AW(fw1n), R8K_MFMA(1, fw0n, fw1n), 2)
-        // P4: the DMA stream enters the next output tile here when kt == nk - 2
-        if (x_rd) R8K_READ_A(0, 1, sb)
-        if (in1 && !in2 && has_next) R8_TILE_SETUP(n_tm, n_tn)
-        if (n2) {
-          if (x_dma) R8_ISSUE_W(0, k2, cb)
-          R8_WAIT_VM(4);
-        } else {
-          R8_WAIT_VM(2);
-        }
-        R8_PHASE_T(R8K_WAIT_A(), R8K_MFMA(0, fw0n, fw1n), 3)
-      } else {
-      // P1: A0 + W0 -> (0,0); stage W1(s+1)
-      if (x_rd) {
-        R8_READ_W(bf0, 0, sb)
-        __builtin_amdgcn_sched_barrier(0);
-        R8_READ_A(0, sb)
-      }
-      if (n1 && x_dma) R8_ISSUE_W(1, k1, cb ^ 1u)
-      R8_PHASE_T(R8_WAIT_LGKM_AW(bf0), if (x_mf) R8_MFMA_Q(0, 0, bf0), 0)
-      // P2: W1 -> (0,1); stage A1(s+1)
-      if (x_rd) R8_READ_W(bf1, 1, sb)
-      if (n1 && x_dma) R8_ISSUE_A(1, k1, cb ^ 1u)
-      R8_PHASE_T(R8_WAIT_LGKM_W(bf1), if (x_mf) R8_MFMA_Q(0, 1, bf1), 1)
-      // P3: A1 -> (1,1); stage A0(s+2).  The DMA stream enters the next output tile here when kt == nk - 2.
-      if (x_rd) R8_READ_A(1, sb)
-      if (in1 && !in2 && has_next) R8_TILE_SETUP(n_tm, n_tn)
-      if (n2 && x_dma) R8_ISSUE_A(0, k2, cb)
-      R8_PHASE_T(R8_WAIT_LGKM_A(), if (x_mf) R8_MFMA_Q(1, 1, bf1), 2)
-      // P4: no reads -> (1,0); stage W0(s+2); all of s+1 must have landed before this phase's first barrier
-      if (n2) {
-        if (x_dma) R8_ISSUE_W(0, k2, cb)
-        R8_WAIT_VM(4);
-      } else {
-        R8_WAIT_VM(0);
-      }
-      R8_PHASE_T(, if (x_mf) R8_MFMA_Q(1, 0, bf0), 3)
-      }
-      if constexpr ((ABL & 1) != 0) {
-        // one 16-byte record per K tile in the (idle) epilogue staging slice of this wave
-        if (gk < 256u && lane == 0) {
-          uint4 rec = {(unsigned)tstamp[0], (unsigned)tstamp[1], (unsigned)tstamp[2], (unsigned)tstamp[3]};
-          *reinterpret_cast<uint4*>(smem + 2 * BUF + wave * 4096 + gk * 16) = rec;
-        }
-      }
+    // Round 6: K tiles with kt + 2 < nk run the STEADY copy of the body (constant stream bookkeeping), the last two of
+    // every output tile the general one - gemm8p_ktile.inc
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt, ++gk) {
+#define R8_STEADY 1
+#include "gemm8p_ktile.inc"
+#undef R8_STEADY
+    }
+    for (; kt < nk; ++kt, ++gk) {
+#define R8_STEADY 0
+#include "gemm8p_ktile.inc"
+#undef R8_STEADY
     }
     li = li_next;
     c_tm = n_tm;
@@ -552,7 +454,10 @@ static int launch8p_s(const GemmArgs& a, hipStream_t stream, const char* epi_nam
   constexpr int BM = 256, BN = 256;
   const long nblk = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const size_t lds = (size_t)2 * (BM + BN) * ROWB + 8 * 4096;  // 160 KiB: one persistent workgroup per CU
-  const long gx = std::min<long>(((nblk + 7) / 8) * 8, 256);
+  // roma_tuning("gemm8p_maxwg", n): tools only - cap the persistent grid (a multiple of 8) to measure what a tile's epilogue
+  // costs when fewer workgroups store at the same time (tools/bench_gemm_burst.py)
+  const long cap = g_gemm8p_maxwg >= 8 ? (g_gemm8p_maxwg / 8) * 8 : 256;
+  const long gx = std::min<long>(((nblk + 7) / 8) * 8, std::min<long>(cap, 256));
   char pname[96];
   snprintf(pname, sizeof pname, "gemm8p_kernel<" ROMA_H16_NAME ",%s,%s,%s>", sizeof(TOUT) == 4 ? "f32" : ROMA_H16_NAME, CONV ? "conv3x3" : "dense", epi_name);
   ProfScope ps(pname, 2.0 * (double)(a.m_alg > 0 ? a.m_alg : a.M) * (a.n_alg > 0 ? a.n_alg : a.N) * (a.k_alg > 0 ? a.k_alg : a.K), "flop", stream);

@@ -11,7 +11,8 @@ exactly there.  This script checks it for every kernel in the file, plus three p
 
   1. no instruction outside ;;#ASMSTART / ;;#ASMEND touches a register with an asm LDS read in flight;
   2. no scratch (spill) traffic between the first and the last MFMA of the kernel;
-  3. no compiler-inserted s_waitcnt inside the K loop except the one lgkmcnt(0) we place at the top of every K tile;
+  3. no compiler-inserted s_waitcnt inside the K loop except the one lgkmcnt(0) we place at the top of every K tile (one per
+     copy of the body: the STEADY and the general inner loop) and lgkmcnt(0) waits in the once-per-tile code between them;
   4. every K-loop `s_waitcnt vmcnt(N)` is ours (inside an asm block).
 
 Exit status 1 if any check fails.
@@ -88,11 +89,37 @@ def audit(name, body):
             problems.append(f"line {i}: `{code}` touches v{sorted(touched)} while an asm ds_read (line {min(pending[r] for r in touched)}) is in flight")
     if scratch:
         problems.append(f"{len(scratch)} scratch access(es) inside the K loop, first: {scratch[0]}")
-    if len(compiler_waits) > 1 or any("lgkmcnt(0)" not in c for _, c in compiler_waits):
-        problems.append(f"compiler-inserted waits inside the K loop: {compiler_waits}")
+    # Round 6: the K loop is two inner loops (the STEADY copy and the general copy of gemm8p_ktile.inc) with once-per-tile
+    # code between them.  Allowed: ONE lgkmcnt(0) per inner loop (ours, at the top of every K tile) and lgkmcnt(0) waits in
+    # the once-per-tile code outside the inner loops; nothing else.
+    # the compiler's block comments say which loop a basic block belongs to: "=> This Inner Loop Header: Depth=2" on the header,
+    # "in Loop: Header=BBx_y Depth=2" on the other blocks of an inner loop, "Depth=1" on the once-per-tile code
+    def loop_of(line_no):
+        j = line_no
+        while j > 0 and not (re.match(r"^\.LBB\d+_\d+:", body[j]) or re.match(r"^; %bb\.\d+:", body[j])):
+            j -= 1
+        head = body[j:j + 5]
+        lab = re.match(r"^\.(LBB\d+_\d+):", body[j])
+        for h in head[:4] if lab else head[:3]:
+            if "Inner Loop Header" in h and lab:
+                return lab.group(1)[1:]
+            m = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", h)
+            if m:
+                return m.group(1) if int(m.group(2)) >= 2 else None
+            if h is not head[0] and (re.match(r"^\.LBB\d+_\d+:", h) or not h.lstrip().startswith(";")):
+                break
+        return None
+    per_loop = {}
+    for i, _ in compiler_waits:
+        lp = loop_of(i)
+        if lp is not None:
+            per_loop[lp] = per_loop.get(lp, 0) + 1
+    loops = sorted(per_loop)
+    if any(n > 1 for n in per_loop.values()) or any("lgkmcnt(0)" not in c for _, c in compiler_waits):
+        problems.append(f"compiler-inserted waits inside the K loop: {compiler_waits} (per inner loop: {per_loop})")
     if foreign_vm:
         problems.append(f"compiler-inserted vmcnt waits inside the K loop: {foreign_vm}")
-    info = {"k_loop_lines": hi - hdr + 1, "mfma": len(mf), "compiler_waits": [c for _, c in compiler_waits]}
+    info = {"k_loop_lines": hi - hdr + 1, "mfma": len(mf), "inner_loops": len(loops), "compiler_waits": [c for _, c in compiler_waits]}
     return problems, info
 
 
