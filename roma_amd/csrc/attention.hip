@@ -318,20 +318,13 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_h16_v2_kernel(cons
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = EXP2 ? __builtin_amdgcn_exp2f(s[kt][r]) : __expf(s[kt][r]);
-    {  // row sums: four independent chains (one 32-deep chain of dependent adds is ~1.7 x slower to issue), carried as two
-       // register PAIRS and added with v_pk_add_f32 (round 6: 14 issue slots instead of 36 - the loop is bound by its VALU
-       // issue, 32 v_exp + ~100 other instructions per tile against 16 MFMAs; every operand is a VGPR pair, so the SGPR
-       // hazard that keeps packed f32 out of this file cannot occur: tools/audit_pk_sgpr.py)
-      typedef float attn_f32x2 __attribute__((ext_vector_type(2)));
-      attn_f32x2 ls2[2] = {attn_f32x2{s[0][0], s[0][1]}, attn_f32x2{s[0][2], s[0][3]}};
+    {  // row sums: four independent chains (one 32-deep chain of dependent adds is ~1.7 x slower to issue)
+      float ls[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int i = (kt == 0 ? 2 : 0); i < 8; ++i) {
-          const attn_f32x2 pr = {s[kt][2 * i], s[kt][2 * i + 1]};
-          asm("v_pk_add_f32 %0, %1, %2" : "=v"(ls2[i & 1]) : "v"(ls2[i & 1]), "v"(pr));
-        }
-      l_run += (ls2[0][0] + ls2[0][1]) + (ls2[1][0] + ls2[1][1]);
+        for (int r = 0; r < 16; ++r) ls[r & 3] += s[kt][r];
+      l_run += (ls[0] + ls[1]) + (ls[2] + ls[3]);
     }
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
