@@ -198,74 +198,74 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const ConvPatchAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int tap = 0, slab = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-      const unsigned cb = kt & 1u, pb = slab & 1u;
-      const unsigned wb = lds0 + WOFF + cb * WBUF;
-      const unsigned pbase = lds0 + pb * PATCH;
-      const bool w1 = kt + 1 < nkt, w2 = kt + 2 < nkt;
-      const bool pnow = tap < 3 && slab + 1 < nslab;  // this tap carries two pieces of the next slab's patch
-      // tap (dy, dx) = (tap / 3 - 1, tap % 3 - 1): an offset of dy * PW + dx patch rows
-      const int dy = (tap * 11) >> 5;  // tap / 3 for tap < 9
-      const int toff = ((dy - 1) * PW + (tap - 3 * dy) - 1) * ROWB;
-      // Nothing of this wave is outstanding on LGKM here (P4 reads nothing new after its wait): say so in a form the compiler sees
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-      // fragment addresses of the row half 0 blocks (kept until P4): row = prow + toff, chunk h ^ ((row >> 1) & 7)
-      unsigned a00, a01, a10, a11;
-#define CP_ADDR(DST, PROW)                                                           \
-  {                                                                                  \
-    const unsigned rb_ = (PROW) + (unsigned)toff; /* row * 128 */                    \
-    DST = pbase + rb_ + ((((rb_ >> 8) & 7u) ^ (unsigned)h) << 4);                    \
-  }
-      CP_ADDR(a00, prow[0][0]) CP_ADDR(a01, prow[0][1])
-      // P1: W halves 0 / 1 and rows 0 of k-pair 0
-      CPK_READ_W(fw0, 0, 0, wb)
-      CPK_READ_W(fw1, 1, 0, wb)
-      __builtin_amdgcn_sched_barrier(0);
-      CPK_READ_A(a00, a01, 0)
-      if (w1) CP_ISSUE_W(1, kt + 1, cb ^ 1u)
-      CPK_PHASE(CPK_WAIT_AWW(fw0, fw1), CPK_MFMA(0, fw0, fw1))
-      // P2: rows 1 of k-pair 0 (+ W half 0 of k-pair 1)
-      CP_ADDR(a10, prow[1][0]) CP_ADDR(a11, prow[1][1])
-      CPK_READ_A(a10, a11, 0)
-      CPK_READ_W(fw0n, 0, 1, wb)
-      if (pnow) {
-        if (tap == 0) CP_ISSUE_P(0, slab + 1, pb ^ 1u)
-        else if (tap == 1) CP_ISSUE_P(2, slab + 1, pb ^ 1u)
-        else CP_ISSUE_P(4, slab + 1, pb ^ 1u)
+    // Round 6: the K loop by slab - the nine taps of every slab but the last as nine STEADY copies of the body with the tap a
+    // constant, the last slab on the general copy (conv_patch_ktile.inc).  The single loop carried ~25 branches per K tile.
+    int kt = 0, slab = 0;
+#define CP_STEADY 1
+    for (; slab + 1 < nslab; ++slab) {
+      {
+#define CP_TAP 0
+#include "conv_patch_ktile.inc"
+#undef CP_TAP
       }
-      CPK_PHASE(CPK_WAIT_AW(fw0n), CPK_MFMA(1, fw0, fw1))
-      // P3: rows 1 of k-pair 1 (+ W half 1 of k-pair 1)
-      CPK_READ_A(a10, a11, 1)
-      CPK_READ_W(fw1n, 1, 1, wb)
-      if (pnow) {
-        if (tap == 0) CP_ISSUE_P(1, slab + 1, pb ^ 1u)
-        else if (tap == 1) CP_ISSUE_P(3, slab + 1, pb ^ 1u)
-        else CP_ISSUE_P(5, slab + 1, pb ^ 1u)
+      ++kt;
+      {
+#define CP_TAP 1
+#include "conv_patch_ktile.inc"
+#undef CP_TAP
       }
-      CPK_PHASE(CPK_WAIT_AW(fw1n), CPK_MFMA(1, fw0n, fw1n))
-      // P4: rows 0 of k-pair 1; W half 0 of K tile kt + 2; all of K tile kt + 1's weights landed before the first barrier
-      CPK_READ_A(a00, a01, 1)
-      if (w2) CP_ISSUE_W(0, kt + 2, cb)
-      if (w2) {
-        if (pnow) {
-          CP_WAIT_VM(4);
-        } else {
-          CP_WAIT_VM(2);
-        }
-      } else {
-        if (pnow) {
-          CP_WAIT_VM(2);
-        } else {
-          CP_WAIT_VM(0);
-        }
+      ++kt;
+      {
+#define CP_TAP 2
+#include "conv_patch_ktile.inc"
+#undef CP_TAP
       }
-      CPK_PHASE(CPK_WAIT_A(), CPK_MFMA(0, fw0n, fw1n))
-      if (++tap == 9) {
-        tap = 0;
-        ++slab;
+      ++kt;
+      {
+#define CP_TAP 3
+#include "conv_patch_ktile.inc"
+#undef CP_TAP
       }
+      ++kt;
+      {
+#define CP_TAP 4
+#include "conv_patch_ktile.inc"
+#undef CP_TAP
+      }
+      ++kt;
+      {
+#define CP_TAP 5
+#include "conv_patch_ktile.inc"
+#undef CP_TAP
+      }
+      ++kt;
+      {
+#define CP_TAP 6
+#include "conv_patch_ktile.inc"
+#undef CP_TAP
+      }
+      ++kt;
+      {
+#define CP_TAP 7
+#include "conv_patch_ktile.inc"
+#undef CP_TAP
+      }
+      ++kt;
+      {
+#define CP_TAP 8
+#include "conv_patch_ktile.inc"
+#undef CP_TAP
+      }
+      ++kt;
     }
+#undef CP_STEADY
+#define CP_STEADY 0
+    for (int tap = 0; kt < nkt; ++kt, ++tap) {
+#define CP_TAP tap
+#include "conv_patch_ktile.inc"
+#undef CP_TAP
+    }
+#undef CP_STEADY
     if (wr == 0) __builtin_amdgcn_s_barrier();  // group 0 meets group 1's extra barrier: both groups are past every LDS read
 
     // ---- epilogue: bias + ReLU, staged through the patch buffer the last slab did NOT read (nobody touches it), whole 16-byte

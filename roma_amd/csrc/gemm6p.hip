@@ -139,8 +139,12 @@ __global__ __launch_bounds__(512, 2) void gemm6p_kernel(const GemmArgs a) {
   __builtin_amdgcn_s_barrier();                  \
   __builtin_amdgcn_sched_barrier(0);
 
+#ifdef ROMA_TOOLS_BUILD  // A/B switches of tools builds: no s_setprio around the MFMA blocks / no wave-group stagger
   const bool prio = !(a.dbg & 64);
   const bool stagger = !(a.dbg & 128);
+#else  // shipped libraries: constants, so that the K loop carries no branch around its s_setprio pairs
+  constexpr bool prio = true, stagger = true;
+#endif
 
   // tile coordinates advance incrementally (one scalar division pair here, none per tile)
   int c_tm = (int)(((long)xcd * per_xcd + li) / NT), c_tn = (int)(((long)xcd * per_xcd + li) % NT);
@@ -179,47 +183,17 @@ __global__ __launch_bounds__(512, 2) void gemm6p_kernel(const GemmArgs a) {
     // tile); rebuilt rather than carried across the epilogue (gemm8p.hip)
     if (gk != 0) R6_TILE_SETUP(c_tm, c_tn)
 
-    for (int kt = 0; kt < nk; ++kt, ++gk) {
-      const unsigned cb = gk & 1u;
-      const unsigned sb = lds0 + cb * BUF;
-      // stream positions s+1 (P1, P2) and s+2 (P3): inside this tile, or the head of the next one
-      const bool in1 = kt + 1 < nk, in2 = kt + 2 < nk;
-      const bool n1 = in1 || has_next, n2 = in2 || has_next;
-      const int k1 = in1 ? kt + 1 : 0, k2 = in2 ? kt + 2 : kt + 2 - nk;
-      // nothing of this wave is outstanding on LGKM here; saying so in a form the compiler sees keeps its loop-carried
-      // bookkeeping (the epilogue's own LDS reads) from dropping an s_waitcnt between the asm fragment reads below
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-      // P1: A + W0 -> block 0; stage A pieces 2,3 of s+1; W1(s) must have landed before P2's reads
-      R6_READ_W(bf0, 0, sb)
-      __builtin_amdgcn_sched_barrier(0);
-      R6_READ_A(sb)
-      if (n1) {
-        R6_ISSUE_A(2, k1, cb ^ 1u) R6_ISSUE_A(3, k1, cb ^ 1u)
-        R6_WAIT_VM(6);
-      } else {
-        R6_WAIT_VM(0);
-      }
-      R6_PHASE(R6_WAIT_LGKM_AW(bf0), R6_MFMA(0, bf0))
-      // P2: W1 -> block 1; stage W1, W2 of s+1; W2(s) must have landed before P3's reads
-      R6_READ_W(bf1, 1, sb)
-      if (n1) {
-        R6_ISSUE_W(1, k1, cb ^ 1u) R6_ISSUE_W(2, k1, cb ^ 1u)
-        R6_WAIT_VM(7);
-      } else {
-        R6_WAIT_VM(0);
-      }
-      R6_PHASE(R6_WAIT_LGKM_W(bf1), R6_MFMA(1, bf1))
-      // P3: W2 -> block 2; stage A pieces 0,1 and W0 of s+2 (the stream enters the next output tile here when
-      // kt == nk - 2); all of A(s+1), W0(s+1) must have landed before the next P1's reads
-      R6_READ_W(bf0, 2, sb)
-      if (in1 && !in2 && has_next) R6_TILE_SETUP(n_tm, n_tn)
-      if (n2) {
-        R6_ISSUE_A(0, k2, cb) R6_ISSUE_A(1, k2, cb) R6_ISSUE_W(0, k2, cb)
-        R6_WAIT_VM(5);
-      } else {
-        R6_WAIT_VM(0);
-      }
-      R6_PHASE(R6_WAIT_LGKM_W(bf0), R6_MFMA(2, bf0))
+    // Round 6: K tiles with kt + 2 < nk run the STEADY copy of the body, the last two of every output tile the general one
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt, ++gk) {
+#define R6_STEADY 1
+#include "gemm6p_ktile.inc"
+#undef R6_STEADY
+    }
+    for (; kt < nk; ++kt, ++gk) {
+#define R6_STEADY 0
+#include "gemm6p_ktile.inc"
+#undef R6_STEADY
     }
     li = li_next;
     c_tm = n_tm;
