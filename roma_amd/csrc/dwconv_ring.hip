@@ -51,18 +51,28 @@ __device__ __forceinline__ void dwr_glds16(const char* src, lds_u8* lds_wave_bas
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (ROMA_LDS void*)lds_wave_base, 16, 0, 0);
 }
 
-// one input row t: read it from the ring, feed the five rolling output rows (acc[k] = output row t - 4 + k, tap row
-// ky = 4 - k), finish and store row t - 4, rotate
-__device__ __forceinline__ void dwr_row(f32x2 (&acc)[5][4][2], const f32x4 (&wreg)[25], f32x2 bias0, f32x2 bias1, unsigned rd,
-                                        bool store, bf16_t* orow, long Cp, int npx) {
-  unsigned long long cr[8];
+// Round 6: the ring reads of input row t + 1 are issued BEFORE the 200 FMAs of row t and waited for behind them (`cr` is
+// written asynchronously by the inline-asm reads: nothing may touch it between dwr_read and dwr_wait - tools/audit_asm_reads.py).
+// Until then every row opened with 8 reads + s_waitcnt lgkmcnt(0): an LDS round trip per row that only one other wave of the
+// SIMD could cover.
+__device__ __forceinline__ void dwr_read(unsigned long long (&cr)[8], unsigned rd) {
   asm volatile(
       "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:128\n\tds_read_b64 %2, %8 offset:256\n\t"
       "ds_read_b64 %3, %8 offset:384\n\tds_read_b64 %4, %8 offset:640\n\tds_read_b64 %5, %8 offset:768\n\t"
-      "ds_read_b64 %6, %8 offset:896\n\tds_read_b64 %7, %8 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+      "ds_read_b64 %6, %8 offset:896\n\tds_read_b64 %7, %8 offset:1024"
       : "=&v"(cr[0]), "=&v"(cr[1]), "=&v"(cr[2]), "=&v"(cr[3]), "=&v"(cr[4]), "=&v"(cr[5]), "=&v"(cr[6]), "=&v"(cr[7])
       : "v"(rd)
       : "memory");
+}
+__device__ __forceinline__ void dwr_wait(unsigned long long (&cr)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(cr[0]), "+v"(cr[1]), "+v"(cr[2]), "+v"(cr[3]), "+v"(cr[4]), "+v"(cr[5]), "+v"(cr[6]), "+v"(cr[7])::"memory");
+}
+
+// one input row t (already in `cr`): convert, start the reads of row t + 1 (ring address rd_next) into `cr`, feed the five
+// rolling output rows (acc[k] = output row t - 4 + k, tap row ky = 4 - k), finish and store row t - 4 at `orow`, rotate
+__device__ __forceinline__ void dwr_row(f32x2 (&acc)[5][4][2], const f32x4 (&wreg)[25], f32x2 bias0, f32x2 bias1,
+                                        unsigned long long (&cr)[8], unsigned rd_next, bool store, bf16_t* orow, long Cp, int npx) {
   f32x2 v[8][2];
 #define ROMA_DWR_CVT(J)                                                  \
   {                                                                      \
@@ -70,10 +80,13 @@ __device__ __forceinline__ void dwr_row(f32x2 (&acc)[5][4][2], const f32x4 (&wre
     v[J][0] = f32x2{h16_lo(lo_), h16_hi(lo_)};                           \
     v[J][1] = f32x2{h16_lo(hi_), h16_hi(hi_)};                           \
   }
-  ROMA_DWR_CVT(0) ROMA_DWR_CVT(1) ROMA_DWR_CVT(2)
+  ROMA_DWR_CVT(0) ROMA_DWR_CVT(1) ROMA_DWR_CVT(2) ROMA_DWR_CVT(3) ROMA_DWR_CVT(4) ROMA_DWR_CVT(5) ROMA_DWR_CVT(6) ROMA_DWR_CVT(7)
+#undef ROMA_DWR_CVT
+#pragma unroll
+  for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j][0]), "+v"(v[j][1]));  // the conversions are done HERE: cr is free
+  dwr_read(cr, rd_next);
 #pragma unroll
   for (int kx = 0; kx < 5; ++kx) {
-    ROMA_DWR_CVT(kx + 3)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -87,7 +100,6 @@ __device__ __forceinline__ void dwr_row(f32x2 (&acc)[5][4][2], const f32x4 (&wre
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-#undef ROMA_DWR_CVT
   if (store) {
 #pragma unroll
     for (int px = 0; px < 4; ++px) {
@@ -106,6 +118,7 @@ __device__ __forceinline__ void dwr_row(f32x2 (&acc)[5][4][2], const f32x4 (&wre
       acc[k][px][0] = acc[k + 1][px][0];
       acc[k][px][1] = acc[k + 1][px][1];
     }
+  dwr_wait(cr);
 }
 
 __global__ __launch_bounds__(256, 2) void dwconv5x5_ring_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
@@ -155,23 +168,37 @@ __global__ __launch_bounds__(256, 2) void dwconv5x5_ring_kernel(const bf16_t* __
   // stays empty), 16-byte part p & 7 of the pixel's 128-byte channel line
   const char* zsrc = reinterpret_cast<const char*>(g_dwr_zero_page);
   const char* inb = reinterpret_cast<const char*>(in + ((long)b * H * W) * Cp) + (long)chunk * 128;
-  unsigned poff[3];  // byte offset inside an image row (< 2^31: checked by the launcher)
-  bool pok[3];
+  // Round 6: every lane carries the 64-bit source pointer of its three pieces for the NEXT in-image row and advances it by the
+  // row pitch when such a row is issued (lanes whose piece is an empty slot or lies outside the image in x keep pointing at
+  // the zero page: increment 0); rows above / below the image take the zero page for every lane behind a wave-uniform
+  // branch.  Until then each row rebuilt `row base + offset`, selected it against the zero page per lane (8 v_cndmask + 4
+  // v_mov per row) and multiplied the row index out in 64 bits.
+  const long pitch = (long)W * Cp * 2;  // (< 2^31: checked by the launcher)
+  const char* pptr[3];
+  unsigned pinc[3];
+  {
+    const int yy0 = max(ys - 2, 0);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int p = 64 * i + lane, s = p >> 3, part = p & 7;
-    const int x = x0 + s - s / 5;
-    pok[i] = (s % 5 != 4) && x >= 0 && x < W;
-    poff[i] = (unsigned)((pok[i] ? x : 0) * Cp * 2 + part * 16);
+    for (int i = 0; i < 3; ++i) {
+      const int p = 64 * i + lane, s = p >> 3, part = p & 7;
+      const int x = x0 + s - s / 5;
+      const bool ok = (s % 5 != 4) && x >= 0 && x < W;
+      pptr[i] = ok ? inb + (long)yy0 * pitch + (long)x * Cp * 2 + part * 16 : zsrc;
+      pinc[i] = ok ? (unsigned)pitch : 0u;
+    }
   }
   lds_u8* const myring = (lds_u8*)ring + wv * (NR * DWR_ROWB);
 #define ROMA_DWR_ISSUE(RROW, SLOT)                                                         \
   {                                                                                        \
     const int yy_ = ys - 2 + (RROW);                                                       \
-    const bool rok_ = (RROW) < T && yy_ >= 0 && yy_ < H;                                   \
-    const char* rb_ = inb + (long)(rok_ ? yy_ : 0) * W * Cp * 2;                           \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i)                                          \
-        dwr_glds16((rok_ && pok[i]) ? rb_ + poff[i] : zsrc, myring + (SLOT) * DWR_ROWB + i * 1024); \
+    if ((RROW) < T && yy_ >= 0 && yy_ < H) { /* wave-uniform */                            \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                      \
+        dwr_glds16(pptr[i], myring + (SLOT) * DWR_ROWB + i * 1024);                        \
+        pptr[i] += pinc[i];                                                                \
+      }                                                                                    \
+    } else {                                                                               \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) dwr_glds16(zsrc, myring + (SLOT) * DWR_ROWB + i * 1024); \
+    }                                                                                      \
   }
 
   f32x2 acc[5][4][2];
@@ -186,28 +213,36 @@ __global__ __launch_bounds__(256, 2) void dwconv5x5_ring_kernel(const bf16_t* __
   const unsigned rd0 = ring_lds + (unsigned)(xq * 5 * 128 + cg * 8);
   bf16_t* const obase = out + ((long)b * H * W) * Cp + c;
 
-  // ---- prologue: rows 0 .. NR - 2 in flight
+  // ---- prologue: rows 0 .. NR - 2 in flight, row 0 in registers
 #pragma unroll
   for (int rr = 0; rr < NR - 1; ++rr) ROMA_DWR_ISSUE(rr, rr);
+  unsigned long long cr[8];
+  ROMA_DWR_WAIT_VM(3 * (NR - 2));  // row 0 has landed: only rows 1 .. NR - 2 may be outstanding
+  dwr_read(cr, rd0);
+  dwr_wait(cr);
 
-  int slot = 0;       // ring slot of input row t
+  int slot1 = 1;      // ring slot of input row t + 1
   int fill = NR - 1;  // ring slot the next DMA goes to (= slot of row t - 1)
-  // Row t has landed once at most the DMA issued AFTER it is outstanding: rows t + 1 .. t + NR - 1, 3 pieces each.  The output
-  // stores of the last iterations are younger than that DMA too, but they may NOT be added to the allowance: vmcnt counts
-  // loads and stores in one counter, loads retire in order among themselves and so do stores, but a store can retire before
-  // an OLDER load - with an allowance of 3 (NR - 1) + 4 k a wave whose young stores were acknowledged early would pass the
-  // wait with row t still in flight and read the slot's previous row (seen as 1-in-1000 one-ulp patches in the two-stream
-  // stress, profiles/r03_v20_determinism_stress.log).  With the allowance equal to the number of younger LOADS the wait is
-  // exact: if row t were outstanding, so would be all 3 (NR - 1) younger pieces.
+  // Row t + 1 is read from the ring during row t's FMAs, so it must have landed here: at most the DMA issued AFTER it may be
+  // outstanding - rows t + 2 .. t + NR - 1, 3 pieces each.  The output stores of the last iterations are younger than that DMA
+  // too, but they may NOT be added to the allowance: vmcnt counts loads and stores in one counter, loads retire in order among
+  // themselves and so do stores, but a store can retire before an OLDER load - with an allowance of 3 (NR - 2) + 4 k a wave
+  // whose young stores were acknowledged early would pass the wait with row t + 1 still in flight and read the slot's previous
+  // row (seen as 1-in-1000 one-ulp patches in the two-stream stress, profiles/r03_v20_determinism_stress.log).  With the
+  // allowance equal to the number of younger LOADS the wait is exact: if row t + 1 were outstanding, so would be all
+  // 3 (NR - 2) younger pieces.  (Past the strip's last row the read returns a stale slot that nobody uses.)
+  // The output row pointer advances by one image row per stored row (round 6: it was rebuilt from 64-bit products per row).
+  bf16_t* orow = obase + ((long)ys * W + xb) * Cp;
+  const long orow_step = (long)W * Cp;
 #pragma nounroll
   for (int t = 0; t < T; ++t) {
     ROMA_DWR_ISSUE(t + NR - 1, fill);
-    ROMA_DWR_WAIT_VM(3 * (NR - 1));
-    const int o = t - 4;
-    dwr_row(acc, wreg, bias0, bias1, rd0 + (unsigned)slot * DWR_ROWB, o >= 0 && npx > 0,
-            obase + ((long)(ys + max(o, 0)) * W + xb) * Cp, (long)Cp, npx);
-    fill = slot;
-    slot = slot + 1 == NR ? 0 : slot + 1;
+    ROMA_DWR_WAIT_VM(3 * (NR - 2));
+    const bool st = t >= 4;
+    dwr_row(acc, wreg, bias0, bias1, cr, rd0 + (unsigned)slot1 * DWR_ROWB, st && npx > 0, orow, (long)Cp, npx);
+    if (st) orow += orow_step;
+    fill = fill + 1 == NR ? 0 : fill + 1;
+    slot1 = slot1 + 1 == NR ? 0 : slot1 + 1;
   }
 #undef ROMA_DWR_ISSUE
   ROMA_DWR_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation

@@ -60,6 +60,11 @@ __global__ __launch_bounds__(384, 2) void ws1x1_kernel(const bf16_t* __restrict_
                                                        long chunks_per_stream, int streams_per_xcd, int dbg) {
   // dbg (roma_tuning "ws1x1" bits, measurements only): 2 = no output stores, 4 = no DMA after the first three chunks, 8 = no MFMA
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // [4 slots][32 px][1152 B], then bias f32[576]
+#ifdef ROMA_TOOLS_BUILD
+  const int dbg_ = dbg;
+#else
+  constexpr int dbg_ = 0;  // the ablation bits exist in tools builds only (make TOOLS=1)
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(384, 2) void ws1x1_kernel(const bf16_t* __restrict_
                  : "=&v"(q0_), "=&v"(q1_)                                                                             \
                  : "v"(tr0), "v"(tr1)                                                                                 \
                  : "memory");                                                                                         \
-    if (!(dbg & 2)) {                                                                                                 \
+    if (!(dbg_ & 2)) {                                                                                                \
       char* cb_ = reinterpret_cast<char*>(C) + out_chunk * (long)(WS_PX * WS_N * 2);                                  \
       asm volatile("global_store_dwordx4 %0, %2, off\n\tglobal_store_dwordx4 %1, %3, off\n\ts_nop 1"                 \
                    :                                                                                                  \
@@ -169,72 +174,17 @@ __global__ __launch_bounds__(384, 2) void ws1x1_kernel(const bf16_t* __restrict_
       for (int i = 0; i < 6; ++i) WS_ISSUE_PIECE(i, st0 + k)
     }
 
-  for (long c = st0; c < end0; ++c) {
-    // chunk c has landed once at most the younger LOADS are outstanding: the pieces of chunks c + 1, c + 2 that exist (the
-    // two stores of the step before are older than the pieces of c + 2 and younger than those of c + 1: they only make the
-    // wait more conservative - a younger store must never be part of the allowance, dwconv_ring.hip)
-    const long ahead = (dbg & 4) ? 0 : std::min(end0 - 1 - c, 2l);
-    if (ahead >= 2) {
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    } else if (ahead == 1) {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    // the outputs of chunk c - 1: every wave is past its last read of that chunk, so the DMA of chunk c + 3 may overwrite its
-    // ring slot - it is issued between the MFMAs below
-    if (out_chunk >= 0) WS_STORE_OUT()  // (out_chunk is workgroup-uniform: every wave takes the same barriers)
-    const unsigned sb = (unsigned)((int)(c & 3) * WS_SLOT);
-    const bool more = c + 3 < end0 && !(dbg & 4);  // wave-uniform
-    const bool domf = !(dbg & 8);
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) WS_READ(sb, ks);
-#pragma unroll
-    for (int ks = 0; ks < 36; ++ks) {
-      if (ks + 3 < 36) WS_READ(sb, ks + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ks + 3 < 36) { WS_WAIT1(ks, 3); }
-      else if (ks + 2 < 36) { WS_WAIT1(ks, 2); }
-      else if (ks + 1 < 36) { WS_WAIT1(ks, 1); }
-      else { WS_WAIT1(ks, 0); }
-      __builtin_amdgcn_sched_barrier(0);
-      if (domf) acc = mfma_h16_32x32x16(wreg[ks], fa[ks & 3], acc);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ks % 6 == 2 && more) WS_ISSUE_PIECE(ks / 6, c + 3)  // one DMA piece per six k-steps
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // bias + activation + pack + half-wave exchange: lane (l31, h) ends up with couts 32 nb + 16 P + 8 h + [0, 8) of pixel l31
-#pragma unroll
-    for (int P = 0; P < 2; ++P) {
-      f32x4 bv0, bv1;
-      {
-        const unsigned ba = lds0 + WS_LDS + (32 * nb + 16 * P + 4 * h) * 4;
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(bv0), "=&v"(bv1)
-                     : "v"(ba)
-                     : "memory");
-      }
-      float e[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        e[q] = acc[8 * P + q] + bv0[q];
-        e[4 + q] = acc[8 * P + 4 + q] + bv1[q];
-      }
-      if (ACT == ACT_RELU) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) e[q] = fmaxf(e[q], 0.f);
-      }
-      const unsigned a0 = pack_bf16x2(e[0], e[1]), a1 = pack_bf16x2(e[2], e[3]);
-      const unsigned b0 = pack_bf16x2(e[4], e[5]), b1 = pack_bf16x2(e[6], e[7]);
-      const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-      const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-      outp[P] = u32x4{s0[0], s1[0], s0[1], s1[1]};
-    }
-    out_chunk = c;
+  // Round 6: steps with the ring full run the STEADY copy of the body, the last three the general one (ws1x1_step.inc)
+  long c = st0;
+  for (; c + 3 < end0 && !(dbg_ & 4); ++c) {
+#define WS_STEADY 1
+#include "ws1x1_step.inc"
+#undef WS_STEADY
+  }
+  for (; c < end0; ++c) {
+#define WS_STEADY 0
+#include "ws1x1_step.inc"
+#undef WS_STEADY
   }
   // the outputs of the last step
   if (out_chunk >= 0) {
@@ -287,6 +237,9 @@ int ws1x1_try_launch(const GemmArgs& a, hipStream_t stream) {
   if (a.M % WS_PX != 0 || a.M < 64 * 1024) return 1;  // whole 32-pixel chunks; small problems stay on the tile kernels
   if (((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.C) | reinterpret_cast<uintptr_t>(a.W)) & 15) != 0) return 1;
   if (a.dbg & 0x3ff) return 1;  // tuning experiments address the tile kernels
+#ifndef ROMA_TOOLS_BUILD
+  ROMA_REQUIRE(!(ws_mode() & ~1), "ws1x1: the ablation bits (2 / 4 / 8 of roma_tuning ws1x1) exist in tools builds only (make TOOLS=1)");
+#endif
   if (a.act == ACT_RELU) return launch_ws<ACT_RELU>(a, stream);
   return launch_ws<ACT_NONE>(a, stream);
 }
