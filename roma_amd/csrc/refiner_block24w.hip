@@ -162,24 +162,36 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
   // ---- DMA descriptors: piece k = 64 i + lane of a row; 13 pieces per 4 pixels (12 data + 1 gap)
   const char* zsrc = reinterpret_cast<const char*>(g_rbw_zero_page);
   const char* inb = reinterpret_cast<const char*>(in + ((long)b * H * W) * CP);
-  unsigned poff[3];
-  bool pok[3];
+  // Round 6 (dwconv_ring.hip): every lane carries the source pointer of its three pieces for the next in-image row and
+  // advances it by the row pitch (increment 0 for gap / out-of-image pieces, which keep pointing at the zero page); rows above
+  // / below the image take the zero page behind a wave-uniform branch.  No per-row selects, no 64-bit row products.
+  const long pitch = (long)W * CP * 2;  // (< 2^31: checked by the launcher)
+  const char* pptr[3];
+  unsigned pinc[3];
+  {
+    const int yy0 = max(ys - 2, 0);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int k = 64 * i + lane, g13 = k / 13, r13 = k - g13 * 13;
-    const int p = 4 * g13 + r13 / 3, part = r13 % 3;
-    const int x = x0 + p;
-    pok[i] = r13 != 12 && p < RBW_PXW + 4 && x >= 0 && x < W;
-    poff[i] = (unsigned)((pok[i] ? x : 0) * CP * 2 + part * 16);
+    for (int i = 0; i < 3; ++i) {
+      const int k = 64 * i + lane, g13 = k / 13, r13 = k - g13 * 13;
+      const int p = 4 * g13 + r13 / 3, part = r13 % 3;
+      const int x = x0 + p;
+      const bool ok = r13 != 12 && p < RBW_PXW + 4 && x >= 0 && x < W;
+      pptr[i] = ok ? inb + (long)yy0 * pitch + (long)x * CP * 2 + part * 16 : zsrc;
+      pinc[i] = ok ? (unsigned)pitch : 0u;
+    }
   }
   lds_u8* const myring = (lds_u8*)ring + wv * (NR * RBW_ROWB);
 #define ROMA_RBW_ISSUE(RROW, SLOT)                                                                  \
   {                                                                                                 \
     const int yy_ = ys - 2 + (RROW);                                                                \
-    const bool rok_ = (RROW) < T && yy_ >= 0 && yy_ < H;                                            \
-    const char* rb_ = inb + (long)(rok_ ? yy_ : 0) * W * CP * 2;                                    \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                   \
-        rbw_glds16((rok_ && pok[i]) ? rb_ + poff[i] : zsrc, myring + (SLOT) * RBW_ROWB + i * 1024); \
+    if ((RROW) < T && yy_ >= 0 && yy_ < H) { /* wave-uniform */                                     \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                               \
+        rbw_glds16(pptr[i], myring + (SLOT) * RBW_ROWB + i * 1024);                                 \
+        pptr[i] += pinc[i];                                                                         \
+      }                                                                                             \
+    } else {                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) rbw_glds16(zsrc, myring + (SLOT) * RBW_ROWB + i * 1024); \
+    }                                                                                               \
   }
 
   const f32x4 bx = *(lds_f32x4*)(wsm + 25 * CP + c);
@@ -204,24 +216,38 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
 #pragma unroll
   for (int rr = 0; rr < NR - 1; ++rr) ROMA_RBW_ISSUE(rr, rr);
 
-  int slot = 0, fill = NR - 1;
-  // Row t has landed once at most the DMA issued AFTER it is outstanding: rows t + 1 .. t + NR - 1, 3 pieces each.  (The
-  // younger output stores must not be added to the allowance - a store can retire before an older load: dwconv_ring.hip.)
+  // Round 6: the ring reads of input row t + 1 are issued behind row t's MFMAs (the converted row and the MFMA operands are
+  // dead by then - issued behind the FMAs, next to the 32 output accumulators, they spilled) and waited for at the top of the
+  // next iteration: the packing and the stores of row t cover the LDS round trip that used to open every row.  `cr` is written asynchronously: nothing may touch it between the read and
+  // the wait (tools/audit_asm_reads.py).
+  unsigned long long cr[8];
+#define ROMA_RBW_READ(RA)                                                                                              \
+  asm volatile(                                                                                                        \
+      "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:48\n\tds_read_b64 %2, %8 offset:96\n\t"                   \
+      "ds_read_b64 %3, %8 offset:144\n\tds_read_b64 %4, %8 offset:208\n\tds_read_b64 %5, %8 offset:256\n\t"      \
+      "ds_read_b64 %6, %8 offset:304\n\tds_read_b64 %7, %8 offset:352"                                               \
+      : "=&v"(cr[0]), "=&v"(cr[1]), "=&v"(cr[2]), "=&v"(cr[3]), "=&v"(cr[4]), "=&v"(cr[5]), "=&v"(cr[6]), "=&v"(cr[7]) \
+      : "v"(RA)                                                                                                        \
+      : "memory")
+#define ROMA_RBW_READ_WAIT()                                                                                           \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                  \
+               : "+v"(cr[0]), "+v"(cr[1]), "+v"(cr[2]), "+v"(cr[3]), "+v"(cr[4]), "+v"(cr[5]), "+v"(cr[6]), "+v"(cr[7])::"memory")
+  ROMA_RBW_WAIT_VM(3 * (NR - 2));  // row 0 has landed: only rows 1 .. NR - 2 may be outstanding
+  ROMA_RBW_READ(rd0);
+
+  int slot1 = 1, fill = NR - 1;  // ring slot of input row t + 1; slot the next DMA goes to (= slot of row t - 1)
+  // Row t + 1 is read during iteration t, so it must have landed here: at most the DMA issued AFTER it may be outstanding -
+  // rows t + 2 .. t + NR - 1, 3 pieces each.  (The younger output stores must not be added to the allowance - a store can
+  // retire before an older load: dwconv_ring.hip.)  The output row pointer advances by one image row per finished row.
+  char* orow_g = reinterpret_cast<char*>(obase + ((long)ys * W + xw0) * CP);
+  const long orow_step = (long)W * CP * 2;
 #pragma nounroll
   for (int t = 0; t < T; ++t) {
     ROMA_RBW_ISSUE(t + NR - 1, fill);
-    ROMA_RBW_WAIT_VM(3 * (NR - 1));
+    ROMA_RBW_WAIT_VM(3 * (NR - 2));
     const int o = t - 4;  // output row (relative to ys) finished by input row t
+    ROMA_RBW_READ_WAIT();
     if (active) {
-      unsigned long long cr[8];
-      const unsigned ra = rd0 + (unsigned)slot * RBW_ROWB;
-      asm volatile(
-          "ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:48\n\tds_read_b64 %2, %8 offset:96\n\t"
-          "ds_read_b64 %3, %8 offset:144\n\tds_read_b64 %4, %8 offset:208\n\tds_read_b64 %5, %8 offset:256\n\t"
-          "ds_read_b64 %6, %8 offset:304\n\tds_read_b64 %7, %8 offset:352\n\ts_waitcnt lgkmcnt(0)"
-          : "=&v"(cr[0]), "=&v"(cr[1]), "=&v"(cr[2]), "=&v"(cr[3]), "=&v"(cr[4]), "=&v"(cr[5]), "=&v"(cr[6]), "=&v"(cr[7])
-          : "v"(ra)
-          : "memory");
 #define ROMA_RBW_CVT(J)                                                  \
   {                                                                      \
     const uint32_t lo_ = (uint32_t)cr[J], hi_ = (uint32_t)(cr[J] >> 32); \
@@ -287,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
           oa[u] = mfma_h16_32x32x16(wA[ks], xf, oa[u]);
         }
       }
+      ROMA_RBW_READ(rd0 + (unsigned)slot1 * RBW_ROWB);  // row t + 1 (past the strip's last row: a stale slot nobody uses)
       if constexpr (FINAL) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -301,7 +328,6 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
         // 32-63 of a with lanes 0-31 of b: for (g = 0, g = 1) of one block lane (l31, hh) ends up with the 8 consecutive
         // channels 8 hh + [0, 8) of its pixel; for g = 2 of BOTH blocks the lower half-wave gets channels 16 .. 23 of pixel l31,
         // the upper one those of pixel 32 + l31 - i.e. of pixel `lane`.  Three 16-byte stores per lane and row.
-        char* const orow_g = reinterpret_cast<char*>(obase + ((long)(ys + o) * W + xw0) * CP);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const unsigned a0 = pack_bf16x2(oa[u][0], oa[u][1]), a1 = pack_bf16x2(oa[u][2], oa[u][3]);
@@ -319,10 +345,15 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
           if (lane < npw) *reinterpret_cast<u32x4_t*>(orow_g + lane * (CP * 2) + 32) = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
         }
       }
+    } else {
+      ROMA_RBW_READ(rd0 + (unsigned)slot1 * RBW_ROWB);
     }
-    fill = slot;
-    slot = slot + 1 == NR ? 0 : slot + 1;
+    if (!FINAL && o >= 0) orow_g += orow_step;
+    fill = fill + 1 == NR ? 0 : fill + 1;
+    slot1 = slot1 + 1 == NR ? 0 : slot1 + 1;
   }
+#undef ROMA_RBW_READ_WAIT
+#undef ROMA_RBW_READ
 #undef ROMA_RBW_ISSUE
   ROMA_RBW_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
 }
