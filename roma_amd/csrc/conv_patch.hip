@@ -119,6 +119,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const ConvPatchAr
     CP_DS_READ(fa[1][gl], (A1) ^ (unsigned)((2 * (GP) + gl) << 5));     \
   }
 
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w), 0, (int)((long)a.Cout * 9 * a.Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.in), 0, (int)((long)a.B * a.H * a.W * a.Cin * 2), 0x00020000);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     // ---- tile -> (image, patch row, patch column, cout tile)
     const int ni = tile % NT;
@@ -131,8 +133,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const ConvPatchAr
 
     // ---- DMA descriptors.  Weights: wave w stages pieces 2 w, 2 w + 1 of every 128-row half-tile (LDS row i of half hf is
     // cout n0 + (i >> 5) * 64 + hf * 32 + (i & 31)); lane -> (row r8 of the piece, 16-byte slot), slot holds chunk slot ^ ((i >> 1) & 7)
-    const char* w_src[2][2];
-    unsigned poff[6];  // patch piece wave + 8 j: byte offset of this lane's chunk from a.in (slab 0), 0xffffffff = zeros
+    // Round 6 (gemm8p.hip): both operands through buffer descriptors - SGPR base + 32-bit lane offset + SGPR slab / K offset;
+    // halo pixels outside the image carry an offset beyond num_records and read zeros in hardware
+    unsigned w_off[2][2];
+    unsigned poff[6];  // patch piece wave + 8 j: byte offset of this lane's chunk from a.in (slab 0), 0x80000000 = zeros
     unsigned prow[2][2];  // patch row (at the centre tap) of this lane's pixel in block (mh, mt), as a byte offset
     {
       int ln_ = lane;  // opaque: derived values are computed here, once per tile
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const ConvPatchAr
           const int i = 16 * wave + 8 * j + r8;
           const int chunk = slot ^ ((i >> 1) & 7);
           const int gn = n0 + (i >> 5) * 64 + hf * 32 + (i & 31);
-          w_src[hf][j] = reinterpret_cast<const char*>(a.w + (long)gn * (9 * a.Cin) + chunk * 8);
+          w_off[hf][j] = (unsigned)(((long)gn * (9 * a.Cin) + chunk * 8) * 2);
         }
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const ConvPatchAr
         const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
         const int chunk = slot ^ ((pr >> 1) & 7);
         const bool ok = pr < PR && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        poff[j] = ok ? (unsigned)(((((long)b * a.H + iy) * a.W + ix) * a.Cin) * 2 + chunk * 16) : 0xffffffffu;
+        poff[j] = ok ? (unsigned)(((((long)b * a.H + iy) * a.W + ix) * a.Cin) * 2 + chunk * 16) : 0x80000000u;
       }
       const int l31_ = ln_ & 31;
 #pragma unroll
@@ -166,20 +170,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const ConvPatchAr
           prow[mh][mt] = (unsigned)(((py + 1) * PW + px + 1) * ROWB);
         }
     }
-    const char* inb = reinterpret_cast<const char*>(a.in);
+#define CP_BL16(RS, VOFF, SOFF, DST) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, (int)(VOFF), (int)(SOFF), 0, 0)
 #define CP_ISSUE_W(HF, KT, BSEL)                                                                              \
   {                                                                                                           \
     char* dst_ = smem + WOFF + (BSEL) * WBUF + (HF) * 128 * ROWB + (2 * wave) * 1024;                         \
-    const long soff_ = (long)(KT) * (BK * 2);                                                                 \
-    glds16(w_src[HF][0] + soff_, dst_);                                                                       \
-    glds16(w_src[HF][1] + soff_, dst_ + 1024);                                                                \
+    const int soff_ = (KT) * (BK * 2);                                                                        \
+    CP_BL16(rs_w, w_off[HF][0], soff_, dst_);                                                                 \
+    CP_BL16(rs_w, w_off[HF][1], soff_, dst_ + 1024);                                                          \
   }
   // patch piece J (wave + 8 J) of channel slab S into patch buffer PSEL
-#define CP_ISSUE_P(J, S, PSEL)                                                                                \
-  {                                                                                                           \
-    const bool ok_ = poff[J] != 0xffffffffu;                                                                  \
-    glds16(ok_ ? inb + poff[J] + (long)(S) * (BK * 2) : zsrc + (lane & 3) * 16, smem + (PSEL) * PATCH + (wave + 8 * (J)) * 1024); \
-  }
+#define CP_ISSUE_P(J, S, PSEL) CP_BL16(rs_in, poff[J], (S) * (BK * 2), smem + (PSEL) * PATCH + (wave + 8 * (J)) * 1024);
 
     // ---- prologue: patch of slab 0, K tile 0 complete, W half 0 of K tile 1 under way
 #pragma unroll
@@ -363,7 +364,7 @@ int conv_patch_try_launch(const GemmArgs& g, hipStream_t stream) {
   const long hw = (long)H * W;
   if (hw <= 0 || g.M % hw != 0 || H < 4 || W < 4) return 1;
   const int B = (int)(g.M / hw);
-  if ((long)g.M * g.conv_c * 2 >= (1l << 32) - (1 << 20)) return 1;  // 32-bit source offsets
+  if ((long)g.M * g.conv_c * 2 >= (1l << 31) - (1 << 20)) return 1;  // 32-bit source offsets below 2^31 (0x80000000 = the out-of-image marker of the buffer descriptor)
   ConvPatchArgs a;
   a.in = reinterpret_cast<const bf16_t*>(g.A);
   a.w = reinterpret_cast<const bf16_t*>(g.W);

@@ -72,8 +72,13 @@ __global__ __launch_bounds__(512, 2) void gemm6p_kernel(const GemmArgs a) {
 
   // ---- LDS-DMA descriptors: lane -> (row r8 of an 8-row piece, 16-byte slot); the slot holds source chunk
   // slot ^ ((LDS row >> 1) & 7).  A: wave w stages LDS rows [32 w, +32) as pieces 0..3; W: piece w of each region.
-  const char* a_src[4];
-  const char* w_src[3];
+  // Round 6 (gemm8p.hip): buffer descriptors - SGPR base + 32-bit lane offset (0x80000000 = outside M / N: the hardware returns
+  // zeros) + the K offset in an SGPR; no VALU in the DMA issue
+  unsigned a_off[4], w_off[3];
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)((((long)a.M - 1) * a.lda + a.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)((((long)a.N - 1) * a.ldw + a.K) * 2), 0x00020000);
+#define R6_BL16(RS, VOFF, SOFF, DST) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, (int)(VOFF), (int)(SOFF), 0, 0)
 #define R6_TILE_SETUP(TMI, TNI)                                                                               \
   {                                                                                                           \
     const int d_m0 = (TMI) * BM, d_n0 = (TNI) * BN;                                                           \
@@ -84,19 +89,19 @@ __global__ __launch_bounds__(512, 2) void gemm6p_kernel(const GemmArgs a) {
       const int i = 32 * wave + 8 * j + r8;                                                                   \
       const int chunk = slot ^ ((i >> 1) & 7);                                                                \
       const int gm = d_m0 + i; /* M < 2^31 - 512 (dispatcher) */                                              \
-      a_src[j] = gm < a.M ? reinterpret_cast<const char*>(Ab + (long)gm * a.lda + chunk * 8) : zrows + chunk * 16; \
+      a_off[j] = gm < a.M ? (unsigned)(((long)gm * a.lda + chunk * 8) * 2) : 0x80000000u;                     \
     }                                                                                                         \
     _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) {                                                        \
       const int q = 8 * wave + r8; /* row inside the 64-row region: column half q >> 5, column q & 31 of block nt */ \
       const int chunk = slot ^ ((q >> 1) & 7);                                                                \
       const int gn = d_n0 + 96 * (q >> 5) + 32 * nt + (q & 31);                                               \
-      w_src[nt] = gn < a.N ? reinterpret_cast<const char*>(Wb + (long)gn * a.ldw + chunk * 8) : zrows + chunk * 16; \
+      w_off[nt] = gn < a.N ? (unsigned)(((long)gn * a.ldw + chunk * 8) * 2) : 0x80000000u;                    \
     }                                                                                                         \
   }
   // A piece J / W region NT at K position KP (in K tiles) into LDS buffer BSEL
-#define R6_ISSUE_A(J, KP, BSEL) glds16(a_src[J] + (long)(KP) * (BK * 2), smem + (BSEL) * BUF + (4 * wave + (J)) * 1024);
+#define R6_ISSUE_A(J, KP, BSEL) R6_BL16(rs_a, a_off[J], (KP) * (BK * 2), smem + (BSEL) * BUF + (4 * wave + (J)) * 1024);
 #define R6_ISSUE_W(NT_, KP, BSEL) \
-  glds16(w_src[NT_] + (long)(KP) * (BK * 2), smem + (BSEL) * BUF + TILE_A + ((NT_) * 8 + wave) * 1024);
+  R6_BL16(rs_w, w_off[NT_], (KP) * (BK * 2), smem + (BSEL) * BUF + TILE_A + ((NT_) * 8 + wave) * 1024);
 
   // ---- fragment read addresses: row = block_row0 + l31 (block_row0 % 32 == 0), 16-byte slot (2g + h) ^ ((l31 >> 1) & 7)
   const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);

@@ -36,6 +36,12 @@
 // packed-f32 GELU epilogue (gemm_device.h): this translation unit is compiled with packed-f32 instructions enabled
 // (Makefile PK_SRCS) and is covered by tools/audit_pk_sgpr.py
 #define ROMA_EPI_PK 1
+// Round 6: the dense operands go through buffer descriptors - buffer_load_dwordx4 ... lds with an SGPR base, a 32-bit lane
+// offset fixed per tile and the K offset in an SGPR - instead of flat 64-bit lane addresses rebuilt per piece: no VALU in the
+// DMA issue, and rows outside M / N (and padded QKV tokens) carry an offset beyond num_records, which the hardware answers
+// with zeros.  fc2 250 -> 229 us, qkv 204 -> 188, proj 68 -> 63, step -1.35 ms, bit-identical (profiles/r06_v23_*).  The 3x3
+// convolution form (tap offsets per piece) keeps the flat addresses.  Undefine for the A/B.
+#define ROMA_R8_BUFLDS 1
 #include "gemm.h"
 
 #include <stdio.h>
@@ -100,7 +106,53 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
   const char* a_src[2][2];  // [half][piece]
   const char* w_src[2][2];
   unsigned a_mask[2][2];    // conv: bit t = tap t of this row is inside the image
+#ifdef ROMA_R8_BUFLDS
+  // dense operands through buffer descriptors (see the top of the file): byte offsets of this lane's pieces, 0x80000000 = outside
+  unsigned a_off[2][2], w_off[2][2];
+  const long a_rows_ = a.qkv_pad ? (long)(a.M / a.npad) * a.ntok : (long)a.M;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, CONV ? 0 : (int)(((a_rows_ - 1) * a.lda + a.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, (int)((((long)a.N - 1) * a.ldw + a.K) * 2), 0x00020000);
+#define R8_BL16(RS, VOFF, SOFF, DST) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(DST), 16, (int)(VOFF), (int)(SOFF), 0, 0)
+#endif
   // descriptors of tile (TMI, TNI) - the DMA stream runs ahead of the math, so they may describe the NEXT output tile
+#ifdef ROMA_R8_BUFLDS
+#define R8_SETUP_W(hf, j, gn, chunk) \
+  w_off[hf][j] = gn < a.N ? (unsigned)(((long)gn * a.ldw + chunk * 8) * 2) : 0x80000000u; \
+  w_src[hf][j] = zrows;
+#define R8_SETUP_A_DENSE(hf, j, gm, chunk)                                                                    \
+  {                                                                                                           \
+    unsigned o_ = 0x80000000u;                                                                                \
+    if (gm < a.M) {                                                                                           \
+      if (a.qkv_pad) {                                                                                        \
+        const int qb_ = gm / a.npad;                                                                          \
+        const int qt_ = gm - qb_ * a.npad;                                                                    \
+        if (qt_ < a.ntok) o_ = (unsigned)((((long)qb_ * a.ntok + qt_) * a.lda + chunk * 8) * 2);              \
+      } else {                                                                                                \
+        o_ = (unsigned)(((long)gm * a.lda + chunk * 8) * 2);                                                  \
+      }                                                                                                       \
+    }                                                                                                         \
+    a_off[hf][j] = o_;                                                                                        \
+    a_src[hf][j] = zrows;                                                                                     \
+  }
+#else
+#define R8_SETUP_W(hf, j, gn, chunk) \
+  w_src[hf][j] = gn < a.N ? reinterpret_cast<const char*>(Wb + (long)gn * a.ldw + chunk * 8) : zrows + chunk * 16;
+#define R8_SETUP_A_DENSE(hf, j, gm, chunk)                                                                    \
+  {                                                                                                           \
+    const char* p = zrows + chunk * 16;                                                                       \
+    if (gm < a.M) {                                                                                           \
+      if (a.qkv_pad) { /* rows = (image, padded token); tokens >= ntok read zeros */                          \
+        const int qb_ = gm / a.npad;                                                                          \
+        const int qt_ = gm - qb_ * a.npad;                                                                    \
+        if (qt_ < a.ntok) p = reinterpret_cast<const char*>(Ab + ((long)qb_ * a.ntok + qt_) * a.lda + chunk * 8); \
+      } else {                                                                                                \
+        p = reinterpret_cast<const char*>(Ab + (long)gm * a.lda + chunk * 8);                                 \
+      }                                                                                                       \
+    }                                                                                                         \
+    a_src[hf][j] = p;                                                                                         \
+  }
+#endif
 #define R8_TILE_SETUP(TMI, TNI)                                                                               \
   {                                                                                                           \
     const int d_m0 = (TMI) * BM, d_n0 = (TNI) * BN;                                                           \
@@ -114,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
       const int chunk = slot ^ ((i >> 1) & 7);                                                                \
       const int gm = d_m0 + (i >> 6) * 128 + hf * 64 + (i & 63); /* M < 2^31: 32-bit divisions below */        \
       const int gn = d_n0 + (i >> 5) * 64 + hf * 32 + (i & 31);                                               \
-      w_src[hf][j] = gn < a.N ? reinterpret_cast<const char*>(Wb + (long)gn * a.ldw + chunk * 8) : zrows + chunk * 16; \
+      R8_SETUP_W(hf, j, gn, chunk)                                                                            \
       if constexpr (CONV) {                                                                                   \
         unsigned mk = 0;                                                                                      \
         const char* p = zrows;                                                                                \
@@ -133,21 +185,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
         a_src[hf][j] = p;                                                                                     \
       } else {                                                                                                \
         a_mask[hf][j] = 0;                                                                                    \
-        const char* p = zrows + chunk * 16;                                                                   \
-        if (gm < a.M) {                                                                                       \
-          if (a.qkv_pad) { /* rows = (image, padded token); tokens >= ntok read zeros */                      \
-            const int qb_ = gm / a.npad;                                                                      \
-            const int qt_ = gm - qb_ * a.npad;                                                                \
-            if (qt_ < a.ntok) p = reinterpret_cast<const char*>(Ab + ((long)qb_ * a.ntok + qt_) * a.lda + chunk * 8); \
-          } else {                                                                                            \
-            p = reinterpret_cast<const char*>(Ab + (long)gm * a.lda + chunk * 8);                             \
-          }                                                                                                   \
-        }                                                                                                     \
-        a_src[hf][j] = p;                                                                                     \
+        R8_SETUP_A_DENSE(hf, j, gm, chunk)                                                                    \
       }                                                                                                       \
     }                                                                                                         \
   }
 
+#ifdef ROMA_R8_BUFLDS
+#define R8_ISSUE_DENSE(RS, OFF, SRC, HF, KP, DST) \
+  { const int so_ = (KP) * (BK * 2); R8_BL16(RS, OFF[HF][0], so_, DST); R8_BL16(RS, OFF[HF][1], so_, (DST) + 1024); }
+#else
+#define R8_ISSUE_DENSE(RS, OFF, SRC, HF, KP, DST) \
+  { const long soff_ = (long)(KP) * (BK * 2); glds16(SRC[HF][0] + soff_, DST); glds16(SRC[HF][1] + soff_, (DST) + 1024); }
+#endif
   // K position KP (in K tiles, of the DMA tile) of A half HF into LDS buffer BSEL
 #define R8_ISSUE_A(HF, KP, BSEL)                                                                              \
   {                                                                                                           \
@@ -163,17 +212,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
         glds16(ok_ ? a_src[HF][j] + soff_ : zrows + (lane & 7) * 16, dst_ + j * 1024);                        \
       }                                                                                                       \
     } else {                                                                                                  \
-      const long soff_ = (long)(KP) * (BK * 2);                                                               \
-      glds16(a_src[HF][0] + soff_, dst_);                                                                     \
-      glds16(a_src[HF][1] + soff_, dst_ + 1024);                                                              \
+      R8_ISSUE_DENSE(rs_a, a_off, a_src, HF, KP, dst_)                                                        \
     }                                                                                                         \
   }
 #define R8_ISSUE_W(HF, KP, BSEL)                                                                              \
   {                                                                                                           \
     char* dst_ = smem + (BSEL) * BUF + TILE_A + (HF) * 128 * ROWB + (2 * wave) * 1024;                        \
-    const long soff_ = (long)(KP) * (BK * 2);                                                                 \
-    glds16(w_src[HF][0] + soff_, dst_);                                                                       \
-    glds16(w_src[HF][1] + soff_, dst_ + 1024);                                                                \
+    R8_ISSUE_DENSE(rs_w, w_off, w_src, HF, KP, dst_)                                                          \
   }
   // one piece (J = 0, 1) of a half-tile: the DMAMF schedule places the two pieces between the MFMAs of a phase
 #define R8_ISSUE_A1(HF, J, KP, BSEL)                                                                          \
@@ -447,6 +492,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
 #undef R8_ISSUE_W
 #undef R8_ISSUE_A
 #undef R8_TILE_SETUP
+#undef R8_ISSUE_DENSE
+#undef R8_SETUP_A_DENSE
+#undef R8_SETUP_W
 }
 
 template <typename TOUT, bool CONV, int EPI, bool DMAMF = false, int SCHED = 0, int ABL = 0>
@@ -520,6 +568,10 @@ int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
   if (a.K % 64 != 0 || a.K < 4 * 64 || a.K > 32704) return 1;
   const bool conv = a.conv_c > 0;
   if (conv && (a.conv_c % 64 != 0 || a.conv_c > 512)) return 1;
+#ifdef ROMA_R8_BUFLDS
+  // the dense operands are addressed with 32-bit byte offsets below 2^31 (the out-of-range marker) inside a buffer descriptor
+  if (!conv && (((long)a.M * a.lda + a.K) * 2 >= (1l << 31) || ((long)a.N * a.ldw + a.K) * 2 >= (1l << 31))) return 1;
+#endif
   // shapes gemm.hip would run on 256 x 256 tiles; for a single pair (M = 3 202 token rows, BASELINE config 2) the wide
   // launches (qkv, fc1: N >= 2048, 150-210 tiles of 256 x 256) are still better off on this kernel's pipelined loop with
   // part of the CUs idle than on gemm.hip's 128 x 128 loop at one wave per SIMD (ROMA_GEMM8P_MINM: A/B)

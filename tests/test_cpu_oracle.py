@@ -635,11 +635,11 @@ def test_dma_ring_kernels_keep_their_queue(built_lib, bdir):
         assert len(ks) == nk and all(k["spill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 256 for k in ks), ks
         full = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", extract_code_object(objs[f])], capture_output=True,
                               text=True, check=True).stdout
-        kerns = [k for k in re.split(r"\n(?=[0-9a-f]+ <_Z)", full) if "global_load_lds_dwordx4" in k]
+        kerns = [k for k in re.split(r"\n(?=[0-9a-f]+ <_Z)", full) if "global_load_lds_dwordx4" in k or re.search(r"buffer_load_dwordx4 .* lds", k)]
         assert len(kerns) == nk, (f, len(kerns))
         for kern in kerns:
             dis = kern.splitlines()
-            dma = [i for i, ln in enumerate(dis) if "global_load_lds_dwordx4" in ln]
+            dma = [i for i, ln in enumerate(dis) if "global_load_lds_dwordx4" in ln or re.search(r"buffer_load_dwordx4 .* lds", ln)]
             assert len(dma) >= 6, f
             # the row loop = from the last DMA issue (the loop's own) to the loop's back edge: the next backward branch
             body = []

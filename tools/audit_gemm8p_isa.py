@@ -110,12 +110,17 @@ def audit(name, body):
                 break
         return None
     per_loop = {}
-    for i, _ in compiler_waits:
+    bad_in_loop = []
+    for i, c in compiler_waits:
         lp = loop_of(i)
         if lp is not None:
             per_loop[lp] = per_loop.get(lp, 0) + 1
+            if "lgkmcnt(0)" not in c:
+                bad_in_loop.append((i, c))
+        elif "lgkmcnt" not in c:  # once-per-tile code: scalar-load waits of any count are fine, nothing else
+            bad_in_loop.append((i, c))
     loops = sorted(per_loop)
-    if any(n > 1 for n in per_loop.values()) or any("lgkmcnt(0)" not in c for _, c in compiler_waits):
+    if any(n > 1 for n in per_loop.values()) or bad_in_loop:
         problems.append(f"compiler-inserted waits inside the K loop: {compiler_waits} (per inner loop: {per_loop})")
     if foreign_vm:
         problems.append(f"compiler-inserted vmcnt waits inside the K loop: {foreign_vm}")

@@ -1,4 +1,4 @@
-"""ISA audit of every counted `s_waitcnt vmcnt(N)`, N > 0, that guards an LDS-DMA load (`global_load_lds_*`): the N youngest
+"""ISA audit of every counted `s_waitcnt vmcnt(N)`, N > 0, that guards an LDS-DMA load (`global_load_lds_*` or `buffer_load_* ... lds`): the N youngest
 vector-memory instructions in front of the wait must all be LOADS.
 
 The rule comes from round 3 (profiles/r03_v20_determinism_stress.log): vmcnt counts loads and stores in one
@@ -36,6 +36,11 @@ from audit_asm_reads import disassemble  # noqa: E402
 KNOWN_LAYOUT = ("refiner_block_kernelILi24E", "refiner_block_kernelILi144E")
 LOAD = ("global_load", "buffer_load", "flat_load")
 OTHER = ("global_store", "buffer_store", "flat_store", "global_atomic", "buffer_atomic", "flat_atomic", "scratch_")
+
+
+def is_dma(c):
+    """LDS-DMA load: `global_load_lds_dwordx4 ...` or (round 6) `buffer_load_dwordx4 ... offen lds`"""
+    return "_lds_" in c or (c.startswith("buffer_load") and re.search(r"\blds\b", c) is not None)
 
 
 def kernels(text):
@@ -97,7 +102,7 @@ def audit_kernel(body):
                 break
         stores = [ci for ci in young if ci.startswith(OTHER)]
         if stores:
-            if awaited is not None and "_lds_" in awaited:
+            if awaited is not None and is_dma(awaited):
                 bad.append((w, n, stores[0]))
             else:
                 soft.append((w, n, stores[0]))
@@ -121,7 +126,7 @@ def main(argv):
             bad, soft, counted = audit_kernel(body)
             total += counted
             nsoft += len(soft)
-            ndma += sum("_lds_" in c for _, c, _ in body)
+            ndma += sum(is_dma(c) for _, c, _ in body)
             layout = any(k in name for k in KNOWN_LAYOUT)
             for tag, lst in (("layout" if layout else "FAIL", bad), ("compiler", soft if show_all else [])):
                 for w, n, ci in lst:
