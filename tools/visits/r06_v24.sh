@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round 6, visit 24: buffer-descriptor LDS-DMA in gemm6p and conv_patch (weights + patch pieces) - A/B against tools/scratch/ab_buf
+# (gemm8p buffered, everything else as before) on one box: bit-identity, per-kernel time, step time, tests.
+set -u
+OUT=$PWD/gpurun_out/v24; rm -rf "$OUT"; mkdir -p "$OUT"
+for i in 1 2; do
+  echo "-- conv before"; ROMA_LIB_DIR=$PWD/tools/scratch/ab_buf timeout 300 python tools/bench_conv_patch.py 2>&1 | grep -v amdgpu | tee -a "$OUT/conv_before.log"
+  echo "-- conv after"; timeout 300 python tools/bench_conv_patch.py 2>&1 | grep -v amdgpu | tee -a "$OUT/conv_after.log"
+  echo "-- gemm before"; ROMA_LIB_DIR=$PWD/tools/scratch/ab_buf timeout 300 python tools/bench_gemm_epilogue.py 2>&1 | grep -v amdgpu | tee -a "$OUT/gemm_before.log"
+  echo "-- gemm after"; timeout 300 python tools/bench_gemm_epilogue.py 2>&1 | grep -v amdgpu | tee -a "$OUT/gemm_after.log"
+done
+echo "== step A/B"
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-other-configs --no-roofline"
+P='import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], round(d["value"],2), "pairs/s", round(d["ms_per_step"],2), "ms")'
+for i in 1 2 3; do
+  ROMA_LIB_DIR=$PWD/tools/scratch/ab_buf timeout 300 $B 2>/dev/null | python -c "$P" "before(ab_buf)" | tee -a "$OUT/bench_ab.log"
+  timeout 300 $B 2>/dev/null | python -c "$P" "after" | tee -a "$OUT/bench_ab.log"
+done
+echo "== operator tests"
+timeout 1500 python -m pytest tests/test_gpu_ops.py -q -x 2>&1 | tail -4 | tee "$OUT/pytest_ops.log"
+echo "== parity"
+timeout 1200 python -m pytest tests/test_gpu_parity.py -q -x 2>&1 | tail -4 | tee "$OUT/pytest_parity.log"
+echo "== done"
