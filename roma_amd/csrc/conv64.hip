@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const bf16_t* __res
   // slot lane % 8).  Lanes whose pixel is outside the image (left / right halo at the image border, padding behind the last
   // pixel) are switched off in every DMA; their ring positions are zeroed once, here, in all four slots.
   const bf16_t* inb = in + (long)b * H * W * 64;
+  // (round 6, gemm8p.hip: the row DMA through a buffer descriptor over image b - SGPR base + the lane's 32-bit offset + the row
+  //  offset in an SGPR - instead of a 64-bit lane address per piece; H * W * 128 B < 2^31: checked by the launcher)
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(inb), 0, (int)((long)H * W * 128), 0x00020000);
   unsigned voff[KW];  // byte offset of the lane's source chunk inside an image row
   bool okx[KW];
   {
@@ -120,13 +123,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const bf16_t* __res
   {                                                                                                            \
     const int yy_ = (YY);                                                                                      \
     if (yy_ >= 0 && yy_ < H) {                                                                                 \
-      const char* rowp_ = reinterpret_cast<const char*>(inb + (long)yy_ * W * 64);                            \
+      const int so_ = yy_ * W * 128;                                                                           \
       _Pragma("unroll") for (int j = 0; j < KW; ++j) {                                                         \
         const int q_ = wave + 4 * j;                                                                           \
         if (q_ < NPIECE) {                                                                                     \
           if (okx[j])                                                                                          \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp_ + voff[j]), \
-                                             (__attribute__((address_space(3))) void*)(ring + (SLOT) * RSTRIDE + q_ * 1024), 16, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(ring + (SLOT) * RSTRIDE + q_ * 1024), \
+                                                     16, (int)voff[j], so_, 0, 0);                             \
         }                                                                                                      \
       }                                                                                                        \
     } else { /* rows above / below the image (first and last strip only) */                                    \
@@ -311,6 +314,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c128_kernel(const bf16_t* __re
   if (lb != (int)blockIdx.x) __builtin_amdgcn_s_barrier();
 
   const bf16_t* inb = in + (long)b * H * W * 128;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(inb), 0, (int)((long)H * W * 256), 0x00020000);  // (conv3x3_c64_kernel)
   unsigned voff[KW];
   bool okx[KW];
   {
@@ -339,13 +343,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c128_kernel(const bf16_t* __re
   {                                                                                                            \
     const int yy_ = (YY);                                                                                      \
     if (yy_ >= 0 && yy_ < H) {                                                                                 \
-      const char* rowp_ = reinterpret_cast<const char*>(inb + (long)yy_ * W * 128);                           \
+      const int so_ = yy_ * W * 256;                                                                           \
       _Pragma("unroll") for (int j = 0; j < KW; ++j) {                                                         \
         const int q_ = wave + 8 * j;                                                                           \
         if (q_ < NPIECE) {                                                                                     \
           if (okx[j])                                                                                          \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp_ + voff[j]), \
-                                             (__attribute__((address_space(3))) void*)(ring + (SLOT) * RSTRIDE + q_ * 1024), 16, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (__attribute__((address_space(3))) void*)(ring + (SLOT) * RSTRIDE + q_ * 1024), \
+                                                     16, (int)voff[j], so_, 0, 0);                             \
         }                                                                                                      \
       }                                                                                                        \
     } else {                                                                                                   \
@@ -616,6 +620,7 @@ int conv64_try_launch(const GemmArgs& a, hipStream_t stream) {
   const int H = a.conv_h, W = a.conv_w;
   const long hw = (long)H * W;
   if (hw <= 0 || a.M % hw != 0) return 1;
+  if ((long)hw * a.conv_c * 2 >= (1l << 31)) return 1;  // 32-bit offsets inside an image's buffer descriptor
   const int B = (int)(a.M / hw);
   const int TW = (!c128 && a.N == 64) ? 128 : 64;
   const int slots = c128 ? 256 : 512;  // persistent workgroups: one (8 waves) or two (4 waves) per CU

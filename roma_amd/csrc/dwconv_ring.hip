@@ -168,36 +168,34 @@ __global__ __launch_bounds__(256, 2) void dwconv5x5_ring_kernel(const bf16_t* __
   // stays empty), 16-byte part p & 7 of the pixel's 128-byte channel line
   const char* zsrc = reinterpret_cast<const char*>(g_dwr_zero_page);
   const char* inb = reinterpret_cast<const char*>(in + ((long)b * H * W) * Cp) + (long)chunk * 128;
-  // Round 6: every lane carries the 64-bit source pointer of its three pieces for the NEXT in-image row and advances it by the
-  // row pitch when such a row is issued (lanes whose piece is an empty slot or lies outside the image in x keep pointing at
-  // the zero page: increment 0); rows above / below the image take the zero page for every lane behind a wave-uniform
-  // branch.  Until then each row rebuilt `row base + offset`, selected it against the zero page per lane (8 v_cndmask + 4
-  // v_mov per row) and multiplied the row index out in 64 bits.
+  // Round 6: the DMA goes through a buffer descriptor over this wave's slice of the image (base = image b, channel chunk): a
+  // 32-bit lane offset fixed for the strip (pixel column + 16-byte part; 0x80000000 for empty slots and columns outside the image:
+  // beyond num_records, the hardware returns zeros) plus the row offset in an SGPR.  No VALU in the issue, no per-row selects,
+  // no 64-bit lane pointers (first version of this round: pointers carried and advanced per row; before: rebuilt per row).
+  // Rows above / below the image take the marker offset for every lane behind a wave-uniform branch.
   const long pitch = (long)W * Cp * 2;  // (< 2^31: checked by the launcher)
-  const char* pptr[3];
-  unsigned pinc[3];
-  {
-    const int yy0 = max(ys - 2, 0);
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), 0, (int)((long)H * pitch - (long)chunk * 128), 0x00020000);
+  unsigned voff[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int p = 64 * i + lane, s = p >> 3, part = p & 7;
-      const int x = x0 + s - s / 5;
-      const bool ok = (s % 5 != 4) && x >= 0 && x < W;
-      pptr[i] = ok ? inb + (long)yy0 * pitch + (long)x * Cp * 2 + part * 16 : zsrc;
-      pinc[i] = ok ? (unsigned)pitch : 0u;
-    }
+  for (int i = 0; i < 3; ++i) {
+    const int p = 64 * i + lane, s = p >> 3, part = p & 7;
+    const int x = x0 + s - s / 5;
+    const bool ok = (s % 5 != 4) && x >= 0 && x < W;
+    voff[i] = ok ? (unsigned)(x * Cp * 2 + part * 16) : 0x80000000u;
   }
+  unsigned vout = 0x80000000u;  // every lane outside: the rows above / below the image
+  asm volatile("" : "+v"(vout));
   lds_u8* const myring = (lds_u8*)ring + wv * (NR * DWR_ROWB);
+#define ROMA_DWR_BL16(VOFF, SOFF, DST) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (ROMA_LDS void*)(DST), 16, (int)(VOFF), (int)(SOFF), 0, 0)
 #define ROMA_DWR_ISSUE(RROW, SLOT)                                                         \
   {                                                                                        \
     const int yy_ = ys - 2 + (RROW);                                                       \
     if ((RROW) < T && yy_ >= 0 && yy_ < H) { /* wave-uniform */                            \
-      _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                      \
-        dwr_glds16(pptr[i], myring + (SLOT) * DWR_ROWB + i * 1024);                        \
-        pptr[i] += pinc[i];                                                                \
-      }                                                                                    \
+      const int so_ = yy_ * (int)pitch;                                                    \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) ROMA_DWR_BL16(voff[i], so_, myring + (SLOT) * DWR_ROWB + i * 1024); \
     } else {                                                                               \
-      _Pragma("unroll") for (int i = 0; i < 3; ++i) dwr_glds16(zsrc, myring + (SLOT) * DWR_ROWB + i * 1024); \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) ROMA_DWR_BL16(vout, 0, myring + (SLOT) * DWR_ROWB + i * 1024); \
     }                                                                                      \
   }
 
@@ -256,7 +254,7 @@ int dwconv5x5_ring_try_launch(const void* in, void* out, const float* w, const f
   static const int env = getenv("ROMA_DW_RING") ? atoi(getenv("ROMA_DW_RING")) : 1;
   if (!(g_dw_ring >= 0 ? g_dw_ring : env)) return 1;
   if (dt != DT_BF16 || Cp % 64 != 0 || Cp < 256 || H < 1 || W < 1) return 1;
-  if ((long)W * Cp * 2 >= (1l << 31)) return 1;  // 32-bit byte offsets inside an image row
+  if ((long)H * W * Cp * 2 >= (1l << 31)) return 1;  // 32-bit byte offsets inside an image (buffer descriptor per image; 0x80000000 = outside)
   if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (reinterpret_cast<uintptr_t>(out) & 7) != 0) return 1;
   if ((reinterpret_cast<uintptr_t>(w) & 15) != 0 || (reinterpret_cast<uintptr_t>(bias) & 15) != 0) return 1;
   const int nchunk = Cp / 64;

@@ -178,23 +178,35 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
 
   const char* zsrc = reinterpret_cast<const char*>(g_rb_zero_page);
   const char* inb = reinterpret_cast<const char*>(in + ((long)b * H * W) * CP);
-  const int qoff0 = (wv * 64 + lane) * 16;
-  bool qok[KW];
+  // Round 6 (dwconv_ring.hip): the DMA goes through a buffer descriptor over image b - a 32-bit lane offset fixed for the strip
+  // (0x80000000 for chunks past the row segment and columns outside the image: beyond num_records, the hardware returns zeros)
+  // plus the row offset in an SGPR; rows above / below the image take the marker behind a wave-uniform branch.  No per-row
+  // selects and no 64-bit lane addresses.
+  const long pitch = (long)W * CP * 2;  // (H * pitch < 2^31: checked by the launcher)
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), 0, (int)((long)H * pitch), 0x00020000);
+  unsigned voff[KW];
 #pragma unroll
   for (int q = 0; q < KW; ++q) {
     const int chunk = (wv + 4 * q) * 64 + lane;
     const int x = x0 - 2 + chunk / (CP / 8);
-    qok[q] = chunk * 16 < Cf::IN_ROWB && x >= 0 && x < W;
+    const bool ok = chunk * 16 < Cf::IN_ROWB && x >= 0 && x < W;
+    voff[q] = ok ? (unsigned)((x0 - 2) * CP * 2 + chunk * 16) : 0x80000000u;
   }
+  unsigned vout = 0x80000000u;
+  asm volatile("" : "+v"(vout));
   const int kw = (NDMA - wv + 3) / 4;  // pieces this wave really issues per row (3 ; 2 ; 2 ; 2)
+#define ROMA_RB1_BL16(VOFF, SOFF, DST) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (ROMA_LDS void*)(DST), 16, (int)(VOFF), (int)(SOFF), 0, 0)
 #define ROMA_RB1_ISSUE_ROW(RROW, SLOT)                                                                 \
   {                                                                                                    \
     const int yy_ = ys - 2 + (RROW);                                                                   \
-    const bool rok_ = (RROW) < T && yy_ >= 0 && yy_ < H;                                               \
-    const char* rb_ = inb + ((long)(rok_ ? yy_ : 0) * W + x0 - 2) * (CP * 2);                          \
-    _Pragma("unroll") for (int q = 0; q < KW; ++q) {                                                   \
-      if (wv + 4 * q < NDMA)                                                                           \
-        rb_glds16((rok_ && qok[q]) ? rb_ + qoff0 + q * 4096 : zsrc, (lds_u8*)ring + (SLOT) * RSTRIDE + (wv + 4 * q) * 1024); \
+    if ((RROW) < T && yy_ >= 0 && yy_ < H) { /* wave-uniform */                                        \
+      const int so_ = yy_ * (int)pitch;                                                                \
+      _Pragma("unroll") for (int q = 0; q < KW; ++q)                                                   \
+        if (wv + 4 * q < NDMA) ROMA_RB1_BL16(voff[q], so_, (lds_u8*)ring + (SLOT) * RSTRIDE + (wv + 4 * q) * 1024); \
+    } else {                                                                                           \
+      _Pragma("unroll") for (int q = 0; q < KW; ++q)                                                   \
+        if (wv + 4 * q < NDMA) ROMA_RB1_BL16(vout, 0, (lds_u8*)ring + (SLOT) * RSTRIDE + (wv + 4 * q) * 1024); \
     }                                                                                                  \
   }
 
@@ -429,6 +441,7 @@ template <int CP>
 static int launch_cp(const void* in, void* out, const float* dw_w, const float* dw_b, const void* pw, long ldpw,
                      const float* pw_b, int B, int H, int W, hipStream_t s, float* delta = nullptr) {
   typedef RBCfg<CP> Cf;
+  ROMA_REQUIRE((long)H * W * CP * 2 < (1l << 31), "refiner_block: an image must stay below 2 GiB (32-bit offsets inside its buffer descriptor)");
   const int nxg = (W + Cf::PX - 1) / Cf::PX;
   // strip height: SY + 4 input rows are read per strip (and ~2 more rows' worth of pipeline fill), and the 512 resident
   // workgroups take the strips in rounds - pick the split of H that minimises rounds x (SY + 6).  ROMA_RB_SY overrides.

@@ -162,35 +162,34 @@ __global__ __launch_bounds__(256, 2) void refiner_block24_wave_kernel(const bf16
   // ---- DMA descriptors: piece k = 64 i + lane of a row; 13 pieces per 4 pixels (12 data + 1 gap)
   const char* zsrc = reinterpret_cast<const char*>(g_rbw_zero_page);
   const char* inb = reinterpret_cast<const char*>(in + ((long)b * H * W) * CP);
-  // Round 6 (dwconv_ring.hip): every lane carries the source pointer of its three pieces for the next in-image row and
-  // advances it by the row pitch (increment 0 for gap / out-of-image pieces, which keep pointing at the zero page); rows above
-  // / below the image take the zero page behind a wave-uniform branch.  No per-row selects, no 64-bit row products.
-  const long pitch = (long)W * CP * 2;  // (< 2^31: checked by the launcher)
-  const char* pptr[3];
-  unsigned pinc[3];
-  {
-    const int yy0 = max(ys - 2, 0);
+  // Round 6 (dwconv_ring.hip): the DMA goes through a buffer descriptor over image b - a 32-bit lane offset fixed for the strip
+  // (0x80000000 for gap pieces and columns outside the image: beyond num_records, the hardware returns zeros) plus the row
+  // offset in an SGPR; rows above / below the image take the marker for every lane behind a wave-uniform branch.  No VALU in
+  // the issue, no per-row selects, no 64-bit lane pointers.
+  const long pitch = (long)W * CP * 2;  // (H * pitch < 2^31: checked by the launcher)
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(inb), 0, (int)((long)H * pitch), 0x00020000);
+  unsigned voff[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int k = 64 * i + lane, g13 = k / 13, r13 = k - g13 * 13;
-      const int p = 4 * g13 + r13 / 3, part = r13 % 3;
-      const int x = x0 + p;
-      const bool ok = r13 != 12 && p < RBW_PXW + 4 && x >= 0 && x < W;
-      pptr[i] = ok ? inb + (long)yy0 * pitch + (long)x * CP * 2 + part * 16 : zsrc;
-      pinc[i] = ok ? (unsigned)pitch : 0u;
-    }
+  for (int i = 0; i < 3; ++i) {
+    const int k = 64 * i + lane, g13 = k / 13, r13 = k - g13 * 13;
+    const int p = 4 * g13 + r13 / 3, part = r13 % 3;
+    const int x = x0 + p;
+    const bool ok = r13 != 12 && p < RBW_PXW + 4 && x >= 0 && x < W;
+    voff[i] = ok ? (unsigned)(x * CP * 2 + part * 16) : 0x80000000u;
   }
+  unsigned vout = 0x80000000u;  // every lane outside: rows above / below the image
+  asm volatile("" : "+v"(vout));
   lds_u8* const myring = (lds_u8*)ring + wv * (NR * RBW_ROWB);
+#define ROMA_RBW_BL16(VOFF, SOFF, DST) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (ROMA_LDS void*)(DST), 16, (int)(VOFF), (int)(SOFF), 0, 0)
 #define ROMA_RBW_ISSUE(RROW, SLOT)                                                                  \
   {                                                                                                 \
     const int yy_ = ys - 2 + (RROW);                                                                \
     if ((RROW) < T && yy_ >= 0 && yy_ < H) { /* wave-uniform */                                     \
-      _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                               \
-        rbw_glds16(pptr[i], myring + (SLOT) * RBW_ROWB + i * 1024);                                 \
-        pptr[i] += pinc[i];                                                                         \
-      }                                                                                             \
+      const int so_ = yy_ * (int)pitch;                                                             \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) ROMA_RBW_BL16(voff[i], so_, myring + (SLOT) * RBW_ROWB + i * 1024); \
     } else {                                                                                        \
-      _Pragma("unroll") for (int i = 0; i < 3; ++i) rbw_glds16(zsrc, myring + (SLOT) * RBW_ROWB + i * 1024); \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) ROMA_RBW_BL16(vout, 0, myring + (SLOT) * RBW_ROWB + i * 1024); \
     }                                                                                               \
   }
 
@@ -367,7 +366,7 @@ int refiner_block24_wave_try_launch(const void* in, void* out, const float* dw_w
 #ifdef ROMA_TOOLS_BUILD
   if (!(g_rb24_wave >= 0 ? g_rb24_wave : env)) return 1;  // A/B: the two-barrier workgroup kernel (refiner_block_2b.inc)
 #endif
-  if (dt != DT_BF16 || H < 1 || W < 1 || (long)W * RBW_C * 2 >= (1l << 31)) return 1;
+  if (dt != DT_BF16 || H < 1 || W < 1 || (long)H * W * RBW_C * 2 >= (1l << 31)) return 1;  // (32-bit offsets inside an image)
   if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (reinterpret_cast<uintptr_t>(delta ? (void*)delta : out) & 15) != 0) return 1;
   if ((reinterpret_cast<uintptr_t>(pw) & 15) != 0 || ldpw % 8 != 0) return 1;
   const int nxg = (W + RBW_PXW - 1) / RBW_PXW;

@@ -117,10 +117,12 @@ __global__ __launch_bounds__(384, 2) void ws1x1_kernel(const bf16_t* __restrict_
   for (int ks = 0; ks < 36; ++ks) asm volatile("" : "+v"(wreg[ks]));
 
   // piece I (0 .. 5) of this wave for chunk CH (a chunk index of the stream, wave-uniform) into ring slot CH & 3
+  // (round 6: through a buffer descriptor - SGPR base, the lane's 32-bit offset inside the chunk, the chunk offset in an SGPR -
+  //  instead of a 64-bit lane address rebuilt per piece; gemm8p.hip)
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(nchunks * (long)WS_SLOT), 0x00020000);
 #define WS_ISSUE_PIECE(I, CH)                                                                                         \
-  __builtin_amdgcn_global_load_lds(                                                                                   \
-      (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(A) + (CH) * (long)WS_SLOT + soff[I]), \
-      (__attribute__((address_space(3))) void*)(lds + (int)((CH) & 3) * WS_SLOT + (6 * wave + (I)) * 1024), 16, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(lds + (int)((CH) & 3) * WS_SLOT + (6 * wave + (I)) * 1024), \
+                                           16, (int)soff[I], (int)((CH) * (long)WS_SLOT), 0, 0);
 
   u32x4 fa[4];  // reads run three k-steps ahead of their MFMAs
 #define WS_READ(SB, KS) \
