@@ -231,14 +231,18 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_h16_v2_kernel(cons
     voff[i] = (unsigned)(idx / (KV / 8)) * (unsigned)a.npad + (unsigned)(idx % (KV / 8)) * 8u;
   }
   u32x4_t kreg[NKC], vreg[NVC];
+  // Round 6: K / V^T tiles through buffer descriptors over this (image, head)'s slabs - the thread's 32-bit offset is fixed,
+  // the tile offset travels in an SGPR: no address arithmetic on the VALU (the loop is bound by its VALU issue slots; the flat
+  // form spent five instructions per tile on 64-bit addresses)
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K), 0, (int)((long)a.npad * HD * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Vt), 0, (int)((long)a.npad * HD * 2), 0x00020000);
 #define ROMA_ATTN_FETCH2(KV0)                                                                      \
   {                                                                                                \
-    const bf16_t* kt_ = K + (long)(KV0) * HD; /* uniform */                                        \
-    const bf16_t* vt_ = Vt + (KV0);                                                                \
+    const int ks_ = (KV0) * (HD * 2), vs_ = (KV0) * 2; /* uniform byte offsets of the tile */       \
     _Pragma("unroll") for (int i = 0; i < NKC; ++i)                                                \
-        kreg[i] = *reinterpret_cast<const u32x4_t*>(kt_ + (unsigned)(tid * 8 + 2048 * i));         \
+        kreg[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_k, tid * 16 + 4096 * i, ks_, 0)); \
     _Pragma("unroll") for (int i = 0; i < NVC; ++i)                                                \
-        vreg[i] = *reinterpret_cast<const u32x4_t*>(vt_ + voff[i]);                                \
+        vreg[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_v, (int)(voff[i] * 2u), vs_, 0)); \
   }
 #define ROMA_ATTN_STAGE(BUF)                                                                        \
   {                                                                                                \
