@@ -219,6 +219,40 @@ def test_gemm8p_matches_classic_and_reference(lib, M, N, K, act, out_f32, sched)
     assert torch.allclose(out[:2048].cpu().double(), ref, atol=2e-3 if out_f32 else 0.03, rtol=1e-4 if out_f32 else 1e-2)
 
 
+def test_gemm8p_buffer_descriptor_extents(lib):
+    """Round 6: the 8-phase kernels address their operands through buffer descriptors (32-bit byte offsets below 2^31, rows
+    outside M / N answered with zeros by the hardware's range check).  (a) An operand VIEW - lda > K, the activation a column
+    slice of a wider matrix - must read exactly its K columns: num_records ends at the last row's last element, and what lies
+    behind a row's K columns inside lda is never touched (poisoned with NaN here).  (b) An operand of 2 GiB or more cannot be
+    described; the dispatcher hands it to the classic flat-address kernel, which must agree with an f64 reference."""
+    M, N, K, LDA = 9000, 512, 512, 1280
+    g = torch.Generator().manual_seed(11)
+    wide = torch.full((M, LDA), float("nan"), dtype=torch.bfloat16)
+    A = (torch.randn(M, K, generator=g)).bfloat16()
+    wide[:, 256:256 + K] = A
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    b = torch.randn(N, generator=g)
+    wd, Wd, bd = wide.cuda(), W.cuda(), b.cuda()
+    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    view = wd[:, 256:256 + K]
+    ok(lib, lib.roma_op_gemm(P(view), LDA, P(Wd), K, P(out), N, M, N, K, 1, 0, 0, 0, P(bd), None, None, 0, 0, 1.0, BF16, BF16, None))
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().T + b.double()
+    assert torch.isfinite(out.float()).all()
+    assert torch.allclose(out.cpu().double(), ref, atol=0.03, rtol=1e-2)
+    # (b) 2.2 GiB activation: M x K x 2 bytes >= 2^31
+    M2, K2, N2 = 1_100_000, 1024, 256
+    A2 = torch.randn(M2, K2, device="cuda", dtype=torch.bfloat16)
+    W2 = (torch.randn(N2, K2, device="cuda") * K2 ** -0.5).to(torch.bfloat16)
+    b2 = torch.randn(N2, device="cuda")
+    out2 = torch.empty((M2, N2), device="cuda", dtype=torch.bfloat16)
+    ok(lib, lib.roma_op_gemm(P(A2), K2, P(W2), K2, P(out2), N2, M2, N2, K2, 1, 0, 0, 0, P(b2), None, None, 0, 0, 1.0, BF16, BF16, None))
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.arange(0, 64), torch.arange(M2 // 2 - 32, M2 // 2 + 32), torch.arange(M2 - 64, M2)]).cuda()
+    ref2 = A2[rows].double() @ W2.double().T + b2.double()
+    assert torch.allclose(out2[rows].double(), ref2, atol=0.03, rtol=1e-2)
+
+
 @pytest.mark.parametrize("M,act", [(65536, 0), (74656, 1), (313600, 0), (65536 + 32 * 113, 1), (746496, 1)])
 def test_ws1x1_matches_tile_kernels_and_reference(lib, M, act):
     """ws1x1.hip (weight-stationary N = K = 576 refiner 1x1: W in registers, pixel chunks through a two-stage LDS-DMA ring,
