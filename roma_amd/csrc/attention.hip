@@ -11,6 +11,7 @@
 #include "attention.h"
 
 #include <stdlib.h>
+#include <type_traits>
 #include <stdio.h>
 #include "gemm.h"  // DT_*
 
@@ -262,92 +263,103 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_h16_v2_kernel(cons
   ROMA_ATTN_STAGE(0);
   ROMA_ATTN_FETCH2(min(KV, a.npad - KV));  // (unconditional fetches: a conditional one made hipcc keep the registers in scratch;
   __syncthreads();                         //  past the end they re-read the last tile)
-  int cur = 0;
-  for (int kv0 = 0; kv0 < a.N; kv0 += KV, cur ^= 1) {
+  // Round 6: the key-tile loop runs in pairs with the LDS buffer index a compile-time constant (a generic lambda instantiated
+  // for 0 and 1), so every staging write and fragment read is `base register + immediate` - the loop is bound by its VALU issue
+  // slots, and selecting the buffer at run time cost ~10 address instructions per tile.  Same operations in the same order.
+  int kv0 = 0;
+  auto tile = [&](auto curc) __attribute__((always_inline)) {
+    constexpr int cur = decltype(curc)::value;
     // stage tile t + 1 into the other buffer: every wave finished reading it (tile t - 1) before the barrier that ended
-    // the previous iteration; its loads were issued a whole tile ago
-    ROMA_ATTN_STAGE(cur ^ 1);
-    ROMA_ATTN_FETCH2(min(kv0 + 2 * KV, a.npad - KV));
-    const bf16_t* const Ks = Ksb[cur];
-    const bf16_t* const Vs = Vsb[cur];
-    f32x16 s[KT];
-    // the two 32-key chains interleaved: consecutive MFMAs never depend on each other
+      // the previous iteration; its loads were issued a whole tile ago
+      ROMA_ATTN_STAGE(cur ^ 1);
+      ROMA_ATTN_FETCH2(min(kv0 + 2 * KV, a.npad - KV));
+      const bf16_t* const Ks = Ksb[cur];
+      const bf16_t* const Vs = Vsb[cur];
+      f32x16 s[KT];
+      // the two 32-key chains interleaved: consecutive MFMAs never depend on each other
 #pragma unroll
-    for (int st = 0; st < NS; ++st) {
+      for (int st = 0; st < NS; ++st) {
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(&Ks[(32 * kt + l31) * KS + 16 * st + 8 * h]);
-        s[kt] = mfma_h16_32x32x16(kf, qf[st], st == 0 ? cneg : s[kt]);  // scores relative to m_ref
-      }
-    }
-    if (kv0 + KV > a.N) {  // only the last tile has keys >= N to mask (uniform branch)
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (key >= a.N) s[kt][r] = -INFINITY;
-        }
-    }
-    float tm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // four independent v_max3 chains, not one of 17
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tm[(2 * kt + (r >> 3)) & 3] = fmaxf(tm[(2 * kt + (r >> 3)) & 3], s[kt][r]);
-    float tmax = attn_max_halves(fmaxf(fmaxf(tm[0], tm[1]), fmaxf(tm[2], tm[3])));
-    const bool first = kv0 == 0;
-    // wave-uniform decision: move the reference (rare after tile 0).  Padding queries (qi >= N) have no vote: their Q rows
-    // are whatever the workspace holds (the model's DINOv2 and decoder layouts share it, so "padding" of one is data of the
-    // other), and a vote of theirs would make the rounding of the VALID queries of the wave depend on that leftover - seen
-    // as run-to-run differences of the last patch token, amplified by the coarse arg-max (profiles/r03_v24_*.log).
-    if (__builtin_amdgcn_ballot_w64(first || (qi < a.N && tmax > THR)) != 0) {
-      const float delta = first ? tmax : fmaxf(tmax, 0.f);
-      if (!first) {  // O and l are still zero on the first tile (and alpha could overflow there)
-        const float alpha = EXP2 ? __builtin_amdgcn_exp2f(-delta) : __expf(-delta);
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-        l_run *= alpha;
-      }
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
-      m_ref += delta;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) cneg[r] = -m_ref;
-    }
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = EXP2 ? __builtin_amdgcn_exp2f(s[kt][r]) : __expf(s[kt][r]);
-    {  // row sums: four independent chains (one 32-deep chain of dependent adds is ~1.7 x slower to issue)
-      float ls[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ls[r & 3] += s[kt][r];
-      l_run += (ls[0] + ls[1]) + (ls[2] + ls[3]);
-    }
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        u32x4_t pk;
-        pk.x = pack_bf16x2(s[kt][8 * u + 0], s[kt][8 * u + 1]);
-        pk.y = pack_bf16x2(s[kt][8 * u + 2], s[kt][8 * u + 3]);
-        pk.z = pack_bf16x2(s[kt][8 * u + 4], s[kt][8 * u + 5]);
-        pk.w = pack_bf16x2(s[kt][8 * u + 6], s[kt][8 * u + 7]);
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-          const bf16_t* vrow = &Vs[(32 * d + l31) * VS + 32 * kt + 16 * u + 4 * h];
-          const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(vrow);
-          const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(vrow + 8);
-          o[d] = mfma_h16_32x32x16(u32x4_t{lo.x, lo.y, hi.x, hi.y}, pk, o[d]);
+        for (int kt = 0; kt < KT; ++kt) {
+          const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(&Ks[(32 * kt + l31) * KS + 16 * st + 8 * h]);
+          s[kt] = mfma_h16_32x32x16(kf, qf[st], st == 0 ? cneg : s[kt]);  // scores relative to m_ref
         }
       }
-    __syncthreads();
+      if (kv0 + KV > a.N) {  // only the last tile has keys >= N to mask (uniform branch)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (key >= a.N) s[kt][r] = -INFINITY;
+          }
+      }
+      float tm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // four independent v_max3 chains, not one of 17
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tm[(2 * kt + (r >> 3)) & 3] = fmaxf(tm[(2 * kt + (r >> 3)) & 3], s[kt][r]);
+      float tmax = attn_max_halves(fmaxf(fmaxf(tm[0], tm[1]), fmaxf(tm[2], tm[3])));
+      const bool first = kv0 == 0;
+      // wave-uniform decision: move the reference (rare after tile 0).  Padding queries (qi >= N) have no vote: their Q rows
+      // are whatever the workspace holds (the model's DINOv2 and decoder layouts share it, so "padding" of one is data of the
+      // other), and a vote of theirs would make the rounding of the VALID queries of the wave depend on that leftover - seen
+      // as run-to-run differences of the last patch token, amplified by the coarse arg-max (profiles/r03_v24_*.log).
+      if (__builtin_amdgcn_ballot_w64(first || (qi < a.N && tmax > THR)) != 0) {
+        const float delta = first ? tmax : fmaxf(tmax, 0.f);
+        if (!first) {  // O and l are still zero on the first tile (and alpha could overflow there)
+          const float alpha = EXP2 ? __builtin_amdgcn_exp2f(-delta) : __expf(-delta);
+#pragma unroll
+          for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+          l_run *= alpha;
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
+        m_ref += delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cneg[r] = -m_ref;
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = EXP2 ? __builtin_amdgcn_exp2f(s[kt][r]) : __expf(s[kt][r]);
+      {  // row sums: four independent chains (one 32-deep chain of dependent adds is ~1.7 x slower to issue)
+        float ls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ls[r & 3] += s[kt][r];
+        l_run += (ls[0] + ls[1]) + (ls[2] + ls[3]);
+      }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          u32x4_t pk;
+          pk.x = pack_bf16x2(s[kt][8 * u + 0], s[kt][8 * u + 1]);
+          pk.y = pack_bf16x2(s[kt][8 * u + 2], s[kt][8 * u + 3]);
+          pk.z = pack_bf16x2(s[kt][8 * u + 4], s[kt][8 * u + 5]);
+          pk.w = pack_bf16x2(s[kt][8 * u + 6], s[kt][8 * u + 7]);
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const bf16_t* vrow = &Vs[(32 * d + l31) * VS + 32 * kt + 16 * u + 4 * h];
+            const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(vrow);
+            const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(vrow + 8);
+            o[d] = mfma_h16_32x32x16(u32x4_t{lo.x, lo.y, hi.x, hi.y}, pk, o[d]);
+          }
+        }
+      __syncthreads();
+  };
+  while (kv0 < a.N) {
+    tile(std::integral_constant<int, 0>{});
+    kv0 += KV;
+    if (kv0 >= a.N) break;
+    tile(std::integral_constant<int, 1>{});
+    kv0 += KV;
   }
   float l = l_run;
   l += __shfl_xor(l, 32);
