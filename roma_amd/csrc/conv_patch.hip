@@ -202,6 +202,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const ConvPatchAr
     // Round 6: the K loop by slab - the nine taps of every slab but the last as nine STEADY copies of the body with the tap a
     // constant, the last slab on the general copy (conv_patch_ktile.inc).  The single loop carried ~25 branches per K tile.
     int kt = 0, slab = 0;
+    unsigned ca[4];  // fragment addresses of the current tap's blocks (conv_patch_ktile.inc); first: tap 0 of slab 0 (patch buffer 0)
+    {
+      const int toff0 = (-PW - 1) * ROWB;
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const unsigned rb_ = prow[mh][mt] + (unsigned)toff0;
+          ca[2 * mh + mt] = lds0 + rb_ + ((((rb_ >> 8) & 7u) ^ (unsigned)h) << 4);
+        }
+    }
 #define CP_STEADY 1
     for (; slab + 1 < nslab; ++slab) {
       {
