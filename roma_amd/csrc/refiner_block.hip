@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
   const int ys = (int)(rr % yt) * SY;
   const int b = (int)(rr / yt);
   const int tid = threadIdx.x;
-  const int wv = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform in a form the compiler sees (round 6: as a plain shift of
+                                                              // tid it put the DMA issue - the LDS target depends on wv - behind exec masks)
+  const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int x0 = xg * PX;
   const int sy = min(SY, H - ys);
   const int T = sy + 4;
@@ -335,7 +337,8 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
     // before an older load: dwconv_ring.hip); they were issued a whole stencil ago.
     if (kw == KW) ROMA_RB_WAIT_VM((NR - 2) * KW); else ROMA_RB_WAIT_VM((NR - 2) * (KW - 1));
     ROMA_RB_BARRIER();  // Xt[t & 1] complete; every wave is done with ring slot `slot`; input row t + 1 is visible
-    ROMA_RB1_ISSUE_ROW(t + NR, slot);
+    // (row t + NR is requested at the END of the iteration, behind this row's stores: the counted wait above then leaves exactly
+    //  the youngest vector-memory instructions - that row's pieces, loads - in flight, the form tools/audit_vmcnt.py can prove)
     if (o >= 0) {
       // ---------------- 1x1 convolution of output row o: own 32-channel block (weights in registers) ...
       int lanev = lane;  // opaque copy: keeps loop-invariant addresses from being hoisted into long-lived registers
@@ -424,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void refiner_block144_1b_kernel(const bf16_
       }
     }
       }
+    ROMA_RB1_ISSUE_ROW(t + NR, slot);
     slot = slot + 1 == NR ? 0 : slot + 1;
   }
   ROMA_RB_WAIT_VM(0);  // trailing zero-page DMAs must not outlive the workgroup's LDS allocation
