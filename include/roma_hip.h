@@ -179,7 +179,9 @@ int roma_destroy(roma_handle_t h);
  * (results agree to f32 rounding); "gp_col_leader" 1 / 0 = inside a column launch one leader workgroup per image factorises
  * the diagonal block and hands its inverse to the row-block workgroups (default) / every workgroup factorises its own copy
  * (bit-identical results; also the time-out path of the hand-off); "gemm8p_maxwg" n = measurement only: cap the persistent grid
- * of the 8-phase GEMM at n workgroups (tools/bench_gemm_burst.py; -1 = one per CU).  Every alternative computes the same values (the stencil / block
+ * of the 8-phase GEMM at n workgroups (tools/bench_gemm_burst.py; -1 = one per CU); "gemm8p_walk" g = tile rows per group of its
+ * walk through an XCD's band of output tiles (1 = row-major; -1 = row-major below 24 tile columns, 8 from there on; same values in
+ * any order: tools/bench_gemm_walk.py).  Every alternative computes the same values (the stencil / block
  * kernels bit for bit); -1 restores the default (or the environment variable of the same name in upper case, ROMA_...). */
 int roma_tuning(const char* key, int value);
 /* measuring tool (tools/bench_gemm_ablation.py): after a GEMM launched with the "gemm_dbg" trace bit (32768), copies the

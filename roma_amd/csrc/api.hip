@@ -239,6 +239,7 @@ int roma_tuning(const char* key, int value) {
   const std::string k(key);
   if (k == "gemm8p") g_gemm_tuning[0] = value;
   else if (k == "gemm_dbg") g_gemm_tuning[1] = value;
+  else if (k == "gemm8p_walk") g_gemm8p_walk = value;
   else if (k == "gemm8p_sched") g_gemm8p_sched = value;
   else if (k == "gemm8p_maxwg") g_gemm8p_maxwg = value;
   else if (k == "ws1x1") g_ws1x1_mode = value;

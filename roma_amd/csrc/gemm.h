@@ -58,6 +58,7 @@ struct GemmArgs {
   // on channel counts padded to whole 128-byte rows (1137 -> 1152, 569 -> 576, 1377 -> 1408); the roofline figure counts
   // the reference's channels, not the zero padding
   int n_alg = 0, k_alg = 0;
+  int walk_gm = 0;  // gemm8p: tile rows per group of the persistent walk (0 / 1 = row major; set by gemm8p_try_launch)
   int dbg = 0;  // tuning experiments only (ROMA_GEMM_DBG): 1 = skip output stores, 2 = skip the K loop
 };
 
@@ -71,7 +72,8 @@ int gemm6p_try_launch(const GemmArgs& a, hipStream_t stream);
 int ws1x1_try_launch(const GemmArgs& a, hipStream_t stream);
 extern int g_ws1x1_mode;  // roma_tuning("ws1x1", v): 1 on (default), 0 off, -1 = environment ROMA_WS1X1
 extern int g_gemm8p_sched;    // gemm8p K-loop schedule: 1 = k-half phases, 0 = quadrant phases, -1 = environment ROMA_GEMM8P_SCHED (default 1)
-extern int g_gemm8p_maxwg;    // gemm8p persistent-grid cap (tools: tools/bench_gemm_burst.py), -1 = 256
+extern int g_gemm8p_maxwg;
+extern int g_gemm8p_walk;    // gemm8p walk group height (tools: tools/bench_gemm_walk.py), -1 = the dispatcher's choice
 int gemm8p_trace_read(unsigned* host, long nbytes);  // phase trace of the last ablation-build launch (tools/bench_gemm_ablation.py)
 extern int g_gemm_tuning[2];  // process-wide A/B switches (roma_tuning): [0] use gemm8p (-1 = env ROMA_GEMM8P, default on), [1] dbg bits
 

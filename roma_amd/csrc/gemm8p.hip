@@ -355,9 +355,22 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
   constexpr bool prio = true, stagger = true;
 #endif
 
-  // tile coordinates advance incrementally (one scalar division pair here, none per tile)
-  int c_tm = (int)(((long)xcd * per_xcd + li) / NT), c_tn = (int)(((long)xcd * per_xcd + li) % NT);
-  const int step_m = (int)(wg_per_xcd / NT), step_n = (int)(wg_per_xcd % NT);
+  // walk order inside the XCD's band: groups of `gm` tile rows, m fastest inside a group - the 32 workgroups of an XCD that run
+  // side by side then cover a gm x (32 / gm) block of tiles ((gm + 32 / gm) operand panels per K step through the XCD's L2)
+  // instead of 32 / NT rows x NT columns.  gm = 1 is the plain row-major walk.  One division pair per output tile.
+  const int MT = (a.M + BM - 1) / BM;
+  const int gm = a.walk_gm > 1 ? a.walk_gm : 1;
+#define R8_TILE_OF(L, TMO, TNO)                                       \
+  {                                                                   \
+    const long l_ = (L);                                              \
+    const int g_ = (int)(l_ / ((long)gm * NT));                       \
+    const int r_ = (int)(l_ - (long)g_ * gm * NT);                    \
+    const int ge_ = min(gm, MT - g_ * gm);                            \
+    TNO = r_ / ge_;                                                   \
+    TMO = g_ * gm + (r_ - TNO * ge_);                                 \
+  }
+  int c_tm, c_tn;
+  R8_TILE_OF((long)xcd * per_xcd + li, c_tm, c_tn)
 
   // ---- prologue: K tile 0 complete, A0 / W0 of K tile 1 under way (nk >= 2 is guaranteed by the dispatcher)
   R8_TILE_SETUP(c_tm, c_tn)
@@ -380,11 +393,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
     const int n0 = c_tn * BN;
     const long li_next = li + wg_per_xcd;
     const bool has_next = li_next < per_xcd && (long)xcd * per_xcd + li_next < nblk;
-    int n_tm = c_tm + step_m, n_tn = c_tn + step_n;
-    if (n_tn >= NT) {
-      n_tn -= NT;
-      ++n_tm;
-    }
+    int n_tm = 0, n_tn = 0;
+    if (has_next) R8_TILE_OF((long)xcd * per_xcd + li_next, n_tm, n_tn)
 
     f32x16 acc[TN][TM];
 #pragma unroll
@@ -471,6 +481,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs a) {
       for (int i = lane; i < 1024; i += 64) dst[i] = src[i];
     }
   }
+#undef R8_TILE_OF
 #undef R8_PHASE_T
 #undef R8K_MFMA
 #undef R8K_WAIT_AWW
@@ -551,7 +562,13 @@ int gemm8p_trace_read(unsigned* host, long n) {
 // gemm_launch's own normalisation (qkv_pad / m_alg already applied).
 int conv64_try_launch(const GemmArgs& a, hipStream_t stream);  // conv64.hip (weight-stationary 3x3, Cin = 64)
 
-int gemm8p_try_launch(const GemmArgs& a, hipStream_t stream) {
+int g_gemm8p_walk = -1;  // roma_tuning("gemm8p_walk", n): tile rows per walk group (1 = row major); -1 = the dispatcher's choice
+int gemm8p_try_launch(const GemmArgs& a_in, hipStream_t stream) {
+  GemmArgs a = a_in;
+  // Row-major inside the band for every shape of the model (NT <= 16: measured neutral, profiles/r06_v33_gemm_walk.log); problems
+  // with 24 or more tile columns walk groups of 8 tile rows (8192^3: 1 309 -> 1 397 TFLOP/s - with one tile row per XCD round the
+  // 33 operand panels of a K step do not stay in the 4 MB L2)
+  a.walk_gm = g_gemm8p_walk >= 1 ? g_gemm8p_walk : ((a.N + 255) / 256 >= 24 ? 8 : 1);
   if (a.conv_c > 0 && a.conv_korder == 1) {  // slab-major VGG layers: the patch-resident kernel (conv_patch.hip, round 6)
     const int rc = conv_patch_try_launch(a, stream);
     if (rc <= 0) return rc;
