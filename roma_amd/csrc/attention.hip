@@ -162,11 +162,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnArgs a) {
 // on instruction issue 0.44).  Three of its four O(tile) VALU passes are removed here:
 //   * "s - m" (32 v_sub): the running reference m_ref enters the score MFMAs through their C operand - a 16-register
 //     block holding -m_ref - so the accumulators come out as q.k - m_ref and go straight into v_exp;
-//   * "o *= alpha" (16 v_pk_mul) and the per-tile alpha: m_ref is only moved when some query of the wave has a score more
-//     than THR = 2^8 above it (or on the first tile).  Until then P = 2^(s - m_ref) <= 256 - well inside bf16 / f16 -
-//     and numerator and denominator carry the same factor 2^(-m_ref), which cancels in O / l.  The decision is taken
-//     after the previous tile's P.V is complete and before this tile's P is exponentiated, so everything at the old
-//     reference (O, l) is scaled exactly once and nothing at the new one is;
+//   * "o *= alpha" (16 v_pk_mul) and the per-tile alpha: m_ref is only moved on the first tile and when some query of the
+//     wave has a tile whose P = 2^(s - m_ref) sum to more than 2^14 (rounds 3-5: when a score was more than 2^8 above the
+//     reference; the test moved from the scores to the row sums late in round 6, see the tile body).  Until then P is well
+//     inside bf16 / f16, and numerator and denominator carry the same factor 2^(-m_ref), which cancels in O / l.  The
+//     decision is taken after the previous tile's P.V is complete and before this tile's P enters l or O, so everything at
+//     the old reference (O, l) is scaled exactly once and nothing at the new one is;
 //   * (the row sums were also tried on the matrix cores - l as one more row block of the P.V product, an A fragment whose
 //     row 0 is all ones: 4 more MFMAs and 16 more registers per tile for 32 v_add less.  Slower at both head sizes,
 //     5.37 -> 5.48 ms and 1.10 -> 1.14 ms per step (profiles/r03_v9_attention.log): with the three passes above gone the
@@ -194,7 +195,6 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_h16_v2_kernel(cons
   constexpr int KV = 64;
   constexpr int KS = HD + 8, VS = KV + 4;  // LDS row pitches, as above
   constexpr int KT = KV / 32, DT = HD / 32, NS = HD / 16;
-  constexpr float THR = EXP2 ? 8.f : 5.5f;  // the same factor (2^8 ~ e^5.5) in either exponent domain
   // two tile buffers: tile t + 1 is staged while tile t is computed - ONE barrier per tile (36 / 70 KiB per workgroup)
   __shared__ __attribute__((aligned(16))) bf16_t Ksb[2][KV * KS];
   __shared__ __attribute__((aligned(16))) bf16_t Vsb[2][HD * VS];
@@ -267,100 +267,119 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_h16_v2_kernel(cons
   // for 0 and 1), so every staging write and fragment read is `base register + immediate` - the loop is bound by its VALU issue
   // slots, and selecting the buffer at run time cost ~10 address instructions per tile.  Same operations in the same order.
   int kv0 = 0;
-  auto tile = [&](auto curc) __attribute__((always_inline)) {
+  // Round 6 (late): the reference-move test leaves the common path.  Tiles after the first exponentiate straight away and look at
+  // the row sums they need anyway: a lane's 32 values of P are all <= their sum, so "sum <= 2^14" proves P <= 2^14 (inside
+  // binary16's range; bfloat16 has f32's) without the 32-deep max tree, its half-wave exchange and the register copies hipcc
+  // put on the not-taken side of the branch (~40 of the ~260 VALU issue slots of a tile).  If some valid query's sum exceeds
+  // the limit - or is not finite: 2^x overflows from x = 128 on - the wave re-does the tile the round-3 way: scores again from
+  // the K tile still in LDS, tile maximum, O and l moved to the new reference, P at the new reference.  Tile 0 always takes
+  // that path's first half (there is no reference yet).  Nothing at the old reference is mixed with anything at the new one:
+  // the P of the first attempt is discarded.
+  constexpr float LIM = 16384.f;
+#define ROMA_ATTN_SCORES()                                                                          \
+  _Pragma("unroll") for (int st = 0; st < NS; ++st) _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) { \
+    const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(&Ks[(32 * kt + l31) * KS + 16 * st + 8 * h]); \
+    s[kt] = mfma_h16_32x32x16(kf, qf[st], st == 0 ? cneg : s[kt]); /* scores relative to m_ref */    \
+  }                                                                                                 \
+  if (kv0 + KV > a.N) { /* only the last tile has keys >= N to mask (uniform branch) */            \
+    /* key = kv0 + 32 kt + 4 h + c_r with c_r = (r & 3) + 8 (r >> 2) a constant: one per-lane limit, constants compared */ \
+    /* against it (as `key >= N` per element the index arithmetic was hoisted out of the branch: 35 VALU on every tile)  */ \
+    int lim_ = a.N - kv0 - 4 * h;                                                                    \
+    asm volatile("" : "+v"(lim_));                                                                  \
+    _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) _Pragma("unroll") for (int r = 0; r < 16; ++r)  \
+        if (32 * kt + (r & 3) + 8 * (r >> 2) >= lim_) s[kt][r] = -INFINITY;                          \
+  }
+#define ROMA_ATTN_EXP_SUM()                                                                         \
+  _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) _Pragma("unroll") for (int r = 0; r < 16; ++r)    \
+      s[kt][r] = EXP2 ? __builtin_amdgcn_exp2f(s[kt][r]) : __expf(s[kt][r]);                        \
+  { /* row sums: four independent chains (one 32-deep chain of dependent adds is ~1.7 x slower to issue) */ \
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};                                                             \
+    _Pragma("unroll") for (int kt = 0; kt < KT; ++kt) _Pragma("unroll") for (int r = 0; r < 16; ++r) ls[r & 3] += s[kt][r]; \
+    lsum = (ls[0] + ls[1]) + (ls[2] + ls[3]);                                                       \
+  }
+  auto tile = [&](auto curc, auto firstc) __attribute__((always_inline)) {
     constexpr int cur = decltype(curc)::value;
+    constexpr bool FIRST = decltype(firstc)::value != 0;
     // stage tile t + 1 into the other buffer: every wave finished reading it (tile t - 1) before the barrier that ended
-      // the previous iteration; its loads were issued a whole tile ago
-      ROMA_ATTN_STAGE(cur ^ 1);
-      ROMA_ATTN_FETCH2(min(kv0 + 2 * KV, a.npad - KV));
-      const bf16_t* const Ks = Ksb[cur];
-      const bf16_t* const Vs = Vsb[cur];
-      f32x16 s[KT];
-      // the two 32-key chains interleaved: consecutive MFMAs never depend on each other
-#pragma unroll
-      for (int st = 0; st < NS; ++st) {
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-          const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(&Ks[(32 * kt + l31) * KS + 16 * st + 8 * h]);
-          s[kt] = mfma_h16_32x32x16(kf, qf[st], st == 0 ? cneg : s[kt]);  // scores relative to m_ref
-        }
+    // the previous iteration; its loads were issued a whole tile ago
+    ROMA_ATTN_STAGE(cur ^ 1);
+    ROMA_ATTN_FETCH2(min(kv0 + 2 * KV, a.npad - KV));
+    const bf16_t* const Ks = Ksb[cur];
+    const bf16_t* const Vs = Vsb[cur];
+    f32x16 s[KT];
+    float lsum = 0.f;
+    // the two 32-key chains interleaved: consecutive MFMAs never depend on each other
+    ROMA_ATTN_SCORES()
+    bool redo = FIRST;
+    if constexpr (!FIRST) {
+      ROMA_ATTN_EXP_SUM()
+      // wave-uniform decision.  Padding queries (qi >= N) have no vote: their Q rows are whatever the workspace holds (the
+      // model's DINOv2 and decoder layouts share it, so "padding" of one is data of the other), and a vote of theirs would make
+      // the rounding of the VALID queries of the wave depend on that leftover - seen as run-to-run differences of the last
+      // patch token, amplified by the coarse arg-max (profiles/r03_v24_*.log).
+      redo = __builtin_expect(__builtin_amdgcn_ballot_w64(qi < a.N && !(lsum <= LIM)) != 0, 0);
+      if (redo) {
+        ROMA_ATTN_SCORES()  // (two statements: scores and mask)
       }
-      if (kv0 + KV > a.N) {  // only the last tile has keys >= N to mask (uniform branch)
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kv0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (key >= a.N) s[kt][r] = -INFINITY;
-          }
-      }
+    }
+    if (__builtin_expect(redo, FIRST)) {  // always on tile 0, rare afterwards
       float tm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // four independent v_max3 chains, not one of 17
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) tm[(2 * kt + (r >> 3)) & 3] = fmaxf(tm[(2 * kt + (r >> 3)) & 3], s[kt][r]);
-      float tmax = attn_max_halves(fmaxf(fmaxf(tm[0], tm[1]), fmaxf(tm[2], tm[3])));
-      const bool first = kv0 == 0;
-      // wave-uniform decision: move the reference (rare after tile 0).  Padding queries (qi >= N) have no vote: their Q rows
-      // are whatever the workspace holds (the model's DINOv2 and decoder layouts share it, so "padding" of one is data of the
-      // other), and a vote of theirs would make the rounding of the VALID queries of the wave depend on that leftover - seen
-      // as run-to-run differences of the last patch token, amplified by the coarse arg-max (profiles/r03_v24_*.log).
-      if (__builtin_amdgcn_ballot_w64(first || (qi < a.N && tmax > THR)) != 0) {
-        const float delta = first ? tmax : fmaxf(tmax, 0.f);
-        if (!first) {  // O and l are still zero on the first tile (and alpha could overflow there)
-          const float alpha = EXP2 ? __builtin_amdgcn_exp2f(-delta) : __expf(-delta);
+      const float tmax = attn_max_halves(fmaxf(fmaxf(tm[0], tm[1]), fmaxf(tm[2], tm[3])));
+      const float delta = FIRST ? tmax : fmaxf(tmax, 0.f);
+      if constexpr (!FIRST) {  // O and l are still zero on the first tile (and alpha could overflow there)
+        const float alpha = EXP2 ? __builtin_amdgcn_exp2f(-delta) : __expf(-delta);
 #pragma unroll
-          for (int d = 0; d < DT; ++d)
+        for (int d = 0; d < DT; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-          l_run *= alpha;
-        }
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
-        m_ref += delta;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cneg[r] = -m_ref;
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        l_run *= alpha;
       }
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kt][r] = EXP2 ? __builtin_amdgcn_exp2f(s[kt][r]) : __expf(s[kt][r]);
-      {  // row sums: four independent chains (one 32-deep chain of dependent adds is ~1.7 x slower to issue)
-        float ls[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
+      m_ref += delta;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+      for (int r = 0; r < 16; ++r) cneg[r] = -m_ref;
+      ROMA_ATTN_EXP_SUM()
+    }
+    l_run += lsum;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) ls[r & 3] += s[kt][r];
-        l_run += (ls[0] + ls[1]) + (ls[2] + ls[3]);
-      }
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
+      for (int u = 0; u < 2; ++u) {
+        u32x4_t pk;
+        pk.x = pack_bf16x2(s[kt][8 * u + 0], s[kt][8 * u + 1]);
+        pk.y = pack_bf16x2(s[kt][8 * u + 2], s[kt][8 * u + 3]);
+        pk.z = pack_bf16x2(s[kt][8 * u + 4], s[kt][8 * u + 5]);
+        pk.w = pack_bf16x2(s[kt][8 * u + 6], s[kt][8 * u + 7]);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          u32x4_t pk;
-          pk.x = pack_bf16x2(s[kt][8 * u + 0], s[kt][8 * u + 1]);
-          pk.y = pack_bf16x2(s[kt][8 * u + 2], s[kt][8 * u + 3]);
-          pk.z = pack_bf16x2(s[kt][8 * u + 4], s[kt][8 * u + 5]);
-          pk.w = pack_bf16x2(s[kt][8 * u + 6], s[kt][8 * u + 7]);
-#pragma unroll
-          for (int d = 0; d < DT; ++d) {
-            const bf16_t* vrow = &Vs[(32 * d + l31) * VS + 32 * kt + 16 * u + 4 * h];
-            const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(vrow);
-            const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(vrow + 8);
-            o[d] = mfma_h16_32x32x16(u32x4_t{lo.x, lo.y, hi.x, hi.y}, pk, o[d]);
-          }
+        for (int d = 0; d < DT; ++d) {
+          const bf16_t* vrow = &Vs[(32 * d + l31) * VS + 32 * kt + 16 * u + 4 * h];
+          const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(vrow);
+          const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(vrow + 8);
+          o[d] = mfma_h16_32x32x16(u32x4_t{lo.x, lo.y, hi.x, hi.y}, pk, o[d]);
         }
-      __syncthreads();
+      }
+    __syncthreads();
   };
+  using c0 = std::integral_constant<int, 0>;
+  using c1 = std::integral_constant<int, 1>;
+  tile(c0{}, c1{});  // tile 0 sets the reference
+  kv0 += KV;
   while (kv0 < a.N) {
-    tile(std::integral_constant<int, 0>{});
+    tile(c1{}, c0{});
     kv0 += KV;
     if (kv0 >= a.N) break;
-    tile(std::integral_constant<int, 1>{});
+    tile(c0{}, c0{});
     kv0 += KV;
   }
+#undef ROMA_ATTN_SCORES
+#undef ROMA_ATTN_EXP_SUM
   float l = l_run;
   l += __shfl_xor(l, 32);
   const float inv = 1.f / l;
