@@ -427,7 +427,17 @@ int Model::pack_weights() {
   }
   if (int rc = upload_f32(H("dinov2.norm.weight"), &dino_nw)) return rc;
   if (int rc = upload_f32(H("dinov2.norm.bias"), &dino_nb)) return rc;
-  if (int rc = make_lin(H("decoder.embedding_decoder.to_out.weight"), &H("decoder.embedding_decoder.to_out.bias"), 4097, 1024, &to_out)) return rc;
+  {
+    // 4097 = 64 * 64 anchors + 1 is not a multiple of 4, which keeps the f32 row writers of the 8-phase kernels away (the launch
+    // fell to the classic 128 x 128 kernel: 4 launches of 183 us per step at 0.4 PFLOP/s).  Three zero rows (weights and bias)
+    // make it 4100: logits columns 4097 .. 4099 come out 0 and nobody reads them (ldl = 4104 below; cls_to_flow takes 4097).
+    const auto& w0 = H("decoder.embedding_decoder.to_out.weight");
+    const auto& b0 = H("decoder.embedding_decoder.to_out.bias");
+    std::vector<float> wpad((size_t)4100 * 1024, 0.f), bpad(4100, 0.f);
+    memcpy(wpad.data(), w0.data(), (size_t)4097 * 1024 * sizeof(float));
+    memcpy(bpad.data(), b0.data(), (size_t)4097 * sizeof(float));
+    if (int rc = make_lin(wpad, &bpad, 4100, 1024, &to_out)) return rc;
+  }
   if (int rc = upload_f32(H("decoder.gps.16.pos_conv.weight"), &gp_w)) return rc;
   if (int rc = upload_f32(H("decoder.gps.16.pos_conv.bias"), &gp_b)) return rc;
   // ---- proj heads (conv1x1 + BN folded)
@@ -1147,7 +1157,7 @@ int Model::match_impl(int B, const float* ima, const float* imb, const float* im
         {
           GemmArgs g;
           g.A = zin; g.lda = 1024; g.W = to_out.w; g.ldw = to_out.ldw; g.C = logits; g.ldc = ldl;
-          g.M = (int)rows_t; g.N = 4097; g.K = 1024; g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = to_out.b;
+          g.M = (int)rows_t; g.N = to_out.N; g.K = 1024; g.in_dt = act_dt; g.out_dt = DT_F32; g.bias = to_out.b;  // 4100: 4097 + 3 zero rows
           RUN(gemm_launch(g, st));
         }
         if (debug && !dry)
