@@ -636,6 +636,9 @@ __global__ __launch_bounds__(256) void refiner_input_small_kernel(const RefinerI
 template <typename T> struct VecIO;
 template <> struct VecIO<float> {
   static constexpr int CV = 4;
+  typedef f32x4 Raw;  // 16 bytes as loaded; cvt() turns them into CV floats (the same values ld() delivers)
+  __device__ static inline Raw ldraw(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  __device__ static inline void cvt(const Raw& x, float* v) { v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3]; }
   __device__ static inline void ld(const float* p, float* v) {
     const f32x4 x = *reinterpret_cast<const f32x4*>(p);
     v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
@@ -644,6 +647,14 @@ template <> struct VecIO<float> {
 };
 template <> struct VecIO<bf16_t> {
   static constexpr int CV = 8;
+  typedef uint4 Raw;
+  __device__ static inline Raw ldraw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  __device__ static inline void cvt(const Raw& u, float* v) {
+    v[0] = h16_lo(u.x); v[1] = h16_hi(u.x);
+    v[2] = h16_lo(u.y); v[3] = h16_hi(u.y);
+    v[4] = h16_lo(u.z); v[5] = h16_hi(u.z);
+    v[6] = h16_lo(u.w); v[7] = h16_hi(u.w);
+  }
   __device__ static inline void ld(const bf16_t* p, float* v) {
     const uint4 u = *reinterpret_cast<const uint4*>(p);
     v[0] = h16_lo(u.x); v[1] = h16_hi(u.x);
@@ -1122,44 +1133,64 @@ __global__ __launch_bounds__(256) void refiner_out_vec_kernel(const T* d, long l
   constexpr int CV = VecIO<T>::CV;
   const int lane = threadIdx.x & 63;
   const int sub = lane & (lpr - 1), rw = lane / lpr, rpw = 64 / lpr;
+  // the lane's 3 x NK x CV out_conv weights, fetched as 16-byte pieces with a clamped index and selected afterwards (Cp is a
+  // multiple of CV, refiner_out_launch checks w's alignment).  As 120 guarded 4-byte loads - a branch around each - this
+  // prologue took a third of a workgroup's life at Cp = 576 (round 6, late: tools/bench_refiner_out.py).
   float wr[NK][3][CV];
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int c = (sub + k * lpr) * CV;
+    const bool okc = c < Cp;
 #pragma unroll
     for (int o = 0; o < 3; ++o)
 #pragma unroll
-      for (int j = 0; j < CV; ++j) wr[k][o][j] = c < Cp ? w[(long)o * Cp + c + j] : 0.f;
+      for (int j4 = 0; j4 < CV; j4 += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(w + (long)o * Cp + (okc ? c : 0) + j4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wr[k][o][j4 + u] = okc ? t[u] : 0.f;
+      }
   }
   const float b0 = bb[0], b1 = bb[1], b2 = bb[2];
   const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw * rows_it + rw;
-#pragma unroll 4
-  for (int it = 0; it < rows_it; ++it) {  // unrolled: the loads of 4 row groups are in flight together
-    const long row = row0 + (long)it * rpw;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    // the running flow / certainty are fetched with the activations, not after the reduction (a dependent
-    // load -> add -> store tail per row group otherwise)
+  // Round 6 (late): the row groups are software-pipelined - the 16-byte pieces (and flow / certainty) of group it + 1 are
+  // requested BEFORE the ~240 VALU instructions and the shuffle reduction of group it, into a second register set (the loop
+  // runs in pairs, so the two sets swap roles without moves).  The `#pragma unroll 4` this replaces never happened (rows_it
+  // is a run-time value): a wave had 5 x 16 bytes per lane in flight, waited, computed with nothing in flight - 1.9 TB/s
+  // at Cp = 576 / 1152 (profiles/r06_final_bench_mixed_kernel_stats.csv of commit 49f591d: 0.98 ms per step for 1.83 GB).
+  // Same loads, same arithmetic in the same order: bit-identical.
+  typedef typename VecIO<T>::Raw Raw;
+  struct Group {
+    Raw v[NK];
+    float f0, f1, c0;
+  };
+  auto fetch = [&](Group& g, long row) __attribute__((always_inline)) {
     // branch-free loads (clamped row and chunk, select afterwards): inside exec-masked blocks hipcc waits for every load on
     // its own, and this kernel is nothing but loads (1.5 TB/s at Cp = 144 with the guarded form)
     const long rowc = row < M ? row : M - 1;
-    const float f0 = flow[rowc * 2 + 0], f1 = flow[rowc * 2 + 1], c0 = cert[rowc];
-    {
-      float v[NK][CV];
+    // the running flow / certainty are fetched with the activations, not after the reduction (a dependent
+    // load -> add -> store tail per row group otherwise)
+    g.f0 = flow[rowc * 2 + 0];
+    g.f1 = flow[rowc * 2 + 1];
+    g.c0 = cert[rowc];
 #pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const int c = (sub + k * lpr) * CV;
-        VecIO<T>::ld(d + rowc * ldd + (c < Cp ? c : 0), v[k]);
-      }
+    for (int k = 0; k < NK; ++k) {
+      const int c = (sub + k * lpr) * CV;
+      g.v[k] = VecIO<T>::ldraw(d + rowc * ldd + (c < Cp ? c : 0));
+    }
+  };
+  auto finish = [&](const Group& g, long row) __attribute__((always_inline)) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const bool ok = (sub + k * lpr) * CV < Cp;
+    for (int k = 0; k < NK; ++k) {
+      float v[CV];
+      VecIO<T>::cvt(g.v[k], v);
+      const bool ok = (sub + k * lpr) * CV < Cp;
 #pragma unroll
-        for (int j = 0; j < CV; ++j) {
-          const float x = ok ? v[k][j] : 0.f;
-          a0 = fmaf(x, wr[k][0][j], a0);
-          a1 = fmaf(x, wr[k][1][j], a1);
-          a2 = fmaf(x, wr[k][2][j], a2);
-        }
+      for (int j = 0; j < CV; ++j) {
+        const float x = ok ? v[j] : 0.f;
+        a0 = fmaf(x, wr[k][0][j], a0);
+        a1 = fmaf(x, wr[k][1][j], a1);
+        a2 = fmaf(x, wr[k][2][j], a2);
       }
     }
     for (int off = lpr >> 1; off >= 1; off >>= 1) {
@@ -1168,10 +1199,19 @@ __global__ __launch_bounds__(256) void refiner_out_vec_kernel(const T* d, long l
       a2 += __shfl_xor(a2, off);
     }
     if (row < M && sub == 0) {
-      flow[row * 2 + 0] = f0 + sx * (a0 + b0);
-      flow[row * 2 + 1] = f1 + sy * (a1 + b1);
-      cert[row] = c0 + (a2 + b2);
+      flow[row * 2 + 0] = g.f0 + sx * (a0 + b0);
+      flow[row * 2 + 1] = g.f1 + sy * (a1 + b1);
+      cert[row] = g.c0 + (a2 + b2);
     }
+  };
+  Group ga, gb;
+  fetch(ga, row0);
+  for (int it = 0; it < rows_it; it += 2) {  // rows_it is even (refiner_out_launch)
+    const long row = row0 + (long)it * rpw;
+    fetch(gb, row + rpw);
+    finish(ga, row);
+    if (it + 2 < rows_it) fetch(ga, row + 2 * rpw);  // uniform
+    finish(gb, row + rpw);
   }
 }
 
@@ -1249,7 +1289,7 @@ int refiner_out_launch(const void* d, long ldd, int dt, const float* w, const fl
   {
     const int cv = dt == DT_F32 ? 4 : 8;
     const int chunks = Cp / cv;
-    if (Cp % cv == 0 && ldd % cv == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 && chunks >= 1) {
+    if (Cp % cv == 0 && ldd % cv == 0 && (reinterpret_cast<uintptr_t>(d) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 && chunks >= 1) {
       int lpr = 1;
       while (lpr < 64 && lpr * 2 <= chunks) lpr *= 2;       // largest power of two <= chunks (<= 64)
       // bf16: chunk counts just above a power of two (18, 72, 144) leave 44 % of the lane-pieces of that split empty (the
@@ -1273,7 +1313,10 @@ int refiner_out_launch(const void* d, long ldd, int dt, const float* w, const fl
       }
       const int nk = (chunks + lpr - 1) / lpr;              // 16-byte pieces per lane per row
       if (nk <= 6) {
-        const int rows_it = 8;
+        // 8 row groups per wave.  (With the weight prologue as guarded scalar loads 32 groups were 1.5 x faster than 8; with the
+        // 16-byte prologue 8 and 16 are equal and 32 loses on the sub-batch sizes - profiles/r06_v39_*.  ROMA_OUT_ROWS_IT: A/B, even.)
+        static const int rows_it_env = getenv("ROMA_OUT_ROWS_IT") ? atoi(getenv("ROMA_OUT_ROWS_IT")) : 0;
+        const int rows_it = rows_it_env >= 2 ? rows_it_env & ~1 : 8;
         const long rows_per_block = 4l * (64 / lpr) * rows_it;
         dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block));
 #define ROMA_ROV(NKV)                                                                                          \
