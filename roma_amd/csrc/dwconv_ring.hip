@@ -265,7 +265,11 @@ int dwconv5x5_ring_try_launch(const void* in, void* out, const float* w, const f
   {
     long best = -1;
     const long per_strip = (long)B * nxg * nchunk;
-    for (int ns = (H + 47) / 48; ns <= std::max(1, H / 6); ++ns) {
+    // (Rounds 3-6 capped a strip at 48 rows; without the cap the five wide shapes are 2.5 % faster in sum - 16 x 108^2 x 1152
+    // 231 -> 216 us, 8 x 216^2 x 576 235 -> 224 - and none slower beyond noise: profiles/r06_v41_dwconv_strip_height.log.
+    // ROMA_DWR_MAXSY: A/B.)
+    static const int max_sy = getenv("ROMA_DWR_MAXSY") ? std::max(6, atoi(getenv("ROMA_DWR_MAXSY"))) : (1 << 20);
+    for (int ns = (H + max_sy - 1) / max_sy; ns <= std::max(1, H / 6); ++ns) {
       const int sy = (H + ns - 1) / ns;
       const long nt = per_strip * ((H + sy - 1) / sy);
       const long cost = ((nt + 2047) / 2048) * (sy + 7);
