@@ -687,6 +687,36 @@ def test_dma_ring_kernels_keep_their_queue(built_lib, bdir):
 
 
 @pytest.mark.parametrize("bdir", BUILD_DIRS)
+def test_refiner_out_conv_kernel_prologue_and_pipeline(built_lib, bdir):
+    """Round 6 (late): the wide-scale out_conv kernel ran at 2.0 TB/s for two reasons that only the ISA shows - the lane's 120
+    weights arrived as 120 guarded 4-byte loads with a branch around each (a third of a workgroup's life), and the row loop had
+    one group's 5 x 16-byte loads in flight, then none while it computed.  Held on the built object for the Cp = 576 / 1152
+    instantiation (16-bit, NK = 5): the weights come as 16-byte loads (no 4-byte global load in the kernel but the running flow /
+    certainty values per group and the bias), and the kernel holds the arithmetic of TWO row groups (the pair loop)."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from audit_asm_reads import extract_code_object
+    obj = os.path.join(ROOT, "roma_amd", "csrc", bdir, "elementwise.o")
+    if not os.path.exists(obj):
+        pytest.skip("object files not present (library shipped pre-built)")
+    dis = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", extract_code_object(obj)], capture_output=True, text=True,
+                         check=True).stdout
+    kerns = [k for k in re.split(r"\n(?=[0-9a-f]+ <_Z)", dis) if re.match(r"[0-9a-f]+ <_ZN4roma22refiner_out_vec_kernelItLi5EE", k)]
+    assert len(kerns) == 1, len(kerns)
+    lines = kerns[0].splitlines()
+    op = [ln.split("//")[0].split() for ln in lines[1:] if ln.strip()]
+    ops = [o[0] for o in op if o]
+    n4 = sum(o == "global_load_dword" for o in ops)
+    n16 = sum(o == "global_load_dwordx4" for o in ops)
+    # 30 weight pieces + 5 per row group in the prologue / the two loop halves (3 x 5) + slack for the compiler's peeling
+    assert n16 >= 40, n16
+    assert n4 <= 16, n4  # flow (8 bytes, may be one dwordx2) / certainty per group and b[0..2]: never one per weight
+    # both halves of the pair loop are in the kernel: two row groups' worth of FMAs (117 each) between the loop's loads
+    fma = sum(o in ("v_fmac_f32_e32", "v_fma_f32", "v_fmac_f32_e64") for o in ops)
+    assert fma >= 2 * 110, fma
+
+
+@pytest.mark.parametrize("bdir", BUILD_DIRS)
 def test_isa_audit_counted_vmcnt_waits_leave_only_loads_in_flight(built_lib, bdir):
     """Every hand-counted `s_waitcnt vmcnt(N)` that guards an LDS-DMA piece - GEMMs (gemm, gemm8p, gemm6p, ws1x1, conv64), the ring
     kernels and the fused refiner blocks - may only leave LOADS in flight: a store inside the allowance can retire before the
